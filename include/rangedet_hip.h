@@ -1,0 +1,174 @@
+/* rangedet_hip.h -- C ABI of librangedet_hip.so: the MI355X (gfx950) RangeDet inference hot path.
+ *
+ * Every entry point replaces one piece of the reference's native/operator surface for this path
+ * (citations relative to /root/reference; see INTEGRATION.md for the binding a maintainer would add):
+ *
+ *   rd_meta_kernel_fwd        MetaKernel.meta_baseline_bias + BN/ReLU/1x1/BN/ReLU
+ *                             rangedet/symbol/backbone/meta_kernel.py:166-240, dla_backbone.py:92-97
+ *   rd_conv2d_bn_act          mx.sym.Convolution + BatchNorm (+ReLU, +residual)   mxnext/simple.py:123-158,
+ *                             mxnext/complicate.py:26-45, dla_backbone.py:18-56, head/builder.py:221-240
+ *   rd_deconv2d_bn_act        mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
+ *                             dla_backbone.py:117-127
+ *   rd_head_out               1x1 logit / delta convs + cast + per-class flatten  head/builder.py:242-261,99-154
+ *   rd_sorted_foreground      Custom op 'get_sorted_foreground'                   operator_py/get_sorted_foreground.py:11-40
+ *   rd_decode3d_bbox          _contrib_Decode3DBbox                               operator_cxx/contrib/decode_3d_bbox-inl.h:169-305
+ *   rd_score_filter_dets      score filter + bbox3d_10dim_to_11dim                tools/test.py:56-81,200-209
+ *   rd_wnms_4c                processing_cxx.wnms_4c                              operator_cxx/src_cxx/nms.h:452-577,781-794
+ *   rd_wnms_order_host        the std::sort ordering of point4_wnms_4c            operator_cxx/src_cxx/nms.h:786-792
+ *   rd_dets12_to_8            bbox3d_12dim_to_8dim                                tools/test.py:43-53
+ *   rd_rotated_iou_8pt        _contrib_RotatedIOU (8-point boxes)                 operator_cxx/contrib/rotated_iou-inl.h:509-547
+ *   rd_batch_max_iou          Custom op 'batch_rotated_iou' ('bev')               operator_py/batch_rotated_iou.py:11-49
+ *
+ * Conventions
+ *   - every function returns an int status (RD_OK == 0, negative = error); nothing aborts or exits.
+ *     rd_last_error_string() gives a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every buffer,
+ *     including workspaces (size them with the *_workspace_bytes functions).  The library never allocates
+ *     on the hot path and never keeps a pointer past the call.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are re-entrant.
+ *   - activations inside the library are channels-last: [B][H][W][Cstride] with the used channels at
+ *     [coff, coff+C); element type RD_F32 (float) or RD_BF16 (raw uint16 bfloat16).
+ *     rd_nchw_to_nhwc / rd_nhwc_to_nchw convert at the reference's NCHW float32 boundary.
+ */
+#ifndef RANGEDET_HIP_H_
+#define RANGEDET_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_EINVAL (-1)     /* bad argument value                       */
+#define RD_ESHAPE (-2)     /* shape the kernels do not support / mismatch (mirrors the reference's CHECKs) */
+#define RD_EWORKSPACE (-3) /* workspace too small                      */
+#define RD_EHIP (-4)       /* HIP runtime error                        */
+
+#define RD_F32 0
+#define RD_BF16 1
+
+/* epilogue flags of the conv family */
+#define RD_RELU_PRE 1  /* ReLU directly after the BN affine (before the residual add)        */
+#define RD_ADD 2       /* add `residual`                                                     */
+#define RD_RELU_POST 4 /* ReLU after the residual add                                        */
+
+int rd_version(void);
+const char* rd_last_error_string(void);
+
+/* ---- layout -------------------------------------------------------------------------------------- */
+/* src NCHW float32 (B,C,H,W) -> dst channels-last [B][H][W][dst_cstride] at channel offset dst_coff.
+ * Channels [C, C+zero_pad) are written as zeros (zero_pad may be 0). */
+int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dst_cstride, int dst_coff,
+                    int zero_pad, int dst_dtype, void* stream);
+int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int src_cstride, int src_coff,
+                    int src_dtype, void* stream);
+
+/* ---- weight packing (HOST, no GPU needed) ---------------------------------------------------------- */
+/* Packed conv weights: [ntaps][nchunk][Cout][8 slots * (16/elem) channels], zero padded; one k-chunk =
+ * 8 slots of 16 bytes.  rd_conv_packed_bytes gives the size.  w_oihw_host is (Cout,Cin,KH,KW) float32
+ * (mx Convolution layout); deconv weight is (Cin,Cout,KH,KW) (mx Deconvolution layout) and is packed per
+ * output phase (phase = ow % stride_w) -- rd_deconv_phase_taps tells how many taps a phase has. */
+size_t rd_conv_packed_bytes(int ntaps, int cin, int cout, int dtype);
+int rd_pack_conv_weight_host(const float* w_oihw_host, int cout, int cin, int kh, int kw, int dtype,
+                             void* packed_host);
+int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase);
+int rd_pack_deconv_weight_host(const float* w_iohw_host, int cin, int cout, int kh, int kw, int stride_w,
+                               int pad_w, int phase, int dtype, void* packed_host);
+
+/* ---- conv family ------------------------------------------------------------------------------------ */
+/* y = act( scale[c]*conv(x, w) + shift[c] (+ residual) ).  stride_h == 1 always (the backbone strides W
+ * only, dla_backbone.py:139-143); kernel (kh,kw) in {(1,1),(3,3)}; pad = (k-1)/2 as mxnext/simple.py:131-135.
+ * cout in {64,128}.  x: [B][H][Win][x_cstride] channels [x_coff, x_coff+cin); cin is rounded up internally to
+ * the packing granule and the buffer must hold zeros there. */
+int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
+                     const float* shift, const void* residual, int r_cstride, int r_coff, void* y,
+                     int y_cstride, int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw,
+                     int stride_w, int flags, int dtype, void* stream);
+/* Transposed conv, kernel (3,kw), stride (1,stride_w), pad (1,pad_w); one call per output phase. */
+int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase,
+                       const float* scale, const float* shift, const void* residual, int r_cstride,
+                       int r_coff, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
+                       int cout, int kh, int kw, int stride_w, int pad_w, int phase, int flags, int dtype,
+                       void* stream);
+
+/* 1x1 conv with bias to nout <= 8 float32 outputs per pixel, written flattened: out[(n_off + h*W + w)*nout + o]
+ * (== the (B, N, nout) tensor after sep_level_type's reshape/transpose/concat; nout == 1 gives (B, N)).
+ * w: (nout, cin) float32 device, bias: (nout).  out_batch_stride in elements. */
+int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const float* bias, float* out,
+                long out_batch_stride, long n_off, int B, int H, int W, int cin, int nout, int dtype,
+                void* stream);
+
+/* ---- Meta-Kernel unit ------------------------------------------------------------------------------- */
+/* Packed parameter block for rd_meta_kernel_fwd (HOST).  Inputs in the reference's layouts:
+ * w0 (32,3) b0 (32) w1 (64,32) b1 (64) [mlp0/mlp1 1x1 convs], s1,t1 (576) [BN folded, index c*9+k],
+ * agg (64,576) [aggregation_conv1], s2,t2 (64).  */
+size_t rd_meta_packed_bytes(int dtype);
+int rd_pack_meta_host(const float* w0, const float* b0, const float* w1, const float* b1, const float* s1,
+                      const float* t1, const float* agg, const float* s2, const float* t2, int dtype,
+                      void* packed_host);
+/* data: [B][H][W][d_cstride] (64 channels at d_coff), coord: NCHW float32 (B,3,H,W) as the reference's
+ * coord_s1 variable, y: [B][H][W][y_cstride] 64 channels at y_coff. */
+int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float* coord_nchw,
+                       const void* packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype,
+                       void* stream);
+
+/* ---- post-processing -------------------------------------------------------------------------------- */
+size_t rd_sorted_foreground_workspace_bytes(long N, long k);
+/* cls_score (B,N) [logits when apply_sigmoid != 0], bbox_delta (B,N,D), pc (B,N,3), mask (B,N) ->
+ * sorted_fg_score (B,k), sorted_fg_bbox_delta (B,k,D), sorted_fg_pc (B,k,3); optional sorted_idx (B,k) int32.
+ * Order: score*mask descending, ties by flat index ascending.  Requires N >= k (get_sorted_foreground.py:65). */
+int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const float* pc, const float* mask,
+                         int B, long N, long k, int D, int apply_sigmoid, float* out_score, float* out_delta,
+                         float* out_pc, int* out_idx, void* ws, size_t ws_bytes, void* stream);
+
+/* bbox_delta (B,N,box_type) + pc (B,N,3) -> (B,N,10); box_type 8 (is_bin=0) or 7 (is_bin=1)
+ * (shape checks of decode_3d_bbox.cc:30-49). */
+int rd_decode3d_bbox(const float* bbox_delta, const float* pc, float* out, int B, long N, int box_type,
+                     int is_bin, void* stream);
+
+/* scores (n), boxes10 (n,10) -> dets (K,12) rows [8 corners, yaw, bottom, height, score] for score > min_score,
+ * input order preserved; *d_count (device int) = K.  dets must hold n rows. */
+size_t rd_score_filter_workspace_bytes(long n);
+int rd_score_filter_dets(const float* scores, const float* boxes10, long n, float min_score, float* dets,
+                         int* d_count, void* ws, size_t ws_bytes, void* stream);
+
+/* Weighted NMS.  dets (Kcap,12) device; the number of valid rows is *d_count when d_count != NULL, else Kcap.
+ * order: device int32 (Kcap) processing order (sorted positions -> row index), or NULL = the library sorts on
+ * the device (score descending, ties by row index ascending).  Outputs: out_dets (Kcap,12), keep (Kcap) row
+ * indices into dets, *d_nkeep = M.  Kcap <= RD_WNMS_MAX_K. */
+#define RD_WNMS_MAX_K 16384
+size_t rd_wnms_workspace_bytes(int Kcap);
+int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh,
+               float thresh_vote, int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws,
+               size_t ws_bytes, void* stream);
+/* HOST: the reference's own ordering (std::sort, score descending, unstable) for dets_host (K,12). */
+int rd_wnms_order_host(const float* dets_host, int K, int* order_host);
+
+/* dets12 (M,12) -> (M,8) [cx,cy,cz,l,w,h,heading,score]; count from *d_count when not NULL. */
+int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out8, void* stream);
+
+/* 8-point rotated IoU: boxes1 (n1,8) x boxes2 (n2,8) -> ious (n1,n2). */
+int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream);
+/* per proposal: max over gt of the cleaned IoU (NaN/Inf/>1/<0 -> 0).  proposals (n, p_stride>=8) */
+int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt,
+                     void* stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline block) --------- */
+#define RD_PROF_CONV 0
+#define RD_PROF_META 1
+#define RD_PROF_HEAD_OUT 2
+#define RD_PROF_SORT 3
+#define RD_PROF_DECODE 4
+#define RD_PROF_WNMS 5
+#define RD_PROF_LAYOUT 6
+#define RD_PROF_NKINDS 7
+int rd_prof_enable(int on);
+int rd_prof_reset(void);
+/* synchronises the recorded events; total_ms / launches per kind */
+int rd_prof_get(int kind, double* total_ms, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANGEDET_HIP_H_ */

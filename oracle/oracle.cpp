@@ -1,0 +1,425 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported, linked or executed by the product path
+// (rangedet_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+//
+// CPU restatement (own structure, same float operation order) of the native pieces of the RangeDet
+// inference hot path.  Citations are relative to /root/reference:
+//   * weighted NMS            operator_cxx/src_cxx/nms.h:452-577 (wnms_4c), :781-794 (point4_wnms_4c)
+//   * BEV / volume IoU        operator_cxx/src_cxx/nms.h:32-250  (OverlapChecker)
+//   * hash prefilter          operator_cxx/src_cxx/nms.h:252-307 (BBoxHash)
+//   * Decode3DBbox            operator_cxx/contrib/decode_3d_bbox-inl.h:64-277
+//   * 8-point rotated IoU     operator_cxx/contrib/rotated_iou-inl.h:49-128,130-172,388-493
+//
+// Pinning status:
+//   wnms / single_overlap : PINNED against the reference source compiled as-is (oracle/_ref, built by
+//                           `make -C oracle ref`; tests/test_oracle_pin.py + tests/golden/*.npz).
+//   decode / rotated IoU  : PARITY UNPINNED.  The reference kernels live in headers that need MXNet's
+//                           internal headers (absent here) so they cannot be built; the reference has no
+//                           tests or golden vectors.  This file follows the cited lines literally.
+//
+// Build: g++ -O3 -ffp-contract=off -shared -fPIC (baseline x86-64, no -march: matches the reference's
+// CMake flags `-O3`, operator_cxx/src_cxx/CMakeLists.txt:19, so no FMA contraction anywhere).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// BEV IoU by half-plane intersection  (nms.h:32-250)
+// ----------------------------------------------------------------------------------------------
+struct Pt { float x, y; };
+struct Edge { Pt a, b; float ang; };
+
+constexpr float kEps = 1e-5f;  // nms.h:35
+
+inline int sgn_eps(float k) {  // nms.h:48-52
+  if (std::fabs(k) < kEps) return 0;
+  return k > 0 ? 1 : -1;
+}
+inline float cross3(Pt o, Pt u, Pt v) {  // nms.h:54-56
+  return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x);
+}
+inline bool edge_less(const Edge& e1, const Edge& e2) {  // nms.h:58-64
+  int d = sgn_eps(e1.ang - e2.ang);
+  if (!d) return sgn_eps(cross3(e1.a, e2.a, e2.b)) > 0;
+  return d < 0;
+}
+inline Pt line_meet(const Edge& e1, const Edge& e2) {  // nms.h:74-83
+  float A1 = e1.b.y - e1.a.y;
+  float B1 = e1.a.x - e1.b.x;
+  float C1 = (e1.b.x - e1.a.x) * e1.a.y - (e1.b.y - e1.a.y) * e1.a.x;
+  float A2 = e2.b.y - e2.a.y;
+  float B2 = e2.a.x - e2.b.x;
+  float C2 = (e2.b.x - e2.a.x) * e2.a.y - (e2.b.y - e2.a.y) * e2.a.x;
+  Pt p;
+  p.x = (C2 * B1 - C1 * B2) / (A1 * B2 - A2 * B1);
+  p.y = (C1 * A2 - C2 * A1) / (A1 * B2 - A2 * B1);
+  return p;
+}
+inline bool outside(const Edge& e0, const Edge& e1, const Edge& e2) {  // nms.h:85-90 (judge)
+  Pt p = line_meet(e1, e2);
+  return sgn_eps(cross3(p, e0.a, e0.b)) > 0;
+}
+
+struct Clipper {
+  Pt p[16];
+  Edge l[16];
+  int dq[16];
+  int pn;
+
+  float fan_area(int s, int e) const {  // nms.h:151-166
+    if (e - s < 3) return 0;
+    float area = 0;
+    for (int i = s + 1; i < e - 1; i++) area += cross3(p[s], p[i], p[i + 1]);
+    if (area < 0) area = -area;
+    return area / 2;
+  }
+  void load_box(const float* box, int s) {  // nms.h:186-194
+    for (int k = 0; k < 4; ++k) {
+      p[s + k].x = box[2 * k];
+      p[s + k].y = box[2 * k + 1];
+    }
+    const Pt &p0 = p[s], &p1 = p[s + 1], &p2 = p[s + 2];
+    bool cw = ((p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y)) > 0;  // nms.h:92-94
+    if (cw) std::reverse(p + s, p + s + 4);
+  }
+  static void make_edge(Edge& e, Pt a, Pt b) {  // nms.h:66-72
+    e.a = a;
+    e.b = b;
+    e.ang = atan2f(b.y - a.y, b.x - a.x);
+  }
+  void half_plane_intersection() {  // nms.h:96-149
+    const int n = 8;
+    std::sort(l, l + n, edge_less);
+    int i, j;
+    for (i = 0, j = 0; i < n; i++)
+      if (sgn_eps(l[i].ang - l[j].ang) > 0) l[++j] = l[i];
+    int t = j + 1;
+    dq[0] = 0;
+    dq[1] = 1;
+    int top = 1, bot = 0;
+    for (i = 2; i < t; i++) {
+      while (top > bot && outside(l[i], l[dq[top]], l[dq[top - 1]])) top--;
+      while (top > bot && outside(l[i], l[dq[bot]], l[dq[bot + 1]])) bot++;
+      dq[++top] = i;
+    }
+    while (top > bot && outside(l[dq[bot]], l[dq[top]], l[dq[top - 1]])) top--;
+    while (top > bot && outside(l[dq[top]], l[dq[bot]], l[dq[bot + 1]])) bot++;
+    dq[++top] = dq[bot];
+    for (pn = 8, i = bot; i < top; i++, pn++) p[pn] = line_meet(l[dq[i + 1]], l[dq[i]]);
+  }
+  float overlap(const float* box1, const float* box2, bool is3d) {  // nms.h:195-249
+    float h1 = -1, h2 = -1, oh = -1;
+    if (is3d) {
+      h1 = box1[10];
+      h2 = box2[10];
+      float bot1 = box1[9], top1 = bot1 + box1[10];  // nms.h:172-184
+      float bot2 = box2[9], top2 = bot2 + box2[10];
+      float min_top = (top1 > top2) ? top2 : top1;
+      float max_bot = (bot1 > bot2) ? bot1 : bot2;
+      float d = min_top - max_bot;
+      oh = d > 0 ? d : 0;
+    }
+    load_box(box2, 0);
+    float area2 = fan_area(0, 4);
+    std::memset(dq, 0, sizeof(dq));
+    load_box(box1, 4);
+    for (int z = 0; z < 4; ++z) {
+      make_edge(l[z], p[z], p[(z + 1) % 4]);
+      make_edge(l[z + 4], p[z + 4], p[(z + 1) % 4 + 4]);
+    }
+    float area1 = fan_area(4, 8);
+    half_plane_intersection();
+    float inter = fan_area(8, pn);
+    if (is3d) {
+      inter *= oh;
+      area1 *= h1;
+      area2 *= h2;
+    }
+    return inter / (area1 + area2 - inter);
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Hash prefilter (nms.h:252-307), including its quirks: numeric_limits<float>::min() as the initial
+// maximum, x-scale used for both minima / y-scale for both maxima, int16 casts, key = i*100 + j.
+// ----------------------------------------------------------------------------------------------
+struct CellHash {
+  float xs, ys;
+  std::unordered_map<int, std::unordered_set<int>> cells;
+  std::vector<int> keys(const float* b) const {
+    float mn[2] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float mx[2] = {std::numeric_limits<float>::min(), std::numeric_limits<float>::min()};
+    for (int i = 0; i < 4; ++i) {
+      mn[0] = std::min(mn[0], b[2 * i]);
+      mn[1] = std::min(mn[1], b[2 * i + 1]);
+      mx[0] = std::max(mx[0], b[2 * i]);
+      mx[1] = std::max(mx[1], b[2 * i + 1]);
+    }
+    int16_t q0 = int16_t(std::floor(mn[0] / xs));
+    int16_t q1 = int16_t(std::floor(mn[1] / xs));
+    int16_t q2 = int16_t(std::ceil(mx[0] / ys));
+    int16_t q3 = int16_t(std::ceil(mx[1] / ys));
+    std::vector<int> out;
+    for (int i = q0; i < q2; ++i)
+      for (int j = q1; j < q3; ++j) out.push_back(i * 100 + j);
+    return out;
+  }
+  void build(const float* dets, int n, int ndim) {
+    for (int i = 0; i < n; ++i)
+      for (int k : keys(dets + (size_t)i * ndim)) cells[k].insert(i);
+  }
+  std::unordered_set<int> candidates(const float* b) const {
+    std::unordered_set<int> r;
+    for (int k : keys(b)) {
+      auto it = cells.find(k);
+      if (it != cells.end()) r.insert(it->second.begin(), it->second.end());
+    }
+    return r;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// 8-point rotated IoU (rotated_iou-inl.h).  DType = float instantiation.
+// ----------------------------------------------------------------------------------------------
+constexpr float kEpsR = 1e-8f;  // rotated_iou-inl.h:20
+inline bool rel_equal(float d1, float d2) {  // :50-53  (divides by min(d1,d2))
+  float m = d1 < d2 ? d1 : d2;
+  return std::fabs((d1 - d2) / m) < kEpsR;
+}
+inline float crs(Pt a, Pt b) { return a.x * b.y - a.y * b.x; }  // :56-59
+inline int rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {              // :69-78
+  auto mn = [](float a, float b) { return a < b ? a : b; };
+  auto mx = [](float a, float b) { return a > b ? a : b; };
+  return mn(p1.x, p2.x) <= mx(q1.x, q2.x) && mn(q1.x, q2.x) <= mx(p1.x, p2.x) &&
+         mn(p1.y, p2.y) <= mx(q1.y, q2.y) && mn(q1.y, q2.y) <= mx(p1.y, p2.y);
+}
+inline int inside_8pt(const float* box, Pt p) {  // :112-128
+  int flag = -1;
+  for (int i = 0; i < 4; i++) {
+    int j = (i + 1) % 4;
+    float pos = (box[2 * j] - box[2 * i]) * (p.y - box[2 * i + 1]) -
+                (box[2 * j + 1] - box[2 * i + 1]) * (p.x - box[2 * i]);
+    if (flag == -1)
+      flag = (pos >= 0.0f);
+    else if (flag != (pos >= 0.0f))
+      return 0;
+  }
+  return 1;
+}
+inline int seg_meet(Pt p1, Pt p0, Pt q1, Pt q0, Pt& ans) {  // :130-172
+  if (rect_cross(p0, p1, q0, q1) == 0) return 0;
+  float A1 = p1.y - p0.y, B1 = p0.x - p1.x, C1 = A1 * p0.x + B1 * p0.y;
+  float A2 = q1.y - q0.y, B2 = q0.x - q1.x, C2 = A2 * q0.x + B2 * q0.y;
+  float det = A1 * B2 - A2 * B1;
+  if (rel_equal(det, 0.0f)) return 0;
+  float x = (B2 * C1 - B1 * C2) / det;
+  float y = (A1 * C2 - A2 * C1) / det;
+  auto on = [&](Pt a, Pt b) {
+    float lx = std::min(a.x, b.x), hx = std::max(a.x, b.x);
+    float ly = std::min(a.y, b.y), hy = std::max(a.y, b.y);
+    return (lx < x || rel_equal(lx, x)) && (hx > x || rel_equal(hx, x)) &&
+           (ly < y || rel_equal(ly, y)) && (hy > y || rel_equal(hy, y));
+  };
+  if (on(p0, p1) && on(q0, q1)) {
+    ans.x = x;
+    ans.y = y;
+    return 1;
+  }
+  return 0;
+}
+}  // namespace
+
+// point_cmp (rotated_iou-inl.h:186-192): compare polar angles about the
+// centroid with atan2.
+static inline int angle_after(Pt a, Pt b, Pt c) {
+  return atan2f(a.y - c.y, a.x - c.x) > atan2f(b.y - c.y, b.x - c.x);
+}
+
+static float overlap_8pt(const float* A, const float* B) {  // :388-464
+  Pt ac[5], bc[5];
+  for (int k = 0; k < 4; ++k) {
+    ac[k] = {A[2 * k], A[2 * k + 1]};
+    bc[k] = {B[2 * k], B[2 * k + 1]};
+  }
+  ac[4] = ac[0];
+  bc[4] = bc[0];
+  Pt cp[16];
+  Pt ctr = {0, 0};
+  int cnt = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      if (seg_meet(ac[i + 1], ac[i], bc[j + 1], bc[j], cp[cnt])) {
+        ctr.x = ctr.x + cp[cnt].x;
+        ctr.y = ctr.y + cp[cnt].y;
+        cnt++;
+      }
+    }
+  for (int k = 0; k < 4; k++) {
+    if (inside_8pt(A, bc[k])) {
+      ctr.x = ctr.x + bc[k].x;
+      ctr.y = ctr.y + bc[k].y;
+      cp[cnt++] = bc[k];
+    }
+    if (inside_8pt(B, ac[k])) {
+      ctr.x = ctr.x + ac[k].x;
+      ctr.y = ctr.y + ac[k].y;
+      cp[cnt++] = ac[k];
+    }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; j++)
+    for (int i = 0; i < cnt - j - 1; i++)
+      if (angle_after(cp[i], cp[i + 1], ctr)) std::swap(cp[i], cp[i + 1]);
+  float area = 0;
+  for (int k = 0; k < cnt - 1; k++) {
+    Pt u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+    Pt v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+    area += crs(u, v);
+  }
+  return (float)(fabsf(area) / 2.0);
+}
+
+static float iou_8pt(const float* a, const float* b) {  // :477-493
+  float sa = (a[2] - a[0]) * (a[5] - a[1]) - (a[3] - a[1]) * (a[4] - a[0]);
+  sa += (a[4] - a[0]) * (a[7] - a[1]) - (a[5] - a[1]) * (a[6] - a[0]);
+  float sb = (b[2] - b[0]) * (b[5] - b[1]) - (b[3] - b[1]) * (b[4] - b[0]);
+  sb += (b[4] - b[0]) * (b[7] - b[1]) - (b[5] - b[1]) * (b[6] - b[0]);
+  sa = (float)(fabsf(sa) / 2.0);
+  sb = (float)(fabsf(sb) / 2.0);
+  if (sa < kEpsR || sb < kEpsR) return 0.0f;
+  float s = overlap_8pt(a, b);
+  return s / fmaxf(sa + sb - s, kEpsR);
+}
+
+extern "C" {
+
+// BEV (or volume) IoU of two 12-float det rows, argument order as nms.h:195 (box1, box2).
+float orc_single_overlap(const float* box1, const float* box2, int is3d) {
+  Clipper c;
+  return c.overlap(box1, box2, is3d != 0);
+}
+
+// nms.h:786-792 : indices sorted by score descending with std::sort (unstable introsort).
+void orc_wnms_order(const float* dets, int K, int* order) {
+  std::iota(order, order + K, 0);
+  std::sort(order, order + K, [&](int i, int j) { return dets[i * 12 + 11] > dets[j * 12 + 11]; });
+}
+
+// nms.h:452-577.  dets (K,12); order (K).  out_dets capacity K*12, keep capacity K.  Returns M.
+int orc_wnms_4c(const float* dets, const int* order, int K, float thresh, float thresh_vote, int is3d,
+                int hash_scale, float* out_dets, int* keep) {
+  if (K == 0) return 0;
+  const int nd = 12, nf = 11;
+  CellHash hash{(float)hash_scale, (float)hash_scale, {}};
+  hash.build(dets, K, nd);
+  Clipper clip;
+  std::vector<int> supp(K, 0), nb;
+  std::vector<float> nby;
+  int M = 0;
+  for (int _i = 0; _i < K; ++_i) {
+    int i = order[_i];
+    if (supp[i] == 1) continue;
+    nb.clear();
+    nb.push_back(i);
+    auto cand = hash.candidates(dets + (size_t)nd * i);
+    for (int _j = _i + 1; _j < K; ++_j) {
+      int j = order[_j];
+      if (supp[j] == 1) continue;
+      if (cand.find(j) == cand.end()) continue;
+      float ovr = clip.overlap(dets + (size_t)i * nd, dets + (size_t)j * nd, is3d != 0);
+      if (ovr >= thresh) supp[j] = 1;
+      if (ovr > thresh_vote) nb.push_back(j);
+    }
+    float sum1[11], sum3[11];
+    for (int k = 0; k < nf; ++k) sum1[k] = sum3[k] = 0.f;
+    const float yaw_i = dets[(size_t)i * nd + 8];
+    float med;
+    nby.clear();
+    for (int l : nb) nby.push_back(dets[(size_t)l * nd + 8]);
+    if (nb.size() <= 2) {
+      med = yaw_i;
+    } else {
+      if (nb.size() % 2 == 0) nby.push_back(yaw_i);
+      std::sort(nby.begin(), nby.end());
+      med = nby[nby.size() / 2];
+    }
+    for (int l : nb) {
+      float yl = dets[(size_t)l * nd + 8];
+      if (std::fmod(std::abs(yl - med), float(2 * 3.1415926)) >= 0.3) continue;  // nms.h:542
+      float p = dets[(size_t)l * nd + 11];
+      for (int k = 0; k < nf; ++k) {
+        sum1[k] += p * dets[(size_t)l * nd + k];
+        sum3[k] += p;
+      }
+    }
+    for (int k = 0; k < nf; ++k) out_dets[(size_t)M * 12 + k] = sum1[k] / sum3[k];
+    out_dets[(size_t)M * 12 + 11] = dets[(size_t)i * nd + 11];
+    keep[M] = i;
+    ++M;
+  }
+  return M;
+}
+
+// decode_3d_bbox-inl.h:169-277 (8-dim) and :64-167 (7-dim "bin").  out pre-filled with 0 (:297).
+void orc_decode3d(const float* delta, const float* pc, float* out, long n, int box_type, int is_bin) {
+  std::memset(out, 0, sizeof(float) * 10 * (size_t)n);
+  for (long idx = 0; idx < n; ++idx) {
+    const float* d = delta + idx * box_type;
+    float pc_x = pc[idx * 3 + 0], pc_y = pc[idx * 3 + 1], pc_z = pc[idx * 3 + 2];
+    float az = atan2f(pc_y, pc_x);
+    float ca = cosf(az), sa = sinf(az);
+    float dx, dy, width, length, height, z0, yaw_l;
+    if (is_bin) {
+      dx = d[0];
+      dy = d[1];
+      float dz = d[2];
+      width = expf(d[3]);
+      length = expf(d[4]);
+      height = expf(d[5]);
+      float cz = pc_z + dz;
+      z0 = (float)(cz - height / 2.0);  // :120  double intermediate
+      yaw_l = d[6] + az;
+    } else {
+      dx = d[0];
+      dy = d[1];
+      dx = dx * fabsf(dx);  // :212-213
+      dy = dy * fabsf(dy);
+      width = expf(d[2]);
+      length = expf(d[3]);
+      height = expf(d[7]);
+      z0 = d[6];
+      yaw_l = atan2f(d[5], d[4]) + az;  // atan2(sin_yaw, cos_yaw) + azimuth  :241-242
+    }
+    float dxl = dx * ca - dy * sa;
+    float dyl = dx * sa + dy * ca;
+    float cx = pc_x + dxl, cy = pc_y + dyl;
+    float sy = sinf(yaw_l), cy_ = cosf(yaw_l);
+    // corners: the literals 0.5 / -0.5 are double, products are rounded to float at construction (:251-254)
+    float hx[4] = {(float)(0.5 * length), (float)(-0.5 * length), (float)(-0.5 * length), (float)(0.5 * length)};
+    float hy[4] = {(float)(-0.5 * width), (float)(-0.5 * width), (float)(0.5 * width), (float)(0.5 * width)};
+    float* o = out + idx * 10;
+    for (int k = 0; k < 4; ++k) {
+      float rx = hx[k] * cy_ - hy[k] * sy;  // Point::rotate :48-53
+      float ry = hx[k] * sy + hy[k] * cy_;
+      o[2 * k] = rx + cx;
+      o[2 * k + 1] = ry + cy;
+    }
+    o[8] = z0;
+    o[9] = z0 + height;
+  }
+}
+
+// rotated_iou-inl.h:509-522, box_type 8 only; ious (n1,n2), pre-filled -1 then overwritten (:541).
+void orc_rotated_iou_8pt(const float* b1, const float* b2, float* ious, long n1, long n2) {
+  for (long i = 0; i < n1; ++i)
+    for (long j = 0; j < n2; ++j) ious[i * n2 + j] = iou_8pt(b1 + i * 8, b2 + j * 8);
+}
+}

@@ -1,0 +1,306 @@
+// Fused Meta-Kernel unit for gfx950 -- ONE kernel for what the reference builds from ~12 MXNet ops
+// (meta_kernel.py:166-240 + dla_backbone.py:92-97):
+//   rel_k = coord[p+d_k] - coord[p]           (im2col zero padding: rel_k = -coord[p] outside the image)
+//   h_k   = relu(W0 rel_k + b0)               3 -> 32        (VALU, K = 3 is too thin for MFMA)
+//   w_k   = W1 h_k + b1                       32 -> 64       (MFMA #1)
+//   a_k   = relu(s1 * (data[p+d_k] (.) w_k) + t1)            BN(576) + ReLU, s1 folded into W1/b1 per tap
+//   y     = relu(s2 * (A . a) + t2)           576 -> 64      (MFMA #2, accumulated over the 9 taps)
+// The 576-channel intermediates never leave registers: MFMA #1 is issued "transposed" (A operand = weights,
+// B operand = per-pixel hidden vector), so its C layout (lane = pixel, regs = channels) is, after the
+// element-wise product, exactly the B operand of MFMA #2 -- the channel <-> (lane,reg) permutation this needs
+// is baked into the packed weights on the host (rd_pack_meta_host), giving each lane 16 CONTIGUOUS channels
+// per 32-channel block (wide LDS reads / global stores).
+//   workgroup = WAVES waves = WAVES rows x 32 columns, persistent over tiles; LDS: bf16 weights (108 KiB),
+//   per-tap constants, and the (WAVES+2) x 34 data halo (XOR-swizzled 16-byte slots).
+//   f32 variant (parity mode): same code, v_mfma_f32_32x32x2_f32, weights streamed from L2 (220 KiB > LDS).
+#pragma once
+#include "rd_common.h"
+
+namespace rd {
+
+struct MetaLayout {  // byte offsets inside the packed parameter block
+  size_t w1s, a2, b1p, t1, w0p, s2t2, total;
+  size_t wbytes;  // w1s + a2 (the part held in LDS for bf16)
+};
+inline MetaLayout meta_layout(int dt) {
+  MetaLayout L;
+  const size_t w1s = dt == RD_BF16 ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
+  const size_t a2 = dt == RD_BF16 ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
+  L.w1s = 0;
+  L.a2 = w1s;
+  L.wbytes = w1s + a2;
+  L.b1p = L.wbytes;
+  L.t1 = L.b1p + 9 * 64 * 4;
+  L.w0p = L.t1 + 9 * 64 * 4;
+  L.s2t2 = L.w0p + 2 * 16 * 4 * 4;
+  L.total = L.s2t2 + 128 * 4;
+  return L;
+}
+inline int meta_perm(int blk, int m) {  // MFMA row m of 32-block blk -> channel
+  return 32 * blk + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+}
+inline void pack_meta(const float* w0, const float* b0, const float* w1, const float* b1, const float* s1,
+                      const float* t1, const float* agg, const float* s2, const float* t2, int dt, void* out) {
+  const MetaLayout L = meta_layout(dt);
+  unsigned char* base = (unsigned char*)out;
+  memset(base, 0, L.total);
+  auto put = [&](size_t byte_off, size_t idx, float v) {
+    if (dt == RD_BF16) ((bf16_t*)(base + byte_off))[idx] = f32_to_bf16(v);
+    else ((float*)(base + byte_off))[idx] = v;
+  };
+  for (int k = 0; k < 9; ++k)
+    for (int mt = 0; mt < 2; ++mt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 31, hi = lane >> 5;
+        const int ch = meta_perm(mt, m);
+        const float s = s1[ch * 9 + k];
+        if (dt == RD_BF16) {
+          for (int ks = 0; ks < 2; ++ks)
+            for (int e = 0; e < 8; ++e) {
+              int j = 16 * ks + 8 * hi + e;
+              put(L.w1s, ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 8 + e, s * w1[ch * 32 + j]);
+            }
+        } else {
+          for (int q = 0; q < 16; ++q) {
+            int j = 2 * q + hi;
+            put(L.w1s, ((((size_t)k * 2 + mt) * 4 + (q >> 2)) * 64 + lane) * 4 + (q & 3), s * w1[ch * 32 + j]);
+          }
+        }
+      }
+  for (int k = 0; k < 9; ++k)
+    for (int ot = 0; ot < 2; ++ot)
+      for (int mt = 0; mt < 2; ++mt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 31, hi = lane >> 5;
+          const int o = meta_perm(ot, m);
+          for (int r = 0; r < 16; ++r) {
+            const int c = 32 * mt + 16 * hi + r;
+            const float v = agg[(size_t)o * 576 + c * 9 + k];
+            if (dt == RD_BF16)
+              put(L.a2, (((((size_t)k * 2 + ot) * 2 + mt) * 2 + (r >> 3)) * 64 + lane) * 8 + (r & 7), v);
+            else
+              put(L.a2, (((((size_t)k * 2 + ot) * 2 + mt) * 4 + (r >> 2)) * 64 + lane) * 4 + (r & 3), v);
+          }
+        }
+  float* fb1 = (float*)(base + L.b1p);
+  float* ft1 = (float*)(base + L.t1);
+  for (int k = 0; k < 9; ++k)
+    for (int c = 0; c < 64; ++c) {
+      fb1[k * 64 + c] = s1[c * 9 + k] * b1[c];
+      ft1[k * 64 + c] = t1[c * 9 + k];
+    }
+  float* fw0 = (float*)(base + L.w0p);
+  for (int hi = 0; hi < 2; ++hi)
+    for (int i = 0; i < 16; ++i) {
+      int j = dt == RD_BF16 ? 16 * (i >> 3) + 8 * hi + (i & 7) : 2 * i + hi;
+      fw0[(hi * 16 + i) * 4 + 0] = w0[j * 3 + 0];
+      fw0[(hi * 16 + i) * 4 + 1] = w0[j * 3 + 1];
+      fw0[(hi * 16 + i) * 4 + 2] = w0[j * 3 + 2];
+      fw0[(hi * 16 + i) * 4 + 3] = b0[j];
+    }
+  float* fs = (float*)(base + L.s2t2);
+  for (int o = 0; o < 64; ++o) {
+    fs[o] = s2[o];
+    fs[64 + o] = t2[o];
+  }
+}
+
+struct MetaArgs {
+  const void* data; int d_cs, d_co;
+  const float* coord;  // NCHW (B,3,H,W)
+  const unsigned char* packed;
+  void* y; int y_cs, y_co;
+  int B, H, W;
+  int tiles_h, tiles_w, ntiles;
+};
+
+template <int DT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
+  using E = Elem<DT>;
+  using T = typename E::T;
+  constexpr bool BF = (DT == RD_BF16);
+  constexpr int PXB = BF ? 128 : 256;  // bytes per pixel (64 channels)
+  constexpr int SPP = PXB / 16;        // 16-byte slots per pixel
+  constexpr int HC = 34;               // halo columns
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  // LDS carve: [weights (bf16 only)] [consts] [halo]
+  constexpr size_t W1S_B = BF ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
+  constexpr size_t A2_B = BF ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
+  constexpr size_t WB = W1S_B + A2_B;
+  constexpr size_t CONST_B = 9 * 64 * 4 * 2 + 512 + 512;
+  unsigned char* lw = smem;                       // bf16: weights live here
+  unsigned char* lc = smem + (BF ? WB : 0);       // consts
+  unsigned char* halo = lc + CONST_B;
+  const float* cb1 = (const float*)lc;            // [9][64]
+  const float* ct1 = cb1 + 9 * 64;                // [9][64]
+  const float* cw0 = ct1 + 9 * 64;                // [2][16][4]
+  const float* cs2 = cw0 + 2 * 16 * 4;            // [64] s2, [64] t2
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int px = lane & 31, hi = lane >> 5;
+  const int NT = WAVES * 64;
+
+  // one-time fill of weights (bf16) and constants
+  if (BF)
+    for (size_t i = tid; i < WB / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)a.packed)[i];
+  for (size_t i = tid; i < CONST_B / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + WB))[i];
+  const unsigned char* w1s = BF ? lw : a.packed;
+  const unsigned char* a2w = w1s + W1S_B;
+
+  const T* data = (const T*)a.data;
+  T* yout = (T*)a.y;
+  const long HW = (long)a.H * a.W;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tw = tile % a.tiles_w;
+    const int th = (tile / a.tiles_w) % a.tiles_h;
+    const int b = tile / (a.tiles_w * a.tiles_h);
+    const int h0 = th * WAVES, w0 = tw * 32;
+    __syncthreads();
+    for (int idx = tid; idx < (WAVES + 2) * HC * SPP; idx += NT) {
+      const int pl = idx / SPP, s = idx - pl * SPP;
+      const int r = pl / HC, c = pl - r * HC;
+      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      Slot16 v = {0u, 0u, 0u, 0u};
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        v = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * E::CH);
+      const int swz = BF ? ((pl >> 1) & 7) : (pl & 15);
+      *(Slot16*)(halo + pl * PXB + ((s ^ swz) << 4)) = v;
+    }
+    __syncthreads();
+
+    const int h = h0 + wv, w = w0 + px;
+    const bool live = (h < a.H) && (w < a.W);
+    const int wc = min(w, a.W - 1), hc = min(h, a.H - 1);
+    const float* cbase = a.coord + (size_t)b * 3 * HW;
+    const float c0 = cbase[0 * HW + (long)hc * a.W + wc];
+    const float c1 = cbase[1 * HW + (long)hc * a.W + wc];
+    const float c2 = cbase[2 * HW + (long)hc * a.W + wc];
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+
+    for (int k = 0; k < 9; ++k) {
+      const int dh = k / 3 - 1, dw = k % 3 - 1;
+      const int nh = hc + dh, nw = wc + dw;
+      float r0 = -c0, r1 = -c1, r2 = -c2;
+      if (nh >= 0 && nh < a.H && nw >= 0 && nw < a.W) {
+        r0 = cbase[0 * HW + (long)nh * a.W + nw] - c0;
+        r1 = cbase[1 * HW + (long)nh * a.W + nw] - c1;
+        r2 = cbase[2 * HW + (long)nh * a.W + nw] - c2;
+      }
+      float hv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 wq = *(const f32x4*)(cw0 + (hi * 16 + i) * 4);
+        hv[i] = fmaxf(wq[0] * r0 + wq[1] * r1 + wq[2] * r2 + wq[3], 0.f);
+      }
+      // MFMA #1: D1[ch][px] = (s1 W1)[ch][:] . h[:]  + s1*b1
+      f32x16 d1[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *(const f32x4*)(cb1 + k * 64 + 32 * mt + 16 * hi + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d1[mt][4 * g + e] = bq[e];
+        }
+      if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s16x8 bfrag;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bfrag[e] = (short)f32_to_bf16(hv[8 * ks + e]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const s16x8 af = *(const s16x8*)(w1s + ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 16);
+            d1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, d1[mt], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 af = *(const f32x4*)(w1s + ((((size_t)k * 2 + mt) * 4 + q4) * 64 + lane) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], hv[4 * q4 + e], d1[mt], 0, 0, 0);
+          }
+      }
+      // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
+      const int pl = (wv + 1 + dh) * HC + (px + 1 + dw);
+      const unsigned char* hp = halo + pl * PXB;
+      const int swz = BF ? ((pl >> 1) & 7) : (pl & 15);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float av[16];
+        if constexpr (BF) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const s16x8 dv = *(const s16x8*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[8 * s2 + e] = bf16_to_f32((bf16_t)dv[e]);
+          }
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 dv = *(const f32x4*)(hp + (((8 * mt + 4 * hi + s4) ^ swz) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[4 * s4 + e] = dv[e];
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 tq = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[4 * g + e] = fmaxf(av[4 * g + e] * d1[mt][4 * g + e] + tq[e], 0.f);
+        }
+        // MFMA #2: acc2[o][px] += A[o][(ch,k)] . a[ch]
+        if constexpr (BF) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            s16x8 bfrag;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfrag[e] = (short)f32_to_bf16(av[8 * s2 + e]);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+              const s16x8 af = *(const s16x8*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 2 + s2) * 64 + lane) * 16);
+              acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+              const f32x4 af = *(const f32x4*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 4 + r4) * 64 + lane) * 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], av[4 * r4 + e], acc2[ot], 0, 0, 0);
+            }
+        }
+      }
+    }
+    // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
+    if (live) {
+      T* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int ob = 32 * ot + 16 * hi;
+        T tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tmp[r] = E::from_f32(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f));
+        Slot16 pk[sizeof(T)];  // 16 elements = sizeof(T) slots of 16 bytes
+        memcpy(pk, tmp, sizeof(tmp));
+#pragma unroll
+        for (int i = 0; i < (int)sizeof(T); ++i) *(Slot16*)(yp + ob + i * E::CH) = pk[i];
+      }
+    }
+  }
+}
+
+}  // namespace rd

@@ -1,0 +1,116 @@
+// 8-point rotated IoU (operator_cxx/contrib/rotated_iou-inl.h:49-128,130-172,186-192,388-493 in the reference)
+// and the 'bev' batch_rotated_iou reduction (operator_py/batch_rotated_iou.py:33-49): one thread per box pair,
+// float arithmetic in the reference's order (FP contraction off).
+#pragma once
+#include "rd_common.h"
+
+namespace rd {
+struct RPt { float x, y; };
+#define RD_NOCONTRACT_R _Pragma("clang fp contract(off)")
+
+__device__ __forceinline__ bool r_eq(float d1, float d2) {  // :50-53, EPS 1e-8, divides by min(d1,d2)
+  RD_NOCONTRACT_R
+  float m = d1 < d2 ? d1 : d2;
+  return fabsf((d1 - d2) / m) < 1e-8f;
+}
+__device__ __forceinline__ int r_inside(const float* box, RPt p) {  // :112-128
+  RD_NOCONTRACT_R
+  int flag = -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int j = (i + 1) & 3;
+    float pos = (box[2 * j] - box[2 * i]) * (p.y - box[2 * i + 1]) - (box[2 * j + 1] - box[2 * i + 1]) * (p.x - box[2 * i]);
+    int ge = pos >= 0.0f;
+    if (flag == -1) flag = ge;
+    else if (flag != ge) return 0;
+  }
+  return 1;
+}
+__device__ __forceinline__ int r_meet(RPt p1, RPt p0, RPt q1, RPt q0, RPt& ans) {  // :130-172
+  RD_NOCONTRACT_R
+  bool rc = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+            fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
+  if (!rc) return 0;
+  float A1 = p1.y - p0.y, B1 = p0.x - p1.x, C1 = A1 * p0.x + B1 * p0.y;
+  float A2 = q1.y - q0.y, B2 = q0.x - q1.x, C2 = A2 * q0.x + B2 * q0.y;
+  float det = A1 * B2 - A2 * B1;
+  if (r_eq(det, 0.0f)) return 0;
+  float x = (B2 * C1 - B1 * C2) / det;
+  float y = (A1 * C2 - A2 * C1) / det;
+  float lx = fminf(p0.x, p1.x), hx = fmaxf(p0.x, p1.x), ly = fminf(p0.y, p1.y), hy = fmaxf(p0.y, p1.y);
+  bool on1 = (lx < x || r_eq(lx, x)) && (hx > x || r_eq(hx, x)) && (ly < y || r_eq(ly, y)) && (hy > y || r_eq(hy, y));
+  lx = fminf(q0.x, q1.x); hx = fmaxf(q0.x, q1.x); ly = fminf(q0.y, q1.y); hy = fmaxf(q0.y, q1.y);
+  bool on2 = (lx < x || r_eq(lx, x)) && (hx > x || r_eq(hx, x)) && (ly < y || r_eq(ly, y)) && (hy > y || r_eq(hy, y));
+  if (on1 && on2) { ans.x = x; ans.y = y; return 1; }
+  return 0;
+}
+__device__ float r_iou8(const float* a, const float* b) {  // :388-464, :477-493
+  RD_NOCONTRACT_R
+  float sa = (a[2] - a[0]) * (a[5] - a[1]) - (a[3] - a[1]) * (a[4] - a[0]);
+  sa += (a[4] - a[0]) * (a[7] - a[1]) - (a[5] - a[1]) * (a[6] - a[0]);
+  float sb = (b[2] - b[0]) * (b[5] - b[1]) - (b[3] - b[1]) * (b[4] - b[0]);
+  sb += (b[4] - b[0]) * (b[7] - b[1]) - (b[5] - b[1]) * (b[6] - b[0]);
+  sa = (float)((double)fabsf(sa) / 2.0);
+  sb = (float)((double)fabsf(sb) / 2.0);
+  if (sa < 1e-8f || sb < 1e-8f) return 0.0f;
+  RPt ac[5], bc[5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { ac[k] = {a[2 * k], a[2 * k + 1]}; bc[k] = {b[2 * k], b[2 * k + 1]}; }
+  ac[4] = ac[0];
+  bc[4] = bc[0];
+  RPt cp[16];
+  RPt ctr = {0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      RPt t;
+      if (r_meet(ac[i + 1], ac[i], bc[j + 1], bc[j], t)) { cp[cnt] = t; ctr.x = ctr.x + t.x; ctr.y = ctr.y + t.y; cnt++; }
+    }
+  for (int k = 0; k < 4; k++) {
+    if (r_inside(a, bc[k])) { ctr.x = ctr.x + bc[k].x; ctr.y = ctr.y + bc[k].y; cp[cnt++] = bc[k]; }
+    if (r_inside(b, ac[k])) { ctr.x = ctr.x + ac[k].x; ctr.y = ctr.y + ac[k].y; cp[cnt++] = ac[k]; }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; j++)
+    for (int i = 0; i < cnt - j - 1; i++)
+      if (atan2f(cp[i].y - ctr.y, cp[i].x - ctr.x) > atan2f(cp[i + 1].y - ctr.y, cp[i + 1].x - ctr.x)) {
+        RPt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; k++) {
+    RPt u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+    RPt v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+    area += u.x * v.y - u.y * v.x;
+  }
+  float s = (float)((double)fabsf(area) / 2.0);
+  return s / fmaxf(sa + sb - s, 1e-8f);
+}
+__global__ __launch_bounds__(256) void riou8_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
+                                                    float* __restrict__ out, long n1, long n2) {
+  long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n1 * n2) return;
+  long r = i / n2, c = i - r * n2;
+  out[i] = r_iou8(b1 + r * 8, b2 + c * 8);
+}
+// one thread per proposal, loop over the (<= 200) GT boxes held in LDS
+__global__ __launch_bounds__(256) void batch_max_iou_kernel(const float* __restrict__ prop, int pstride,
+                                                            const float* __restrict__ gt, float* __restrict__ out,
+                                                            long n, int ngt) {
+  __shared__ float g[256 * 8];
+  for (int i = threadIdx.x; i < ngt * 8; i += 256) g[i] = gt[i];
+  __syncthreads();
+  long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  float box[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) box[k] = prop[i * pstride + k];
+  float best = 0.f;
+  for (int j = 0; j < ngt; ++j) {
+    float v = r_iou8(box, g + j * 8);
+    if (!(v == v) || isinf(v) || v > 1.0f || v < 0.f) v = 0.f;
+    best = j == 0 ? v : fmaxf(best, v);
+  }
+  out[i] = best;
+}
+}  // namespace rd

@@ -1,0 +1,346 @@
+// Weighted NMS (operator_cxx/src_cxx/nms.h:452-577 in the reference), decomposed for the GPU so that every
+// float operation happens in the reference's order (this file is compiled with FP contraction OFF):
+//   1. prep   : per box (in processing order) clockwise-normalised corners, the 4 edge polar angles (the only
+//               atan2f of the algorithm -- hoisted out of the O(K^2) part), area, bottom, height.
+//   2. pairs  : for sorted positions q1 < q2 the half-plane-intersection IoU (nms.h:96-249) -> two K x K/64
+//               bit matrices  thr[q1] (ovr >= thresh)  and  vote[q1] (ovr > thresh_vote).  No spatial prefilter:
+//               the reference's 100 m hash passes every pair inside +-100 m, and an AABB reject is NOT
+//               result-neutral (disjoint boxes can produce a non-zero "IoU" in the reference's clipper).
+//   3. scan   : one wavefront walks the sorted positions; for an unsuppressed q it snapshots
+//               nb[q] = vote[q] & ~supp (written back in place) and ORs thr[q] into supp (64 words per step).
+//   4. merge  : one wavefront per kept row: median yaw by rank selection, then the 11 score-weighted sums in
+//               neighbourhood order (lane f accumulates field f sequentially -> same rounding as the reference).
+#pragma once
+#include "rd_common.h"
+
+namespace rd {
+
+struct WPt { float x, y; };
+struct WEdge { WPt a, b; float ang; };
+constexpr int PREP_F = 16;  // floats per prepped box: 8 corners, 4 angles, area, bottom, height, pad
+
+#define RD_NOCONTRACT _Pragma("clang fp contract(off)")
+
+__device__ __forceinline__ int w_sgn(float k) {  // nms.h:48-52, EPS = 1e-5
+  RD_NOCONTRACT
+  if (fabsf(k) < 1e-5f) return 0;
+  return k > 0 ? 1 : -1;
+}
+__device__ __forceinline__ float w_cross3(WPt o, WPt u, WPt v) {  // nms.h:54-56
+  RD_NOCONTRACT
+  return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x);
+}
+__device__ __forceinline__ bool w_less(const WEdge& e1, const WEdge& e2) {  // nms.h:58-64
+  RD_NOCONTRACT
+  int d = w_sgn(e1.ang - e2.ang);
+  if (!d) return w_sgn(w_cross3(e1.a, e2.a, e2.b)) > 0;
+  return d < 0;
+}
+__device__ __forceinline__ WPt w_meet(const WEdge& e1, const WEdge& e2) {  // nms.h:74-83
+  RD_NOCONTRACT
+  float A1 = e1.b.y - e1.a.y;
+  float B1 = e1.a.x - e1.b.x;
+  float C1 = (e1.b.x - e1.a.x) * e1.a.y - (e1.b.y - e1.a.y) * e1.a.x;
+  float A2 = e2.b.y - e2.a.y;
+  float B2 = e2.a.x - e2.b.x;
+  float C2 = (e2.b.x - e2.a.x) * e2.a.y - (e2.b.y - e2.a.y) * e2.a.x;
+  WPt p;
+  p.x = (C2 * B1 - C1 * B2) / (A1 * B2 - A2 * B1);
+  p.y = (C1 * A2 - C2 * A1) / (A1 * B2 - A2 * B1);
+  return p;
+}
+__device__ __forceinline__ bool w_outside(const WEdge& e0, const WEdge& e1, const WEdge& e2) {  // nms.h:85-90
+  WPt p = w_meet(e1, e2);
+  return w_sgn(w_cross3(p, e0.a, e0.b)) > 0;
+}
+
+// box1 = the earlier (kept candidate) box, box2 = the later one; pre1/pre2 their prepped records.
+__device__ float w_overlap(const float* pre1, const float* pre2, bool is3d) {
+  RD_NOCONTRACT
+  WEdge l[8];
+  // nms.h:210-225: p[0..3] = box2, p[4..7] = box1 ; l[z] from box2, l[z+4] from box1
+#pragma unroll
+  for (int z = 0; z < 4; ++z) {
+    int z1 = (z + 1) & 3;
+    l[z].a = {pre2[2 * z], pre2[2 * z + 1]};
+    l[z].b = {pre2[2 * z1], pre2[2 * z1 + 1]};
+    l[z].ang = pre2[8 + z];
+    l[z + 4].a = {pre1[2 * z], pre1[2 * z + 1]};
+    l[z + 4].b = {pre1[2 * z1], pre1[2 * z1 + 1]};
+    l[z + 4].ang = pre1[8 + z];
+  }
+  float area1 = pre1[12], area2 = pre2[12];
+  // std::sort on 8 elements == libstdc++ __insertion_sort (n <= 16), restated literally because the
+  // comparator is not a strict weak order (nms.h:58-64,98)
+  for (int i = 1; i < 8; ++i) {
+    WEdge val = l[i];
+    if (w_less(val, l[0])) {
+      for (int j = i; j > 0; --j) l[j] = l[j - 1];
+      l[0] = val;
+    } else {
+      int j = i;
+      while (w_less(val, l[j - 1])) {
+        l[j] = l[j - 1];
+        --j;
+      }
+      l[j] = val;
+    }
+  }
+  int i, j;
+  for (i = 0, j = 0; i < 8; i++)
+    if (w_sgn(l[i].ang - l[j].ang) > 0) l[++j] = l[i];
+  const int t = j + 1;
+  int dq[16];
+  dq[0] = 0;
+  dq[1] = 1;
+  int top = 1, bot = 0;
+  for (i = 2; i < t; i++) {
+    while (top > bot && w_outside(l[i], l[dq[top]], l[dq[top - 1]])) top--;
+    while (top > bot && w_outside(l[i], l[dq[bot]], l[dq[bot + 1]])) bot++;
+    dq[++top] = i;
+  }
+  while (top > bot && w_outside(l[dq[bot]], l[dq[top]], l[dq[top - 1]])) top--;
+  while (top > bot && w_outside(l[dq[top]], l[dq[bot]], l[dq[bot + 1]])) bot++;
+  dq[++top] = dq[bot];
+  // polygon vertices + fan area (nms.h:147-166), vertices generated on the fly
+  const int nv = top - bot;
+  float inter = 0.f;
+  if (nv >= 3) {
+    WPt p0 = w_meet(l[dq[bot + 1]], l[dq[bot]]);
+    WPt pa = w_meet(l[dq[bot + 2]], l[dq[bot + 1]]);
+    float area = 0.f;
+    for (int k = 2; k < nv; ++k) {
+      WPt pb = w_meet(l[dq[bot + k + 1]], l[dq[bot + k]]);
+      area += w_cross3(p0, pa, pb);
+      pa = pb;
+    }
+    if (area < 0) area = -area;
+    inter = area / 2;
+  }
+  if (is3d) {  // nms.h:168-184,234-239
+    float bot1 = pre1[13], h1 = pre1[14], top1 = bot1 + h1;
+    float bot2 = pre2[13], h2 = pre2[14], top2 = bot2 + h2;
+    float min_top = (top1 > top2) ? top2 : top1;
+    float max_bot = (bot1 > bot2) ? bot1 : bot2;
+    float d = min_top - max_bot;
+    float oh = d > 0 ? d : 0;
+    inter *= oh;
+    area1 *= h1;
+    area2 *= h2;
+  }
+  return inter / (area1 + area2 - inter);
+}
+
+__global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict__ dets, const int* __restrict__ order,
+                                                        int cap, const int* __restrict__ d_count, float* __restrict__ prep) {
+  RD_NOCONTRACT
+  int q = blockIdx.x * 256 + threadIdx.x;
+  int K = d_count ? min(*d_count, cap) : cap;
+  if (q >= K) return;
+  const float* b = dets + (size_t)order[q] * 12;
+  WPt p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = {b[2 * k], b[2 * k + 1]};
+  bool cw = ((p[1].x - p[0].x) * (p[2].y - p[0].y) - (p[2].x - p[0].x) * (p[1].y - p[0].y)) > 0;  // nms.h:92-94
+  if (cw) {  // std::reverse of the 4 corners (nms.h:191-193)
+    WPt t0 = p[0], t1 = p[1];
+    p[0] = p[3];
+    p[1] = p[2];
+    p[2] = t1;
+    p[3] = t0;
+  }
+  float* o = prep + (size_t)q * PREP_F;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = p[k].x;
+    o[2 * k + 1] = p[k].y;
+    int k1 = (k + 1) & 3;
+    o[8 + k] = atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);  // nms.h:71
+  }
+  float area = 0.f;
+  area += w_cross3(p[0], p[1], p[2]);
+  area += w_cross3(p[0], p[2], p[3]);
+  if (area < 0) area = -area;
+  o[12] = area / 2;
+  o[13] = b[9];
+  o[14] = b[10];
+  o[15] = 0.f;
+}
+
+// grid (nb, nb), 64 threads: tile (row block = blockIdx.y, col block = blockIdx.x), upper triangle only.
+__global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict__ prep, int cap,
+                                                        const int* __restrict__ d_count, float thresh, float thresh_vote,
+                                                        int is3d, unsigned long long* __restrict__ thr,
+                                                        unsigned long long* __restrict__ vote, int nwcap) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  const int K = d_count ? min(*d_count, cap) : cap;
+  if (cb < rb || rb * 64 >= K || cb * 64 >= K) return;
+  __shared__ float colp[64 * PREP_F];
+  const int t = threadIdx.x;
+  {
+    int q2 = cb * 64 + t;
+#pragma unroll
+    for (int k = 0; k < PREP_F; ++k) colp[t * PREP_F + k] = q2 < K ? prep[(size_t)q2 * PREP_F + k] : 0.f;
+  }
+  __syncthreads();
+  const int q1 = rb * 64 + t;
+  if (q1 >= K) return;
+  float mine[PREP_F];
+#pragma unroll
+  for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
+  unsigned long long mt = 0ull, mv = 0ull;
+  for (int c = 0; c < 64; ++c) {
+    int q2 = cb * 64 + c;
+    if (q2 < K && q2 > q1) {
+      float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0);
+      if (ovr >= thresh) mt |= 1ull << c;
+      if (ovr > thresh_vote) mv |= 1ull << c;
+    }
+  }
+  thr[(size_t)q1 * nwcap + cb] = mt;
+  vote[(size_t)q1 * nwcap + cb] = mv;
+}
+
+// one wavefront; supp lives in LDS (cap <= RD_WNMS_MAX_K -> 256 words)
+__global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long* __restrict__ thr,
+                                                       unsigned long long* __restrict__ vote, int cap,
+                                                       const int* __restrict__ d_count, int nwcap,
+                                                       const int* __restrict__ order, int* __restrict__ keep_q,
+                                                       int* __restrict__ keep, int* __restrict__ d_nkeep) {
+  __shared__ unsigned long long supp[RD_WNMS_MAX_K / 64];
+  const int lane = threadIdx.x;
+  const int K = d_count ? min(*d_count, cap) : cap;
+  const int nw = (K + 63) >> 6;
+  for (int w = lane; w < nw; w += 64) supp[w] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+  int M = 0;
+  int q = 0;
+  while (q < K) {
+    const int w0 = q >> 6;
+    unsigned long long avail = ~supp[w0] & (~0ull << (q & 63));
+    if (avail == 0ull) {
+      q = (w0 + 1) << 6;
+      continue;
+    }
+    q = (w0 << 6) + __ffsll(avail) - 1;
+    if (q >= K) break;
+    for (int w = w0 + lane; w < nw; w += 64) {
+      unsigned long long s = supp[w];
+      unsigned long long tb = thr[(size_t)q * nwcap + w];
+      unsigned long long vb = vote[(size_t)q * nwcap + w];
+      vote[(size_t)q * nwcap + w] = vb & ~s;  // neighbourhood snapshot before this row's suppression
+      supp[w] = s | tb;
+    }
+    if (lane == 0) {
+      keep_q[M] = q;
+      keep[M] = order[q];
+    }
+    ++M;
+    ++q;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) *d_nkeep = M;
+}
+
+__global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict__ dets, const int* __restrict__ order,
+                                                        const unsigned long long* __restrict__ vote, int cap,
+                                                        const int* __restrict__ d_count, int nwcap,
+                                                        const int* __restrict__ keep_q, const int* __restrict__ d_nkeep,
+                                                        float* __restrict__ out) {
+  RD_NOCONTRACT
+  const int mrow = blockIdx.x;
+  if (mrow >= *d_nkeep) return;
+  __shared__ int nbl[RD_WNMS_MAX_K];
+  __shared__ float yws[RD_WNMS_MAX_K + 1];
+  const int lane = threadIdx.x;
+  const int K = d_count ? min(*d_count, cap) : cap;
+  const int nw = (K + 63) >> 6;
+  const int q = keep_q[mrow];
+  const int irow = order[q];
+  const float yaw_i = dets[(size_t)irow * 12 + 8];
+  // neighbourhood list in ascending sorted position, self first (nms.h:496-517)
+  int n = 1;
+  if (lane == 0) {
+    nbl[0] = q;
+    yws[0] = yaw_i;
+  }
+  for (int w = q >> 6; w < nw; ++w) {
+    unsigned long long word = vote[(size_t)q * nwcap + w];
+    if ((word >> lane) & 1ull) {
+      int pos = n + __popcll(word & ((1ull << lane) - 1ull));
+      int q2 = (w << 6) + lane;
+      nbl[pos] = q2;
+      yws[pos] = dets[(size_t)order[q2] * 12 + 8];
+    }
+    n += __popcll(word);
+  }
+  __syncthreads();
+  // median yaw (nms.h:527-540)
+  float med = yaw_i;
+  if (n > 2) {
+    int sz = n;
+    if ((n & 1) == 0) {
+      if (lane == 0) yws[n] = yaw_i;
+      sz = n + 1;
+    }
+    __syncthreads();
+    const int target = sz >> 1;
+    float found = 0.f;
+    int have = 0;
+    for (int c0 = 0; c0 < sz; c0 += 64) {
+      int c = c0 + lane;
+      int ok = 0;
+      float v = 0.f;
+      if (c < sz) {
+        v = yws[c];
+        int less = 0, eq = 0;
+        for (int k = 0; k < sz; ++k) {
+          float u = yws[k];
+          less += (u < v);
+          eq += (u == v);
+        }
+        ok = (less <= target) && (target < less + eq);
+      }
+      unsigned long long bm = __ballot(ok);
+      if (bm != 0ull && !have) {
+        int src = __ffsll(bm) - 1;
+        found = __shfl(v, src);
+        have = 1;
+      } else {
+        (void)__shfl(v, 0);  // keep the collective wave-uniform
+      }
+    }
+    if (have) med = found;
+  }
+  // weighted sums in neighbourhood order (nms.h:541-573): lane f < 11 owns field f
+  float sum1 = 0.f, sum3 = 0.f;
+  for (int k = 0; k < n; ++k) {
+    const float* r = dets + (size_t)order[nbl[k]] * 12;
+    float yl = r[8];
+    if ((double)fmodf(fabsf(yl - med), float(2 * 3.1415926)) >= 0.3) continue;
+    float p = r[11];
+    if (lane < 11) {
+      sum1 += p * r[lane];
+      sum3 += p;
+    }
+  }
+  if (lane < 11) out[(size_t)mrow * 12 + lane] = sum1 / sum3;
+  if (lane == 11) out[(size_t)mrow * 12 + 11] = dets[(size_t)irow * 12 + 11];
+}
+
+__global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) order[i] = i;
+}
+
+struct WnmsWs {
+  float* prep;
+  unsigned long long *thr, *vote;
+  int *keep_q, *order;
+  void* sort_ws;
+  int nwcap;
+};
+inline size_t wnms_ws_bytes(int cap);
+inline WnmsWs wnms_ws_carve(void* ws, int cap);
+
+}  // namespace rd

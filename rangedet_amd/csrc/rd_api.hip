@@ -1,0 +1,351 @@
+// librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
+#include "k_conv.h"
+#include "k_meta.h"
+#include "k_misc.h"
+#include "k_riou.h"
+#include "k_sort.h"
+#include "k_wnms.h"
+
+#include <algorithm>
+#include <numeric>
+
+using namespace rd;
+
+namespace rd {
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t wnms_ws_bytes(int cap) {
+  const size_t nw = (size_t)(cap + 63) / 64;
+  return align256((size_t)cap * PREP_F * 4) + 2 * align256((size_t)cap * nw * 8) + 2 * align256((size_t)cap * 4) +
+         align256(sort_ws_bytes(cap)) + 256;
+}
+inline WnmsWs wnms_ws_carve(void* ws, int cap) {
+  WnmsWs w;
+  const size_t nw = (size_t)(cap + 63) / 64;
+  unsigned char* p = (unsigned char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  w.nwcap = (int)nw;
+  w.prep = (float*)p; p += align256((size_t)cap * PREP_F * 4);
+  w.thr = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
+  w.vote = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
+  w.keep_q = (int*)p; p += align256((size_t)cap * 4);
+  w.order = (int*)p; p += align256((size_t)cap * 4);
+  w.sort_ws = p;
+  return w;
+}
+template <class K>
+inline void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+}  // namespace rd
+
+extern "C" {
+
+int rd_version(void) { return 100; }
+const char* rd_last_error_string(void) { return rd::err_buf(); }
+
+// ---- layout ---------------------------------------------------------------------------------------------
+int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int dst_cstride, int dst_coff,
+                    int zero_pad, int dst_dtype, void* stream) {
+  RD_REQUIRE(src && dst, RD_EINVAL, "nchw_to_nhwc: null pointer");
+  RD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && zero_pad >= 0, RD_ESHAPE, "nchw_to_nhwc: bad shape");
+  RD_REQUIRE(dst_coff >= 0 && dst_coff + C + zero_pad <= dst_cstride, RD_ESHAPE, "nchw_to_nhwc: channels exceed stride");
+  hipStream_t st = (hipStream_t)stream;
+  const long HW = (long)H * W, total = (long)B * (C + zero_pad) * HW;
+  const int grid = (int)std::min<long>((total + 255) / 256, 8192);
+  ProfScope ps(RD_PROF_LAYOUT, st);
+  if (dst_dtype == RD_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_BF16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
+  else if (dst_dtype == RD_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_F32>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
+  else
+    return rd::fail(RD_EINVAL, "nchw_to_nhwc: dtype %d", dst_dtype);
+  return check_launch("nchw_to_nhwc");
+}
+int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int src_cstride, int src_coff,
+                    int src_dtype, void* stream) {
+  RD_REQUIRE(src && dst, RD_EINVAL, "nhwc_to_nchw: null pointer");
+  RD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, RD_ESHAPE, "nhwc_to_nchw: bad shape");
+  RD_REQUIRE(src_coff >= 0 && src_coff + C <= src_cstride, RD_ESHAPE, "nhwc_to_nchw: channels exceed stride");
+  hipStream_t st = (hipStream_t)stream;
+  const long HW = (long)H * W, total = (long)B * C * HW;
+  const int grid = (int)std::min<long>((total + 255) / 256, 8192);
+  ProfScope ps(RD_PROF_LAYOUT, st);
+  if (src_dtype == RD_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<RD_BF16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, src_cstride, src_coff, total);
+  else if (src_dtype == RD_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<RD_F32>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, src_cstride, src_coff, total);
+  else
+    return rd::fail(RD_EINVAL, "nhwc_to_nchw: dtype %d", src_dtype);
+  return check_launch("nhwc_to_nchw");
+}
+
+// ---- packing (host) -------------------------------------------------------------------------------------
+size_t rd_conv_packed_bytes(int ntaps, int cin, int cout, int dtype) { return conv_packed_bytes(ntaps, cin, cout, dtype); }
+int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, int dtype, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv: null pointer");
+  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_conv: dtype");
+  RD_REQUIRE(kh * kw >= 1 && kh * kw <= 9 && (kh & 1) && (kw & 1), RD_ESHAPE, "pack_conv: kernel (%d,%d)", kh, kw);
+  TapList tl = conv_taps(kh, kw);
+  pack_taps(tl.n, cin, cout, dtype, out, [&](int co, int ci, int t) {
+    return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]];
+  });
+  return RD_OK;
+}
+int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase) {
+  if (stride_w < 1 || phase < 0 || phase >= stride_w) return RD_EINVAL;
+  TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
+  return tl.n > 9 ? RD_ESHAPE : tl.n;
+}
+int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                               int phase, int dtype, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_deconv: null pointer");
+  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_deconv: dtype");
+  RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
+  TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
+  RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
+  pack_taps(tl.n, cin, cout, dtype, out, [&](int co, int ci, int t) {
+    return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
+  });
+  return RD_OK;
+}
+
+// ---- conv family ------------------------------------------------------------------------------------------
+int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
+                     const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                     int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int flags,
+                     int dtype, void* stream) {
+  RD_REQUIRE(x && w_packed && y, RD_EINVAL, "conv2d: null pointer");
+  RD_REQUIRE((kh == 1 && kw == 1) || (kh == 3 && kw == 3), RD_ESHAPE, "conv2d: kernel (%d,%d) not in {1x1,3x3}", kh, kw);
+  RD_REQUIRE(stride_w == 1 || stride_w == 2, RD_ESHAPE, "conv2d: stride_w %d", stride_w);
+  RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "conv2d: y channels exceed stride");
+  const int pad = (kw - 1) / 2;
+  const int Wout = (Win + 2 * pad - kw) / stride_w + 1;  // mx Convolution output size
+  TapList tl = conv_taps(kh, kw);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 1>);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 1>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 2>);
+  return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
+                     y_coff, B, H, Win, Wout, Wout, cin, cout, stride_w, 1, 0, flags, dtype, (hipStream_t)stream);
+}
+int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase, const float* scale,
+                       const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                       int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                       int phase, int flags, int dtype, void* stream) {
+  RD_REQUIRE(x && w_packed_phase && y, RD_EINVAL, "deconv2d: null pointer");
+  RD_REQUIRE(kh == 3, RD_ESHAPE, "deconv2d: kernel height %d (only 3, pad 1, stride 1)", kh);
+  RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "deconv2d: phase %d of stride %d", phase, stride_w);
+  RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "deconv2d: y channels exceed stride");
+  const int Wout = (Win - 1) * stride_w - 2 * pad_w + kw;  // mx Deconvolution output size
+  RD_REQUIRE(Wout > phase, RD_ESHAPE, "deconv2d: empty phase");
+  const int Wq = (Wout - phase + stride_w - 1) / stride_w;
+  TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
+  RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "deconv2d: %d taps per phase unsupported", tl.n);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 1>);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 1>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 2>);
+  return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
+                     y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
+                     (hipStream_t)stream);
+}
+
+int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const float* bias, float* out,
+                long out_batch_stride, long n_off, int B, int H, int W, int cin, int nout, int dtype, void* stream) {
+  RD_REQUIRE(x && w && bias && out, RD_EINVAL, "head_out: null pointer");
+  RD_REQUIRE(cin % 8 == 0 && cin <= 128 && cin > 0, RD_ESHAPE, "head_out: cin %d (multiple of 8, <= 128)", cin);
+  RD_REQUIRE(nout == 1 || nout == 7 || nout == 8, RD_ESHAPE, "head_out: nout %d not in {1,7,8}", nout);
+  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "head_out: dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const long HW = (long)H * W;
+  dim3 grid((unsigned)std::min<long>((HW + 31) / 32, 4096), B);
+  ProfScope ps(RD_PROF_HEAD_OUT, st);
+#define RD_HO(DT, NO) hipLaunchKernelGGL((head_out_kernel<DT, NO>), grid, dim3(256), 0, st, x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
+  if (dtype == RD_BF16) { if (nout == 1) RD_HO(RD_BF16, 1); else if (nout == 7) RD_HO(RD_BF16, 7); else RD_HO(RD_BF16, 8); }
+  else { if (nout == 1) RD_HO(RD_F32, 1); else if (nout == 7) RD_HO(RD_F32, 7); else RD_HO(RD_F32, 8); }
+#undef RD_HO
+  return check_launch("head_out");
+}
+
+// ---- Meta-Kernel ---------------------------------------------------------------------------------------------
+size_t rd_meta_packed_bytes(int dtype) { return meta_layout(dtype).total; }
+int rd_pack_meta_host(const float* w0, const float* b0, const float* w1, const float* b1, const float* s1,
+                      const float* t1, const float* agg, const float* s2, const float* t2, int dtype, void* out) {
+  RD_REQUIRE(w0 && b0 && w1 && b1 && s1 && t1 && agg && s2 && t2 && out, RD_EINVAL, "pack_meta: null pointer");
+  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_meta: dtype");
+  pack_meta(w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype, out);
+  return RD_OK;
+}
+int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float* coord_nchw, const void* packed,
+                       void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream) {
+  RD_REQUIRE(data && coord_nchw && packed && y, RD_EINVAL, "meta_kernel: null pointer");
+  RD_REQUIRE(B > 0 && H > 0 && W > 0, RD_ESHAPE, "meta_kernel: empty shape");
+  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "meta_kernel: dtype");
+  const int ch = ch_per_slot(dtype);
+  RD_REQUIRE(d_cstride % ch == 0 && d_coff % ch == 0 && y_cstride % ch == 0 && y_coff % ch == 0, RD_ESHAPE,
+             "meta_kernel: channel strides/offsets must be 16-byte multiples");
+  RD_REQUIRE(d_coff + 64 <= d_cstride && y_coff + 64 <= y_cstride, RD_ESHAPE, "meta_kernel: needs 64 channels");
+  hipStream_t st = (hipStream_t)stream;
+  MetaArgs a;
+  a.data = data; a.d_cs = d_cstride; a.d_co = d_coff; a.coord = coord_nchw; a.packed = (const unsigned char*)packed;
+  a.y = y; a.y_cs = y_cstride; a.y_co = y_coff; a.B = B; a.H = H; a.W = W;
+  constexpr int WAVES = 8;
+  a.tiles_h = (H + WAVES - 1) / WAVES;
+  a.tiles_w = (W + 31) / 32;
+  a.ntiles = B * a.tiles_h * a.tiles_w;
+  const size_t consts = 9 * 64 * 4 * 2 + 1024;
+  ProfScope ps(RD_PROF_META, st);
+  if (dtype == RD_BF16) {
+    const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128;
+    allow_big_lds(meta_kernel<RD_BF16, WAVES>);
+    hipLaunchKernelGGL((meta_kernel<RD_BF16, WAVES>), dim3(std::min(a.ntiles, 256)), dim3(WAVES * 64), lds, st, a);
+  } else {
+    const size_t lds = consts + (size_t)(WAVES + 2) * 34 * 256;
+    allow_big_lds(meta_kernel<RD_F32, WAVES>);
+    hipLaunchKernelGGL((meta_kernel<RD_F32, WAVES>), dim3(std::min(a.ntiles, 512)), dim3(WAVES * 64), lds, st, a);
+  }
+  return check_launch("meta_kernel");
+}
+
+// ---- post-processing -------------------------------------------------------------------------------------------
+size_t rd_sorted_foreground_workspace_bytes(long N, long k) { (void)k; return sort_ws_bytes(N) + 256; }
+int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const float* pc, const float* mask, int B,
+                         long N, long k, int D, int apply_sigmoid, float* out_score, float* out_delta, float* out_pc,
+                         int* out_idx, void* ws, size_t ws_bytes, void* stream) {
+  RD_REQUIRE(cls_score && bbox_delta && pc && out_score && out_delta && out_pc && ws, RD_EINVAL, "sorted_foreground: null pointer");
+  RD_REQUIRE(B > 0 && N > 0 && k > 0 && D > 0, RD_ESHAPE, "sorted_foreground: empty shape");
+  RD_REQUIRE(N >= k, RD_ESHAPE, "sorted_foreground: N (%ld) < num_fgs (%ld)", N, k);  // get_sorted_foreground.py:65
+  RD_REQUIRE(N < (1L << 31), RD_ESHAPE, "sorted_foreground: N too large");
+  RD_REQUIRE(ws_bytes >= rd_sorted_foreground_workspace_bytes(N, k), RD_EWORKSPACE, "sorted_foreground: workspace %zu < %zu",
+             ws_bytes, rd_sorted_foreground_workspace_bytes(N, k));
+  hipStream_t st = (hipStream_t)stream;
+  void* wsa = (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  SortWs s = sort_ws_carve(wsa, N);
+  ProfScope ps(RD_PROF_SORT, st);
+  for (int b = 0; b < B; ++b) {
+    hipLaunchKernelGGL(sort_keygen_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, cls_score + (size_t)b * N,
+                       mask ? mask + (size_t)b * N : nullptr, N, apply_sigmoid, s.keysA, s.idxA);
+    int rc = radix_sort_pairs(s, N, st);
+    if (rc != RD_OK) return rc;
+    hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, s.keysA, s.idxA, k, D,
+                       bbox_delta + (size_t)b * N * D, pc + (size_t)b * N * 3, out_score + (size_t)b * k,
+                       out_delta + (size_t)b * k * D, out_pc + (size_t)b * k * 3, out_idx ? out_idx + (size_t)b * k : nullptr);
+  }
+  return check_launch("sorted_foreground");
+}
+
+int rd_decode3d_bbox(const float* bbox_delta, const float* pc, float* out, int B, long N, int box_type, int is_bin,
+                     void* stream) {
+  RD_REQUIRE(bbox_delta && pc && out, RD_EINVAL, "decode3d: null pointer");
+  RD_REQUIRE(B > 0 && N > 0, RD_ESHAPE, "decode3d: empty shape");
+  RD_REQUIRE((is_bin && box_type == 7) || (!is_bin && box_type == 8), RD_ESHAPE,
+             "decode3d: box_type %d with is_bin=%d (8 for regular, 7 for bin)", box_type, is_bin);
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * N;
+  ProfScope ps(RD_PROF_DECODE, st);
+  hipLaunchKernelGGL(decode3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bbox_delta, pc, out, n, box_type, is_bin);
+  return check_launch("decode3d");
+}
+
+size_t rd_score_filter_workspace_bytes(long n) { return (size_t)((n + 255) / 256 + 8) * 4 + 256; }
+int rd_score_filter_dets(const float* scores, const float* boxes10, long n, float min_score, float* dets, int* d_count,
+                         void* ws, size_t ws_bytes, void* stream) {
+  RD_REQUIRE(scores && boxes10 && dets && d_count && ws, RD_EINVAL, "score_filter: null pointer");
+  RD_REQUIRE(n > 0, RD_ESHAPE, "score_filter: empty input");
+  RD_REQUIRE(ws_bytes >= rd_score_filter_workspace_bytes(n), RD_EWORKSPACE, "score_filter: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int* blk = (int*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  const int nblk = (int)((n + 255) / 256);
+  ProfScope ps(RD_PROF_WNMS, st);
+  hipLaunchKernelGGL(filter_count_kernel, dim3(nblk), dim3(256), 0, st, scores, n, min_score, blk);
+  hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(256), 0, st, blk, nblk, d_count);
+  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblk), dim3(256), 0, st, scores, boxes10, n, min_score, blk, dets);
+  return check_launch("score_filter");
+}
+
+size_t rd_wnms_workspace_bytes(int Kcap) { return Kcap > 0 ? wnms_ws_bytes(Kcap) : 0; }
+int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh, float thresh_vote,
+               int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws, size_t ws_bytes, void* stream) {
+  RD_REQUIRE(dets && out_dets && keep && d_nkeep && ws, RD_EINVAL, "wnms_4c: null pointer");
+  RD_REQUIRE(Kcap > 0 && Kcap <= RD_WNMS_MAX_K, RD_ESHAPE, "wnms_4c: Kcap %d not in [1, %d]", Kcap, RD_WNMS_MAX_K);
+  RD_REQUIRE(ws_bytes >= rd_wnms_workspace_bytes(Kcap), RD_EWORKSPACE, "wnms_4c: workspace %zu < %zu", ws_bytes,
+             rd_wnms_workspace_bytes(Kcap));
+  hipStream_t st = (hipStream_t)stream;
+  WnmsWs w = wnms_ws_carve(ws, Kcap);
+  ProfScope ps(RD_PROF_WNMS, st);
+  const int* ord = order;
+  if (!ord) {  // device ordering: score descending, ties by row index ascending
+    void* swa = (void*)(((uintptr_t)w.sort_ws + 255) & ~(uintptr_t)255);
+    SortWs s = sort_ws_carve(swa, Kcap);
+    hipLaunchKernelGGL(sort_keygen_dets_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, Kcap, d_count, s.keysA, s.idxA);
+    int rc = radix_sort_pairs(s, Kcap, st);
+    if (rc != RD_OK) return rc;
+    if (hipMemcpyAsync(w.order, s.idxA, (size_t)Kcap * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return rd::fail(RD_EHIP, "wnms_4c: order copy");
+    ord = w.order;
+  }
+  const int nb = (Kcap + 63) / 64;
+  hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep);
+  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb, nb), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d,
+                     w.thr, w.vote, w.nwcap);
+  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), 0, st, w.thr, w.vote, Kcap, d_count, w.nwcap, ord, w.keep_q,
+                     keep, d_nkeep);
+  allow_big_lds(wnms_merge_kernel);
+  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), 0, st, dets, ord, w.vote, Kcap, d_count, w.nwcap, w.keep_q,
+                     d_nkeep, out_dets);
+  return check_launch("wnms_4c");
+}
+int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
+  RD_REQUIRE(K >= 0 && (K == 0 || (dets_host && order_host)), RD_EINVAL, "wnms_order_host: bad arguments");
+  // the reference's ordering, literally (nms.h:786-792): std::sort is unstable, so equal scores come out in
+  // libstdc++ introsort order -- reproduced by running the same call on the host.
+  std::iota(order_host, order_host + K, 0);
+  std::sort(order_host, order_host + K, [&](int i, int j) { return dets_host[i * 12 + 11] > dets_host[j * 12 + 11]; });
+  return RD_OK;
+}
+
+int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out8, void* stream) {
+  RD_REQUIRE(dets12 && out8, RD_EINVAL, "dets12_to_8: null pointer");
+  RD_REQUIRE(Mcap > 0, RD_ESHAPE, "dets12_to_8: empty input");
+  hipLaunchKernelGGL(dets12_to_8_kernel, dim3((Mcap + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets12, Mcap, d_count, out8);
+  return check_launch("dets12_to_8");
+}
+
+int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream) {
+  RD_REQUIRE(boxes1 && boxes2 && ious, RD_EINVAL, "rotated_iou: null pointer");
+  RD_REQUIRE(n1 > 0 && n2 > 0, RD_ESHAPE, "rotated_iou: empty input");
+  hipLaunchKernelGGL(riou8_kernel, dim3((unsigned)((n1 * n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, ious, n1, n2);
+  return check_launch("rotated_iou_8pt");
+}
+int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt, void* stream) {
+  RD_REQUIRE(proposals && gt8 && out, RD_EINVAL, "batch_max_iou: null pointer");
+  RD_REQUIRE(n > 0 && n_gt > 0 && n_gt <= 256 && p_stride >= 8, RD_ESHAPE, "batch_max_iou: n_gt %d (<=256), p_stride %d (>=8)", n_gt, p_stride);
+  hipLaunchKernelGGL(batch_max_iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, proposals, p_stride, gt8, out, n, n_gt);
+  return check_launch("batch_max_iou");
+}
+
+// ---- profiling -------------------------------------------------------------------------------------------------
+int rd_prof_enable(int on) {
+  Prof& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.on = on != 0;
+  return RD_OK;
+}
+int rd_prof_reset(void) {
+  Prof& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.drain();
+  for (int k = 0; k < RD_PROF_NKINDS; ++k) { p.total[k] = 0; p.count[k] = 0; }
+  return RD_OK;
+}
+int rd_prof_get(int kind, double* total_ms, long* launches) {
+  RD_REQUIRE(kind >= 0 && kind < RD_PROF_NKINDS && total_ms && launches, RD_EINVAL, "prof_get: bad arguments");
+  Prof& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.drain();
+  *total_ms = p.total[kind];
+  *launches = p.count[kind];
+  return RD_OK;
+}
+
+}  // extern "C"

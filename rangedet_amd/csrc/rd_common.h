@@ -1,0 +1,134 @@
+// Shared host/device helpers for librangedet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rangedet_hip.h"
+
+namespace rd {
+
+// ---- error channel ---------------------------------------------------------------------------------
+inline char* err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define RD_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) return rd::fail(code, __VA_ARGS__); \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RD_EHIP, "%s: %s", what, hipGetErrorString(e));
+  return RD_OK;
+}
+
+// ---- per-kind event profiling ------------------------------------------------------------------------
+struct Prof {
+  bool on = false;
+  std::mutex mu;
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+  double total[RD_PROF_NKINDS] = {0};
+  long count[RD_PROF_NKINDS] = {0};
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void drain() {
+    for (auto& s : spans) {
+      hipEventSynchronize(s.b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, s.a, s.b);
+      total[s.kind] += ms;
+      count[s.kind] += 1;
+      pool.push_back(s.a);
+      pool.push_back(s.b);
+    }
+    spans.clear();
+  }
+};
+inline Prof& prof() {
+  static Prof p;
+  return p;
+}
+struct ProfScope {
+  hipEvent_t a = nullptr;
+  int kind;
+  hipStream_t st;
+  ProfScope(int k, hipStream_t s) : kind(k), st(s) {
+    Prof& p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> g(p.mu);
+    a = p.get();
+    hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    Prof& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    hipEvent_t b = p.get();
+    hipEventRecord(b, st);
+    p.spans.push_back({a, b, kind});
+  }
+};
+
+// ---- element types -----------------------------------------------------------------------------------
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32 on gfx950
+#endif
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+template <int DT> struct Elem;
+template <> struct Elem<RD_F32> {
+  typedef float T;
+  static constexpr int CH = 4;  // channels per 16-byte slot
+  __host__ __device__ static float from_f32(float v) { return v; }
+  __host__ __device__ static float to_f32(float v) { return v; }
+};
+template <> struct Elem<RD_BF16> {
+  typedef bf16_t T;
+  static constexpr int CH = 8;
+  __host__ __device__ static bf16_t from_f32(float v) { return f32_to_bf16(v); }
+  __host__ __device__ static float to_f32(bf16_t v) { return bf16_to_f32(v); }
+};
+inline int elem_size(int dt) { return dt == RD_BF16 ? 2 : 4; }
+inline int ch_per_slot(int dt) { return dt == RD_BF16 ? 8 : 4; }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+typedef unsigned Slot16 __attribute__((ext_vector_type(4)));  // one 16-byte LDS/global granule (register-resident)
+
+}  // namespace rd
