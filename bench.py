@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- range-image frames/s of the RangeDet inference hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full pass of the hot path over one synthetic 64x2650(pad 2656)x8 range image per rank:
+DLA backbone + fused Meta-Kernel + 3-level heads + sigmoid/top-50000/sort + 3D box decode + score filter + weighted NMS
+(config `rangedet_veh_wo_aug_4_18e`, bf16 activations/weights with fp32 accumulation; BASELINE configs[1] plus the WNMS
+of configs[2]).  Inputs are resident in HBM before the timed region.  Frames shard across ranks with no data-path
+collective (weak scaling); for N > 1 every step ends with the one RCCL all_gather of the padded detections
+(SURVEY.md 8e).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0
+MAX_DET = 200               # rpn_post_nms_top_n / padded gather rows (config:139)
+
+
+def conv_flops(plan):
+    """Algorithmic FLOPs of the conv-family launches of one frame, and the number of launches (from the lowered plan)."""
+    fl, n = 0.0, 0
+    for s in plan.steps:
+        if s["kind"] == "conv":
+            fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
+            n += 1
+        elif s["kind"] == "deconv":
+            # every output pixel sums kh*kw/stride taps
+            fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1] / s["stride_w"]
+            n += s["stride_w"]
+    return fl, n
+
+
+def cpu_baseline(params, frame, budget_frames=1):
+    """The oracle (PyTorch-CPU fp32 restatement + C++ decode/wnms) timed on this box's host cores: reported, not a target."""
+    import torch
+    from oracle import graph_ref
+    t0 = time.time()
+    for _ in range(budget_frames):
+        out = graph_ref.forward(frame, params)
+        graph_ref.postprocess(out["fg_cls_score"][0], out["decoded_bbox"][0])
+    dt = time.time() - t0
+    return {"value": budget_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frame(s) of the same 64x2656x8 workload: PyTorch-CPU fp32 restatement of the MXNet graph "
+                      "(the reference's MXNet CPU path cannot run: mxnet is not installed) + C++ decode/wnms restatement" % budget_frames}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rangedet_amd import lib as rdlib, synth
+    from rangedet_amd.pipeline import RangeDetPipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dt = rdlib.RD_BF16 if args.dtype == "bf16" else rdlib.RD_F32
+
+    params = synth.make_weights(seed=18)
+    pipe = RangeDetPipeline(params, dtype=dt, wnms_cap=4096)
+    # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
+    frames_np = [synth.make_frame(rank + world * i) for i in range(args.frames)]
+    frames = [{k: torch.from_numpy(v).to(dev) for k, v in f.items()} for f in frames_np]
+    L = pipe.lib
+    gather_in = torch.zeros(MAX_DET * 12 + 1, device=dev)
+    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
+    post = pipe.post[0]
+    A = pipe.alloc
+
+    def step(i):
+        pipe.enqueue(frames[i % len(frames)])
+        if world > 1:
+            rows = A.view_f32(post.out, (post.cap, 12))[:MAX_DET].reshape(-1)
+            gather_in[:-1].copy_(rows)
+            gather_in[-1:].copy_(A.view_i32(post.nkeep, (1,)).float())
+            dist.all_gather(gather_out, gather_in)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = post.collect()
+
+    # ---- per-kernel timing with HIP events on the launch stream, over a replay of the same steps ------------------
+    roof = meta_info = prof = None
+    if rank == 0:
+        L.call("rd_prof_reset")
+        L.call("rd_prof_enable", 1)
+        nprof = min(args.steps, 20)
+        for i in range(nprof):
+            pipe.enqueue(frames[i % len(frames)])
+        torch.cuda.synchronize(dev)
+        prof = L.prof()
+        L.call("rd_prof_enable", 0)
+        fl, nlaunch = conv_flops(pipe.plan)
+        ms, cnt = prof["conv"]
+        avg_ms = ms / max(cnt, 1)
+        achieved = (fl / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0
+        roof = {"kernel": "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
+                "achieved": achieved, "peak": PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3, "unit": "TFLOP/s",
+                "frac": achieved / (PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3), "traffic": None,
+                "launches_per_frame": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_frame": fl / 1e9}
+        mms, mcnt = prof["meta"]
+        esz = 2 if dt == rdlib.RD_BF16 else 4
+        mbytes = 64 * 2656 * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)
+        meta_info = {"kernel": "meta_kernel (fused Meta-Kernel unit)", "bound": "hbm",
+                     "achieved": mbytes / (mms / max(mcnt, 1) * 1e-3) / 1e9 if mcnt else 0.0, "peak": PEAK_HBM_GBPS,
+                     "unit": "GB/s", "avg_launch_ms": mms / max(mcnt, 1), "bytes_per_launch": mbytes,
+                     "tflops": 19.29e9 / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
+        meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
+
+    if rank == 0:
+        out = {
+            "metric": "range-image frames/sec (64x2650, 8ch) at 1/2/4/8 GPU; Meta-Kernel HBM GB/s vs peak",
+            "value": args.steps * world / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "rangedet_veh_wo_aug_4_18e: DLA backbone + Meta-Kernel + heads + top-50000 + 3D decode "
+                                   "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, 1 frame per step per GPU, "
+                                   "random-init weights (seed 18)", "frames_per_step": world, "parallelism": "frame-parallel dp%d" % world,
+                       "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"]))},
+            "roofline": roof, "meta_kernel": meta_info,
+            "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(params, frames_np[0])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""ctypes binding of librangedet_hip.so (include/rangedet_hip.h).
+
+The product path: ``get_lib()`` opens ``rangedet_amd/librangedet_hip.so`` -- built by ``rangedet_amd.build`` with
+hipcc for gfx950 -- and raises ``RuntimeError`` when it is missing.  There is no CPU fallback of any kind.
+(``Lib(path)`` takes an explicit path only so that the CPU-only test tier can bind the hipemu build of the same
+sources, tests/emu; nothing in this package ever does that.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
+RD_F32, RD_BF16 = 0, 1
+RD_RELU_PRE, RD_ADD, RD_RELU_POST = 1, 2, 4
+RD_WNMS_MAX_K = 16384
+PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "librangedet_hip.so")
+
+c_int, c_long, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/rangedet_hip.h declares
+SIGNATURES = {
+    "rd_version": (c_int, []),
+    "rd_last_error_string": (ctypes.c_char_p, []),
+    "rd_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rd_pack_conv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_deconv_phase_taps": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "rd_pack_deconv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_conv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p]),
+    "rd_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_void_p]),
+    "rd_meta_packed_bytes": (c_size_t, [c_int]),
+    "rd_pack_meta_host": (c_int, [c_void_p] * 9 + [c_int, c_void_p]),
+    "rd_meta_kernel_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p]),
+    "rd_sorted_foreground_workspace_bytes": (c_size_t, [c_long, c_long]),
+    "rd_sorted_foreground": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_long, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rd_decode3d_bbox": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
+    "rd_score_filter_workspace_bytes": (c_size_t, [c_long]),
+    "rd_score_filter_dets": (c_int, [c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rd_wnms_workspace_bytes": (c_size_t, [c_int]),
+    "rd_wnms_4c": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_size_t, c_void_p]),
+    "rd_wnms_order_host": (c_int, [c_void_p, c_int, c_void_p]),
+    "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),
+    "rd_batch_max_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "rd_prof_enable": (c_int, [c_int]),
+    "rd_prof_reset": (c_int, []),
+    "rd_prof_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_long)]),
+}
+
+
+class RangeDetError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librangedet_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def ptr(x):
+    """Raw address of a numpy array, a torch tensor, an int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+class Lib:
+    def __init__(self, path=DEFAULT_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s not found: the HIP extension is not built (run `python -m rangedet_amd.build`). "
+                "There is no CPU fallback." % path)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        self.rd_last_error_string = self.cdll.rd_last_error_string
+
+    def call(self, name, *args):
+        """Invoke a status-returning entry point; raise RangeDetError on a negative status."""
+        rc = getattr(self.cdll, name)(*args)
+        if rc < 0:
+            raise RangeDetError(rc, self.cdll.rd_last_error_string().decode())
+        return rc
+
+    def raw(self, name):
+        return getattr(self.cdll, name)
+
+    # ---- host-side packers (numpy in, numpy out) ---------------------------------------------------------
+    def pack_conv_weight(self, w_oihw, dtype):
+        w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+        cout, cin, kh, kw = w.shape
+        out = np.zeros(self.cdll.rd_conv_packed_bytes(kh * kw, cin, cout, dtype), dtype=np.uint8)
+        self.call("rd_pack_conv_weight_host", w.ctypes.data, cout, cin, kh, kw, dtype, out.ctypes.data)
+        return out
+
+    def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype):
+        w = np.ascontiguousarray(w_iohw, dtype=np.float32)
+        cin, cout, kh, kw = w.shape
+        nt = self.cdll.rd_deconv_phase_taps(kh, kw, stride_w, pad_w, phase)
+        if nt < 0:
+            raise RangeDetError(nt, "deconv phase taps")
+        out = np.zeros(self.cdll.rd_conv_packed_bytes(nt, cin, cout, dtype), dtype=np.uint8)
+        self.call("rd_pack_deconv_weight_host", w.ctypes.data, cin, cout, kh, kw, stride_w, pad_w, phase, dtype,
+                  out.ctypes.data)
+        return out
+
+    def pack_meta(self, w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (w0, b0, w1, b1, s1, t1, agg, s2, t2)]
+        assert arrs[0].shape == (32, 3) and arrs[2].shape == (64, 32) and arrs[6].shape == (64, 576)
+        out = np.zeros(self.cdll.rd_meta_packed_bytes(dtype), dtype=np.uint8)
+        self.call("rd_pack_meta_host", *[a.ctypes.data for a in arrs], dtype, out.ctypes.data)
+        return out
+
+    def wnms_order_host(self, dets):
+        d = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 12)
+        order = np.empty(d.shape[0], dtype=np.int32)
+        self.call("rd_wnms_order_host", d.ctypes.data, d.shape[0], order.ctypes.data)
+        return order
+
+    def prof(self):
+        out = {}
+        ms, n = ctypes.c_double(), c_long()
+        for k, v in PROF_KINDS.items():
+            self.call("rd_prof_get", v, ctypes.byref(ms), ctypes.byref(n))
+            out[k] = (ms.value, n.value)
+        return out
+
+
+_LIB = None
+
+
+def get_lib():
+    """The product library.  Raises RuntimeError if librangedet_hip.so has not been built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib(DEFAULT_PATH)
+    return _LIB

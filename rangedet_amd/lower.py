@@ -1,0 +1,411 @@
+"""Lowering: recorded symbol graph (rangedet_amd.mx) -> plan of fused HIP launches (include/rangedet_hip.h).
+
+Fusions (each replaces an MXNet op chain of the reference by one kernel):
+  relu(BN(Convolution(x)))                         -> rd_conv2d_bn_act                         (dla_backbone.py:24-32, builder.py:221-240)
+  relu(BN(Convolution(x)) + shortcut)              -> rd_conv2d_bn_act + RD_ADD|RD_RELU_POST   (dla_backbone.py:34-56)
+  BN(Convolution 1x1)   (projection shortcut)      -> rd_conv2d_bn_act, no activation          (dla_backbone.py:44-51)
+  skip + relu(BN(Deconvolution(u)))                -> rd_deconv2d_bn_act per phase, RD_RELU_PRE|RD_ADD   (dla_backbone.py:117-126)
+  meta_baseline_bias(...) + BN + relu + 1x1 + BN + relu   -> rd_meta_kernel_fwd                (meta_kernel.py:166-240, dla_backbone.py:92-97)
+  concat(data, agg3)                               -> producers write straight into one buffer (dla_backbone.py:153-154)
+  1x1 logit/delta conv + cast + reshape/slice/squeeze/transpose + concat over levels
+                                                   -> rd_head_out into flat (B,N[,8]) buffers   (builder.py:242-261,99-154)
+  sigmoid + Custom(get_sorted_foreground)          -> rd_sorted_foreground(apply_sigmoid=1)     (builder.py:459-461,512-521)
+  contrib.Decode3DBbox                             -> rd_decode3d_bbox                          (builder.py:522-525)
+Anything that does not match raises NotImplementedError at lowering time -- there is no slow generic path.
+"""
+from dataclasses import dataclass, field
+
+from .lib import RD_ADD, RD_BF16, RD_F32, RD_RELU_POST, RD_RELU_PRE
+
+
+@dataclass
+class TRef:
+    """Channels-last activation [B][H][W][cs], channels [co, co+C) of logical buffer `buf`."""
+    buf: int
+    C: int
+    H: int
+    W: int
+    cs: int
+    co: int = 0
+
+
+@dataclass
+class FlatRef:
+    """Flat float32 device tensor (B, *shape)."""
+    buf: int
+    shape: tuple
+
+
+@dataclass
+class Plan:
+    dtype: int
+    batch: int
+    steps: list = field(default_factory=list)
+    buffers: dict = field(default_factory=dict)   # logical id -> dict(nbytes, persistent, zero)
+    outputs: list = field(default_factory=list)   # per Group output: ("flat", FlatRef) | ("input", name) | ("zeros", shape)
+    input_vars: dict = field(default_factory=dict)  # var name -> shape (without batch) expected from the caller
+    num_classes: int = 1
+
+
+def _strip_cast(s):
+    while s.op == "cast":
+        s = s.inputs[0]
+    return s
+
+
+def _is(s, op, **attrs):
+    return s.op == op and all(s.attrs.get(k) == v for k, v in attrs.items())
+
+
+class Lowering:
+    def __init__(self, group, input_shapes, dtype, batch):
+        """input_shapes: var name -> shape WITHOUT the batch dim, e.g. input_data: (8,64,2656)."""
+        assert dtype in (RD_F32, RD_BF16)
+        self.dtype = dtype
+        self.esz = 2 if dtype == RD_BF16 else 4
+        self.gran = 16 if dtype == RD_BF16 else 8  # channel granule = one MFMA k-step
+        self.B = batch
+        self.shapes = dict(input_shapes)
+        self.plan = Plan(dtype=dtype, batch=batch)
+        self.memo = {}
+        self.nbuf = 0
+        self.consumers = {}
+        self._count_consumers(group)
+        for out in group.inputs:
+            self.plan.outputs.append(self.emit_value(out))
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------------
+    def _count_consumers(self, root):
+        seen = set()
+
+        def walk(s):
+            for i in s.inputs:
+                self.consumers[i.uid] = self.consumers.get(i.uid, 0) + 1
+                if i.uid not in seen:
+                    seen.add(i.uid)
+                    walk(i)
+        walk(root)
+
+    def new_buf(self, nbytes, persistent=False, zero=False):
+        self.nbuf += 1
+        self.plan.buffers[self.nbuf] = dict(nbytes=int(nbytes), persistent=persistent, zero=zero)
+        return self.nbuf
+
+    def new_act(self, C, H, W, persistent=False, zero=False, cs=None):
+        cs = cs or -(-C // self.gran) * self.gran
+        buf = self.new_buf(self.B * H * W * cs * self.esz, persistent or cs != C, zero or cs != C)
+        return TRef(buf, C, H, W, cs, 0)
+
+    def step(self, kind, **kw):
+        kw["kind"] = kind
+        self.plan.steps.append(kw)
+
+    def want_input(self, name):
+        if name not in self.shapes:
+            raise KeyError("lowering needs the shape of input variable %r" % name)
+        self.plan.input_vars[name] = tuple(self.shapes[name])
+        return tuple(self.shapes[name])
+
+    # ---- activations (4-D) ---------------------------------------------------------------------------------------
+    def emit_act(self, s, dest=None):
+        s = _strip_cast(s)
+        key = s.uid
+        if s.op == "var" and dest is not None:  # an input variable may be staged again, straight into a concat buffer
+            return self._emit_act(s, dest)
+        if key in self.memo:
+            if dest is not None:
+                raise NotImplementedError("%s is needed both stand-alone and inside a concat buffer" % s.name)
+            return self.memo[key]
+        r = self._emit_act(s, dest)
+        if dest is None:
+            self.memo[key] = r
+        return r
+
+    def _out(self, C, H, W, dest):
+        if dest is None:
+            return self.new_act(C, H, W)
+        buf, cs, co = dest
+        return TRef(buf, C, H, W, cs, co)
+
+    def _emit_act(self, s, dest):
+        if s.op == "var":
+            C, H, W = self.want_input(s.name)
+            out = self._out(C, H, W, dest) if dest else self.new_act(C, H, W, persistent=True)
+            pad = (out.cs - out.co - C) if dest is None else 0
+            self.step("nchw_in", name=s.name, out=out, zero_pad=pad)
+            return out
+        if _is(s, "Activation", act_type="relu"):
+            inner = s.inputs[0]
+            if inner.op == "elemwise_add":
+                return self._residual_block(inner, dest)
+            if inner.op == "BatchNorm" and inner.inputs[0].op == "Convolution":
+                conv = inner.inputs[0]
+                meta = self._match_meta(conv)
+                if meta is not None:
+                    return self._emit_meta(meta, conv, inner, dest)
+                return self._conv_bn(conv, inner, RD_RELU_POST, None, dest)
+        if s.op == "BatchNorm" and s.inputs[0].op == "Convolution":
+            return self._conv_bn(s.inputs[0], s, 0, None, dest)
+        if s.op == "elemwise_add":
+            return self._agg_add(s, dest)
+        if _is(s, "concat", dim=1):
+            return self._concat(s, dest)
+        raise NotImplementedError("no HIP lowering for %r (op %s) as an activation" % (s.name, s.op))
+
+    def _conv_geom(self, conv, x):
+        k = conv.attrs["kernel"]
+        st = conv.attrs["stride"]
+        pad = conv.attrs["pad"]
+        if k not in ((1, 1), (3, 3)) or st[0] != 1 or st[1] not in (1, 2) or pad != ((k[0] - 1) // 2, (k[1] - 1) // 2):
+            raise NotImplementedError("Convolution %s: kernel %s stride %s pad %s" % (conv.name, k, st, pad))
+        Wout = (x.W + 2 * pad[1] - k[1]) // st[1] + 1
+        return k, st[1], Wout
+
+    def _conv_bn(self, conv, bn, flags, residual, dest):
+        if not conv.attrs["no_bias"]:
+            raise NotImplementedError("Convolution %s with bias followed by BatchNorm" % conv.name)
+        x = self.emit_act(conv.inputs[0])
+        k, sw, Wout = self._conv_geom(conv, x)
+        cout = conv.attrs["num_filter"]
+        if cout not in (64, 128):
+            raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
+        out = self._out(cout, x.H, Wout, dest)
+        self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual, cin=x.C,
+                  cout=cout, k=k, stride_w=sw, flags=flags)
+        return out
+
+    def _residual_block(self, add, dest):
+        a, b = add.inputs
+        main = sc = None
+        for m, o in ((a, b), (b, a)):
+            if m.op == "BatchNorm" and m.inputs[0].op == "Convolution" and m.inputs[0].attrs["kernel"] == (3, 3):
+                main, sc = m, o
+                break
+        if main is None:
+            raise NotImplementedError("relu(add) without a BN(conv3x3) branch at %s" % add.name)
+        res = self.emit_act(sc)
+        return self._conv_bn(main.inputs[0], main, RD_ADD | RD_RELU_POST, res, dest)
+
+    def _agg_add(self, add, dest):
+        a, b = add.inputs
+        for skip, up in ((a, b), (b, a)):
+            if _is(up, "Activation", act_type="relu") and up.inputs[0].op == "BatchNorm" and \
+                    up.inputs[0].inputs[0].op == "Deconvolution":
+                bn = up.inputs[0]
+                dc = bn.inputs[0]
+                x = self.emit_act(dc.inputs[0])
+                res = self.emit_act(skip)
+                kh, kw = dc.attrs["kernel"]
+                sh, sw = dc.attrs["stride"]
+                ph, pw = dc.attrs["pad"]
+                if kh != 3 or sh != 1 or ph != 1:
+                    raise NotImplementedError("Deconvolution %s: kernel/stride/pad height" % dc.name)
+                Wout = (x.W - 1) * sw - 2 * pw + kw
+                cout = dc.attrs["num_filter"]
+                out = self._out(cout, x.H, Wout, dest)
+                if (res.C, res.H, res.W) != (cout, x.H, Wout):
+                    raise ValueError("agg add shape mismatch at %s" % add.name)
+                self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
+                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD)
+                return out
+        raise NotImplementedError("elemwise_add %s is not skip + relu(BN(Deconvolution))" % add.name)
+
+    def _concat(self, s, dest):
+        if dest is not None:
+            raise NotImplementedError("nested channel concat")
+        parts = [_strip_cast(i) for i in s.inputs]
+        dims = []
+        for p in parts:
+            if p.op == "var":
+                dims.append(self.want_input(p.name))
+            else:
+                dims.append(None)
+        # emit non-var parts first to learn their shape, writing into the shared buffer
+        # channel counts: var from its shape, computed parts from their producing conv
+        def chans(p):
+            if p.op == "var":
+                return self.shapes[p.name][0]
+            q = p
+            while q.op in ("Activation", "BatchNorm", "elemwise_add", "cast"):
+                q = q.inputs[0]
+            return q.attrs["num_filter"]
+        cs_list = [chans(p) for p in parts]
+        Ctot = sum(cs_list)
+        ref_hw = None
+        for p, d in zip(parts, dims):
+            if d is not None:
+                ref_hw = (d[1], d[2])
+        if ref_hw is None:
+            raise NotImplementedError("concat without a variable input: spatial size unknown before emission")
+        out = self.new_act(Ctot, ref_hw[0], ref_hw[1], persistent=True, zero=True)
+        co = 0
+        for p, c in zip(parts, cs_list):
+            r = self.emit_act(p, dest=(out.buf, out.cs, co))
+            if (r.H, r.W) != ref_hw:
+                raise ValueError("concat %s: spatial mismatch" % s.name)
+            co += c
+        return out
+
+    # ---- Meta-Kernel unit ------------------------------------------------------------------------------------------
+    def _match_meta(self, agg_conv):
+        """agg_conv = Convolution 1x1 whose input is relu(BN(reshape(multiply(reshape(im2col(data)), mlp(...)))))."""
+        try:
+            a = agg_conv.inputs[0]
+            if not _is(a, "Activation", act_type="relu"):
+                return None
+            bn1 = a.inputs[0]
+            if bn1.op != "BatchNorm" or bn1.inputs[0].op != "reshape":
+                return None
+            mul = bn1.inputs[0].inputs[0]
+            if mul.op != "multiply":
+                return None
+        except (IndexError, AttributeError):
+            return None
+        ds, wts = mul.inputs
+        if not (ds.op == "reshape" and ds.inputs[0].op == "im2col"):
+            raise NotImplementedError("meta kernel: unexpected data-sample branch at %s" % mul.name)
+        im_d = ds.inputs[0]
+        data = im_d.inputs[0]
+        if im_d.attrs != dict(kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(1, 1)):
+            raise NotImplementedError("meta kernel: only 3x3/stride 1/pad 1 sampling")
+        # weights branch: reshape(conv(relu(conv(reshape(broadcast_minus(reshape(im2col(coord)), expand_dims(coord)))))))
+        c1 = wts.inputs[0] if wts.op == "reshape" else None
+        ok = c1 is not None and c1.op == "Convolution" and _is(c1.inputs[0], "Activation", act_type="relu")
+        c0 = c1.inputs[0].inputs[0] if ok else None
+        ok = ok and c0.op == "Convolution" and c0.inputs[0].op == "reshape" and c0.inputs[0].inputs[0].op == "broadcast_minus"
+        if not ok:
+            raise NotImplementedError("meta kernel: unexpected MLP branch (only fc+relu+fc without norm)")
+        bm = c0.inputs[0].inputs[0]
+        nb, ctr = bm.inputs
+        if not (nb.op == "reshape" and nb.inputs[0].op == "im2col" and ctr.op == "expand_dims"):
+            raise NotImplementedError("meta kernel: unexpected relative-coordinate branch")
+        coord = _strip_cast(ctr.inputs[0])
+        if _strip_cast(nb.inputs[0].inputs[0]).uid != coord.uid or coord.op != "var":
+            raise NotImplementedError("meta kernel: coordinates must be one input variable")
+        if (c0.attrs["num_filter"], c1.attrs["num_filter"], agg_conv.attrs["num_filter"]) != (32, 64, 64) or \
+                c0.attrs["no_bias"] or c1.attrs["no_bias"] or not agg_conv.attrs["no_bias"]:
+            raise NotImplementedError("meta kernel: only the shipped 3->32->64 (bias) MLP, 64 data channels, 576->64")
+        return dict(data=data, coord=coord.name, mlp0=c0.name, mlp1=c1.name, bn1=bn1.name, eps1=bn1.attrs["eps"])
+
+    def _emit_meta(self, m, agg_conv, bn2, dest):
+        x = self.emit_act(m["data"])
+        if x.C != 64:
+            raise NotImplementedError("meta kernel: %d data channels" % x.C)
+        cshape = self.want_input(m["coord"])
+        if cshape != (3, x.H, x.W):
+            raise ValueError("meta kernel: coord shape %s vs data %s" % (cshape, (x.H, x.W)))
+        out = self._out(64, x.H, x.W, dest)
+        self.step("meta", x=x, out=out, coord=m["coord"], mlp0=m["mlp0"], mlp1=m["mlp1"], bn1=m["bn1"], eps1=m["eps1"],
+                  agg=agg_conv.name, bn2=bn2.name, eps2=bn2.attrs["eps"])
+        return out
+
+    # ---- head / post-processing values -----------------------------------------------------------------------------
+    def emit_value(self, s):
+        s0 = s
+        key = ("v", s.uid, s.index)
+        if key in self.memo:
+            return self.memo[key]
+        if s.op == "var":
+            self.plan.input_vars.setdefault(s.name, None)
+            v = ("input", s.name)
+        elif s.op == "zeros":
+            v = ("zeros", s.attrs["shape"])
+        elif s.op == "Custom" and s.attrs["op_type"] == "get_sorted_foreground":
+            v = ("flat", self._sorted_fg(s)[s.index])
+        elif s.op == "Decode3DBbox":
+            v = ("flat", self._decode(s))
+        else:
+            raise NotImplementedError("graph output %r (op %s) has no HIP lowering" % (s0.name, s.op))
+        self.memo[key] = v
+        return v
+
+    def _flat_levels(self, s, transposed):
+        """s = concat over levels of squeeze(slice_axis(reshape(cast(Convolution 1x1 + bias)))) [transpose for deltas].
+        Returns [(conv, class index)] in concat order."""
+        levels = s.inputs if s.op == "concat" else [s]
+        out = []
+        for lv in levels:
+            q = lv
+            if transposed:
+                if not _is(q, "transpose", axes=(0, 2, 1)):
+                    raise NotImplementedError("bbox_delta level is not transposed (0,2,1)")
+                q = q.inputs[0]
+            if q.op != "squeeze" or q.inputs[0].op != "slice_axis" or q.inputs[0].inputs[0].op != "reshape":
+                raise NotImplementedError("per-class flatten chain not recognised at %s" % lv.name)
+            sl = q.inputs[0]
+            cls_i = sl.attrs["begin"]
+            if sl.attrs["axis"] != 1 or sl.attrs["end"] != cls_i + 1:
+                raise NotImplementedError("slice_axis %s" % sl.name)
+            conv = _strip_cast(sl.inputs[0].inputs[0])
+            if conv.op != "Convolution" or conv.attrs["kernel"] != (1, 1) or conv.attrs["no_bias"]:
+                raise NotImplementedError("head output must be a 1x1 Convolution with bias at %s" % lv.name)
+            out.append((conv, cls_i))
+        return out
+
+    def _sorted_fg(self, s):
+        key = ("sfg", s.uid)
+        if key in self.memo:
+            return self.memo[key]
+        score, delta, pc, mask = s.inputs
+        apply_sigmoid = 0
+        if _is(score, "Activation", act_type="sigmoid"):
+            apply_sigmoid = 1
+            score = score.inputs[0]
+        lv_s = self._flat_levels(score, False)
+        lv_d = self._flat_levels(delta, True)
+        if len(lv_s) != len(lv_d):
+            raise ValueError("score / delta level count")
+        feats, N = [], 0
+        for (cs_, ci), (cd_, di) in zip(lv_s, lv_d):
+            fs = self.emit_act(cs_.inputs[0])
+            fd = self.emit_act(cd_.inputs[0])
+            feats.append((cs_, ci, fs, cd_, di, fd, N))
+            N += fs.H * fs.W
+        ncls = lv_s[0][0].attrs["num_filter"]
+        D = lv_d[0][0].attrs["num_filter"] // ncls
+        logit = FlatRef(self.new_buf(self.B * N * 4, persistent=True), (N,))
+        dl = FlatRef(self.new_buf(self.B * N * D * 4, persistent=True), (N, D))
+        for cs_, ci, fs, cd_, di, fd, off in feats:
+            self.step("head_out", name=cs_.name, x=fs, out=logit, n_off=off, N=N, rows=(ci, ci + 1), nout=1)
+            self.step("head_out", name=cd_.name, x=fd, out=dl, n_off=off, N=N, rows=(di * D, di * D + D), nout=D)
+        pcs = self._concat_vars(pc, 3)
+        msk = self._concat_vars(mask, None)
+        k = int(s.attrs["num_fgs"])
+        if N < k:
+            raise ValueError("get_sorted_foreground: N (%d) < num_fgs (%d)" % (N, k))  # get_sorted_foreground.py:65
+        o_s = FlatRef(self.new_buf(self.B * k * 4, persistent=True), (k,))
+        o_d = FlatRef(self.new_buf(self.B * k * D * 4), (k, D))
+        o_p = FlatRef(self.new_buf(self.B * k * 3 * 4), (k, 3))
+        self.step("sorted_fg", score=logit, delta=dl, pc=pcs, mask=msk, N=N, k=k, D=D, apply_sigmoid=apply_sigmoid,
+                  out_score=o_s, out_delta=o_d, out_pc=o_p)
+        self.memo[key] = (o_s, o_d, o_p)
+        return self.memo[key]
+
+    def _concat_vars(self, s, last):
+        parts = s.inputs if s.op == "concat" else [s]
+        names, n = [], 0
+        for p in parts:
+            p = _strip_cast(p)
+            if p.op != "var":
+                raise NotImplementedError("pc / mask inputs must be input variables")
+            shp = self.want_input(p.name)
+            names.append((p.name, shp[0]))
+            n += shp[0]
+        ref = FlatRef(self.new_buf(self.B * n * (last or 1) * 4, persistent=True), (n, last) if last else (n,))
+        self.step("concat_in", names=names, out=ref, last=last or 1, N=n)
+        return ref
+
+    def _decode(self, s):
+        d, p = s.inputs
+        if not (d.op == "Custom" and p.op == "Custom" and d.uid == p.uid and d.index == 1 and p.index == 2):
+            raise NotImplementedError("Decode3DBbox inputs must be outputs 1,2 of get_sorted_foreground")
+        o_s, o_d, o_p = self._sorted_fg(d)
+        k = o_d.shape[0]
+        out = FlatRef(self.new_buf(self.B * k * 10 * 4, persistent=True), (k, 10))
+        self.step("decode", delta=o_d, pc=o_p, out=out, k=k, box_type=o_d.shape[1], is_bin=int(s.attrs["is_bin"]))
+        return out
+
+
+def lower(test_symbol, input_shapes, dtype=RD_BF16, batch=1):
+    """test_symbol: the Group returned by RangeRCNN.get_test_symbol.  Returns a Plan."""
+    return Lowering(test_symbol, input_shapes, dtype, batch).plan

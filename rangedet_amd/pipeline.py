@@ -1,0 +1,94 @@
+"""End-to-end frame runner: the build's counterpart of the per-frame body of the reference's eval driver
+(tools/test.py:143-161 forward + :184-224 post-process): config -> test symbol -> lowered plan -> Executor, then
+score filter, 10->11 dim, weighted NMS and 12->8 dim on the device.
+"""
+import numpy as np
+
+from . import lib as rdlib
+from .config import rangedet_veh_wo_aug_4_18e as cfgmod
+from .lower import lower
+from .runtime import Executor, TorchAllocator
+
+
+def input_shapes(H, W, strides=(1, 2, 4)):
+    shapes = {'input_data': (8, H, W), 'coord_s1': (3, H, W)}
+    for s in strides:
+        shapes['pc_vehicle_frame_s%d' % s] = (H * W // s, 3)
+        shapes['range_image_mask_s%d' % s] = (H * W // s,)
+    return shapes
+
+
+class PostProcessor:
+    """tools/test.py:200-224 on the device for one frame: (k,) scores + (k,10) boxes -> (M,12) rows, keep, (M,8)."""
+
+    def __init__(self, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096):
+        self.k, self.cap = k, min(cap, rdlib.RD_WNMS_MAX_K)
+        self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
+        self.L, self.A = lib, alloc
+        A, L = alloc, lib
+        self.dets = A.alloc(k * 12 * 4)
+        self.count = A.alloc(16, zero=True)
+        self.ws_f_bytes = L.raw("rd_score_filter_workspace_bytes")(k)
+        self.ws_f = A.alloc(self.ws_f_bytes)
+        self.ws_w_bytes = L.raw("rd_wnms_workspace_bytes")(self.cap)
+        self.ws_w = A.alloc(self.ws_w_bytes)
+        self.out = A.alloc(self.cap * 12 * 4)
+        self.keep = A.alloc(self.cap * 4)
+        self.nkeep = A.alloc(16, zero=True)
+        self.out8 = A.alloc(self.cap * 8 * 4)
+
+    def enqueue(self, score_ptr, box_ptr, order_ptr=None):
+        L, A, st = self.L, self.A, self.A.stream
+        L.call("rd_score_filter_dets", score_ptr, box_ptr, self.k, self.min_score, A.ptr(self.dets), A.ptr(self.count),
+               A.ptr(self.ws_f), self.ws_f_bytes, st)
+        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr, self.thr_lo, self.thr_hi,
+               self.is3d, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, st)
+        L.call("rd_dets12_to_8", A.ptr(self.out), self.cap, A.ptr(self.nkeep), A.ptr(self.out8), st)
+
+    def collect(self):
+        A = self.A
+        A.sync()
+        K = int(A.to_numpy(A.view_i32(self.count, (1,)))[0])
+        M = int(A.to_numpy(A.view_i32(self.nkeep, (1,)))[0])
+        if K > self.cap:
+            raise rdlib.RangeDetError(rdlib.RD_EWORKSPACE, "%d detections above min_score exceed the WNMS capacity %d" % (K, self.cap))
+        rows = A.to_numpy(A.view_f32(self.out, (self.cap, 12)))[:M].copy()
+        keep = A.to_numpy(A.view_i32(self.keep, (self.cap,)))[:M].copy()
+        d8 = A.to_numpy(A.view_f32(self.out8, (self.cap, 8)))[:M].copy()
+        return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
+
+
+class RangeDetPipeline:
+    def __init__(self, params, dtype=rdlib.RD_BF16, feat_size=(64, 2650), pad_field=(64, 2656), batch=1,
+                 pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None):
+        self.cfg = cfgmod.get_config(False, variant=variant, feat_size=feat_size, pad_field=pad_field,
+                                     batch_image=batch, pre_nms_top_n={variant: pre_nms_top_n})
+        General, RpnParam, ModelParam, TestParam = self.cfg[0], self.cfg[2], self.cfg[6], self.cfg[8]
+        self.lib = lib or rdlib.get_lib()
+        self.alloc = alloc or TorchAllocator()
+        self.plan = lower(ModelParam.test_symbol, input_shapes(*pad_field), dtype, batch)
+        self.exe = Executor(self.plan, params, self.lib, self.alloc)
+        cname = General.class_names[0]
+        self.k = pre_nms_top_n
+        self.batch = batch
+        self.post = [PostProcessor(self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
+                                   TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap) for _ in range(batch)]
+
+    def forward(self, inputs):
+        """Graph outputs only: [rec_id, fg_cls_score (B,k), decoded_bbox (B,k,10), zeros, gt_bbox_imu, gt_class]."""
+        return self.exe.forward(inputs)
+
+    def enqueue(self, inputs):
+        outs = self.exe.forward(inputs)
+        sc, bx = outs[1], outs[2]
+        for b in range(self.batch):
+            self.post[b].enqueue(self.alloc.ptr(sc[b]) if hasattr(sc[b], "data_ptr") else sc[b].ctypes.data,
+                                 self.alloc.ptr(bx[b]) if hasattr(bx[b], "data_ptr") else bx[b].ctypes.data)
+        return outs
+
+    def run(self, inputs):
+        outs = self.enqueue(inputs)
+        res = [p.collect() for p in self.post]
+        r0 = dict(res[0]) if self.batch == 1 else dict(frames=res)
+        r0["fg_cls_score"], r0["decoded_bbox"] = outs[1], outs[2]
+        return r0

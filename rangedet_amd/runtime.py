@@ -1,0 +1,231 @@
+"""Executor: binds a lowered Plan (rangedet_amd.lower) to device buffers and parameters and replays it as C-ABI calls
+into librangedet_hip.so on one HIP stream.  PyTorch is used only as the device allocator / stream provider.
+
+This is the build's counterpart of the reference's DetModule.bind/set_params/forward/get_outputs
+(utils/detection_module.py:419-510,627-679,783-805) for the test symbol: ``Executor(plan, params).forward(inputs)``
+returns the Group outputs [rec_id, fg_cls_score, decoded_bbox, zeros, gt_bbox_imu, gt_class] (builder.py:77).
+"""
+import numpy as np
+
+from . import lib as rdlib
+from .lower import FlatRef, TRef
+
+
+class TorchAllocator:
+    """Device memory + stream through torch (ROCm).  Fails loudly without a GPU -- there is no CPU path."""
+
+    def __init__(self, device="cuda:0", stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("rangedet_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._stream = stream
+
+    @property
+    def stream(self):
+        st = self._stream or self.torch.cuda.current_stream(self.device)
+        return st.cuda_stream
+
+    def alloc(self, nbytes, zero=False):
+        f = self.torch.zeros if zero else self.torch.empty
+        return f(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
+        return t
+
+    def ptr(self, buf):
+        return buf.data_ptr()
+
+    def view_f32(self, buf, shape):
+        n = int(np.prod(shape))
+        return buf[: n * 4].view(self.torch.float32).view(*shape)
+
+    def view_i32(self, buf, shape):
+        n = int(np.prod(shape))
+        return buf[: n * 4].view(self.torch.int32).view(*shape)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def as_device_f32(self, x):
+        """numpy / torch input -> contiguous float32 device tensor (no copy if it already is one)."""
+        t = self.torch
+        if isinstance(x, np.ndarray):
+            return t.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+        return x.to(device=self.device, dtype=t.float32).contiguous()
+
+    def assign(self, dst_view, src):
+        dst_view.copy_(src.reshape(dst_view.shape))
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def bn_affine(P, name, eps):
+    g, b, m, v = (np.asarray(P[name + s], np.float64) for s in ("_gamma", "_beta", "_moving_mean", "_moving_var"))
+    s = g / np.sqrt(v + eps)
+    return s.astype(np.float32), (b - m * s).astype(np.float32)
+
+
+class Executor:
+    def __init__(self, plan, params, lib=None, alloc=None, reuse_buffers=True):
+        self.plan = plan
+        self.lib = lib or rdlib.get_lib()
+        self.alloc = alloc or TorchAllocator()
+        self.dtype = plan.dtype
+        self.B = plan.batch
+        self._phys = {}
+        self._assign_buffers(reuse_buffers)
+        self._bound = [self._bind(st, params) for st in plan.steps]
+
+    # ---- memory ------------------------------------------------------------------------------------------------
+    def _assign_buffers(self, reuse):
+        plan = self.plan
+        last_use, first_def = {}, {}
+        for i, st in enumerate(plan.steps):
+            for v in st.values():
+                if isinstance(v, (TRef, FlatRef)):
+                    last_use[v.buf] = i
+                    first_def.setdefault(v.buf, i)
+        for kind, v in plan.outputs:
+            if kind == "flat":
+                last_use[v.buf] = len(plan.steps) + 1
+        free = {}
+        release = {}
+        for b, i in last_use.items():
+            release.setdefault(i, []).append(b)
+        order = sorted(plan.buffers, key=lambda b: first_def.get(b, 0))
+        by_def = {}
+        for b in order:
+            by_def.setdefault(first_def.get(b, 0), []).append(b)
+        for i in range(len(plan.steps) + 2):
+            for b in by_def.get(i, []):
+                info = plan.buffers[b]
+                if reuse and not info["persistent"] and free.get(info["nbytes"]):
+                    self._phys[b] = free[info["nbytes"]].pop()
+                else:
+                    self._phys[b] = self.alloc.alloc(info["nbytes"], zero=info["zero"])
+            for b in release.get(i, []):
+                info = plan.buffers[b]
+                if reuse and not info["persistent"] and last_use[b] <= len(plan.steps):
+                    free.setdefault(info["nbytes"], []).append(self._phys[b])
+        self.device_bytes = sum(int(t.numel()) if hasattr(t, "numel") else len(t) for t in {id(v): v for v in self._phys.values()}.values())
+
+    def p(self, ref):
+        return self.alloc.ptr(self._phys[ref.buf])
+
+    # ---- parameter binding -------------------------------------------------------------------------------------------
+    def _bind(self, st, P):
+        L, A, dt = self.lib, self.alloc, self.dtype
+        k = st["kind"]
+        b = dict(st)
+        if k == "conv":
+            b["w"] = A.upload(L.pack_conv_weight(P[st["name"] + "_weight"], dt))
+            s, t = bn_affine(P, st["bn"], st["eps"])
+            b["scale"], b["shift"] = A.upload(s), A.upload(t)
+        elif k == "deconv":
+            w = P[st["name"] + "_weight"]
+            b["w"] = [A.upload(L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt)) for ph in range(st["stride_w"])]
+            s, t = bn_affine(P, st["bn"], st["eps"])
+            b["scale"], b["shift"] = A.upload(s), A.upload(t)
+        elif k == "meta":
+            s1, t1 = bn_affine(P, st["bn1"], st["eps1"])
+            s2, t2 = bn_affine(P, st["bn2"], st["eps2"])
+            pk = L.pack_meta(P[st["mlp0"] + "_weight"].reshape(32, 3), P[st["mlp0"] + "_bias"],
+                             P[st["mlp1"] + "_weight"].reshape(64, 32), P[st["mlp1"] + "_bias"], s1, t1,
+                             P[st["agg"] + "_weight"].reshape(64, 576), s2, t2, dt)
+            b["packed"] = A.upload(pk)
+        elif k == "head_out":
+            r0, r1 = st["rows"]
+            w = np.asarray(P[st["name"] + "_weight"], np.float32).reshape(-1, st["x"].C)[r0:r1]
+            b["w"] = A.upload(w)
+            b["bias"] = A.upload(np.asarray(P[st["name"] + "_bias"], np.float32)[r0:r1])
+        elif k == "sorted_fg":
+            nb = L.raw("rd_sorted_foreground_workspace_bytes")(st["N"], st["k"])
+            b["ws"] = A.alloc(nb)
+            b["ws_bytes"] = nb
+        return b
+
+    # ---- execution ------------------------------------------------------------------------------------------------------
+    def forward(self, inputs):
+        """inputs: name -> float32 array/tensor WITH batch dim (the reference's data_name list, config:400-404)."""
+        L, A, dt, B = self.lib, self.alloc, self.dtype, self.B
+        st_ = A.stream
+        dev = {}
+
+        def din(name):
+            if name not in dev:
+                dev[name] = A.as_device_f32(inputs[name])
+            return dev[name]
+
+        for b in self._bound:
+            k = b["kind"]
+            if k == "nchw_in":
+                o = b["out"]
+                src = din(b["name"])
+                assert tuple(src.shape) == (B, o.C, o.H, o.W), (b["name"], tuple(src.shape), (B, o.C, o.H, o.W))
+                L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
+            elif k == "conv":
+                x, o, r = b["x"], b["out"], b["res"]
+                L.call("rd_conv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]),
+                       self.p(r) if r else None, r.cs if r else 0, r.co if r else 0, self.p(o), o.cs, o.co, B, x.H, x.W,
+                       b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["flags"], dt, st_)
+            elif k == "deconv":
+                x, o, r = b["x"], b["out"], b["res"]
+                for ph in range(b["stride_w"]):
+                    L.call("rd_deconv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"][ph]), A.ptr(b["scale"]),
+                           A.ptr(b["shift"]), self.p(r), r.cs, r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"],
+                           b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["pad_w"], ph, b["flags"], dt, st_)
+            elif k == "meta":
+                x, o = b["x"], b["out"]
+                c = din(b["coord"])
+                assert tuple(c.shape) == (B, 3, x.H, x.W)
+                L.call("rd_meta_kernel_fwd", self.p(x), x.cs, x.co, A.ptr(c), A.ptr(b["packed"]), self.p(o), o.cs, o.co,
+                       B, x.H, x.W, dt, st_)
+            elif k == "head_out":
+                x, o = b["x"], b["out"]
+                L.call("rd_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["bias"]), self.p(o),
+                       b["N"] * b["nout"], b["n_off"], B, x.H, x.W, x.C, b["nout"], dt, st_)
+            elif k == "concat_in":
+                o = b["out"]
+                dst = A.view_f32(self._phys[o.buf], (B,) + tuple(o.shape))
+                off = 0
+                for name, n in b["names"]:
+                    src = din(name)
+                    A.assign(dst[:, off:off + n], src)
+                    off += n
+            elif k == "sorted_fg":
+                L.call("rd_sorted_foreground", self.p(b["score"]), self.p(b["delta"]), self.p(b["pc"]), self.p(b["mask"]),
+                       B, b["N"], b["k"], b["D"], b["apply_sigmoid"], self.p(b["out_score"]), self.p(b["out_delta"]),
+                       self.p(b["out_pc"]), None, A.ptr(b["ws"]), b["ws_bytes"], st_)
+            elif k == "decode":
+                L.call("rd_decode3d_bbox", self.p(b["delta"]), self.p(b["pc"]), self.p(b["out"]), B, b["k"],
+                       b["box_type"], b["is_bin"], st_)
+            else:
+                raise RuntimeError("unknown plan step %r" % k)
+        outs = []
+        for kind, v in self.plan.outputs:
+            if kind == "flat":
+                outs.append(A.view_f32(self._phys[v.buf], (B,) + tuple(v.shape)))
+            elif kind == "input":
+                outs.append(inputs.get(v))
+            else:
+                outs.append(np.zeros(v, np.float32))
+        return outs
+
+    def read_flat(self, ref):
+        """numpy copy of a flat float32 plan tensor (B, *shape), e.g. the pre-sort logits/deltas (tests only)."""
+        self.alloc.sync()
+        return np.array(self.alloc.to_numpy(self.alloc.view_f32(self._phys[ref.buf], (self.B,) + tuple(ref.shape))))
+
+    def debug_tensor(self, ref):
+        """NCHW float32 numpy copy of an activation (tests only)."""
+        A, L = self.alloc, self.lib
+        out = A.alloc(self.B * ref.C * ref.H * ref.W * 4)
+        L.call("rd_nhwc_to_nchw", self.p(ref), A.ptr(out), self.B, ref.C, ref.H, ref.W, ref.cs, ref.co, self.dtype, A.stream)
+        A.sync()
+        return A.to_numpy(A.view_f32(out, (self.B, ref.C, ref.H, ref.W)))

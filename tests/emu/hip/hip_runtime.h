@@ -238,6 +238,8 @@ inline unsigned long long __ballot(int pred) {
   hipemu::wave_barrier();
   return m;
 }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
 inline int __all(int p) { return __ballot(!p) == 0ull; }
 inline int __any(int p) { return __ballot(p) != 0ull; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -1,0 +1,307 @@
+"""Parity of every C-ABI entry point against the oracle / a plain PyTorch-CPU fp32 reference on seeded inputs.
+Each case runs on 'emu' (hipemu CPU build of the same HIP sources; CPU tier) and on 'hip' (real MI355X; -m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import BOTH
+from emu_util import bf16_round, empty_nhwc, from_nhwc, to_nhwc, bf16_bits_to_f32
+from oracle import cpu_ops as O
+from oracle import graph_ref as G
+from rangedet_amd import lib as R
+from rangedet_amd import synth
+from rangedet_amd.runtime import bn_affine
+
+F32, BF16 = R.RD_F32, R.RD_BF16
+
+
+def _gran(dt):
+    return 16 if dt == BF16 else 8
+
+
+def _tol(dt, ref):
+    # f32: accumulation-order noise only.  bf16: inputs are pre-rounded to bf16 so the only error is the output rounding
+    # (half a bf16 ulp = 2^-9 relative) plus fp32 accumulation.
+    return 2e-5 * max(1.0, float(np.abs(ref).max())) if dt == F32 else 2 ** -8 * max(1.0, float(np.abs(ref).max()))
+
+
+def run_conv(be, dt, B, H, W, cin, cout, k, stride, flags, cs_in=None, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    Wout = (W + 2 * (k // 2) - k) // stride + 1
+    res = rng.standard_normal((B, cout, H, Wout)).astype(np.float32)
+    if dt == BF16:
+        x, w, res = bf16_round(x), bf16_round(w), bf16_round(res)
+    g = _gran(dt)
+    cs = cs_in or -(-cin // g) * g
+    L = be.lib
+    xin, rin = be.up(to_nhwc(x, dt, cstride=cs)), be.up(to_nhwc(res, dt))
+    y = be.empty(B * H * Wout * cout * 4)
+    wp, dsc, dsh = be.up(L.pack_conv_weight(w, dt)), be.up(sc), be.up(sh)
+    L.call("rd_conv2d_bn_act", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), be.ptr(rin), cout, 0, be.ptr(y),
+           cout, 0, B, H, W, cin, cout, k, k, stride, flags, dt, be.stream)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, stride), padding=k // 2).numpy()
+    ref = ref * sc[None, :, None, None] + sh[None, :, None, None]
+    if flags & R.RD_RELU_PRE:
+        ref = np.maximum(ref, 0)
+    if flags & R.RD_ADD:
+        ref = ref + res
+    if flags & R.RD_RELU_POST:
+        ref = np.maximum(ref, 0)
+    raw = be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, Wout, cout))
+    got = from_nhwc(raw, dt, cout)
+    assert np.abs(got - ref).max() <= _tol(dt, ref), (np.abs(got - ref).max(), _tol(dt, ref))
+
+
+CONV_CASES = [
+    # dt, B, H, W, cin, cout, k, stride, flags
+    (F32, 1, 5, 70, 8, 64, 3, 1, 4),       # first layer (8 input channels), partial column tile, H not multiple of RO
+    (F32, 1, 3, 40, 64, 128, 3, 1, 6),     # residual add + relu, cout 128
+    (BF16, 1, 4, 70, 16, 64, 3, 1, 4),
+    (BF16, 2, 3, 33, 128, 128, 3, 2, 6),   # stride (1,2), two k-chunks, batch 2
+    (BF16, 1, 2, 20, 72, 128, 3, 1, 4),    # head level 0: 72 channels in an 80-wide buffer (partial k-chunk)
+    (F32, 1, 2, 21, 64, 128, 1, 2, 0),     # projection shortcut 1x1 stride 2, no activation
+    (F32, 1, 2, 64, 128, 64, 3, 1, 1),     # relu before (no) add
+]
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_bn_act(be, case):
+    dt, B, H, W, cin, cout, k, s, fl = case
+    run_conv(be, dt, B, H, W, cin, cout, k, s, fl, cs_in=80 if cin == 72 else None)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(F32, 1, 3, 10, 128, 64, (3, 8), 4, 2), (BF16, 1, 2, 20, 128, 128, (3, 8), 4, 2),
+                                  (F32, 2, 2, 13, 64, 64, (3, 4), 2, 1), (BF16, 1, 3, 24, 128, 64, (3, 4), 2, 1)])
+def test_deconv2d_bn_act(be, case):
+    dt, B, H, W, cin, cout, k, s, pw = case
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, k[0], k[1])) / np.sqrt(cin * k[0] * k[1] / s)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    Wout = (W - 1) * s - 2 * pw + k[1]
+    res = rng.standard_normal((B, cout, H, Wout)).astype(np.float32)
+    if dt == BF16:
+        x, w, res = bf16_round(x), bf16_round(w), bf16_round(res)
+    L = be.lib
+    xin, rin = be.up(to_nhwc(x, dt)), be.up(to_nhwc(res, dt))
+    y = be.empty(B * H * Wout * cout * 4)
+    dsc, dsh = be.up(sc), be.up(sh)
+    for ph in range(s):
+        wp = be.up(L.pack_deconv_weight(w, s, pw, ph, dt))
+        L.call("rd_deconv2d_bn_act", be.ptr(xin), cin, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), be.ptr(rin), cout, 0,
+               be.ptr(y), cout, 0, B, H, W, cin, cout, k[0], k[1], s, pw, ph, R.RD_RELU_PRE | R.RD_ADD, dt, be.stream)
+    ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, s), padding=(1, pw)).numpy()
+    ref = np.maximum(ref * sc[None, :, None, None] + sh[None, :, None, None], 0) + res
+    got = from_nhwc(be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, Wout, cout)), dt, cout)
+    assert np.abs(got - ref).max() <= _tol(dt, ref)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40)])
+def test_meta_kernel_unit(be, case):
+    """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97."""
+    dt, B, H, W = case
+    rng = np.random.default_rng(0)
+    P = synth.make_weights(seed=18, width=W)
+    data = rng.standard_normal((B, 64, H, W)).astype(np.float32)
+    coord = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    if dt == BF16:
+        data = bf16_round(data)
+    name = 'res1_unit2'
+    ref = G.meta_kernel_unit(G.T(data), G.T(coord), P, name).numpy()
+    s1, t1 = bn_affine(P, name + "point_wise_mlp_bn1", G.EPS)
+    s2, t2 = bn_affine(P, name + "aggregation_bn1", G.EPS)
+    pre = name + "_%d" % W
+    L = be.lib
+    pk = L.pack_meta(P[pre + "_mlp0_weight"].reshape(32, 3), P[pre + "_mlp0_bias"], P[pre + "_mlp1_weight"].reshape(64, 32),
+                     P[pre + "_mlp1_bias"], s1, t1, P[name + "aggregation_conv1_weight"].reshape(64, 576), s2, t2, dt)
+    x, c, pkd = be.up(to_nhwc(data, dt)), be.up(coord), be.up(pk)
+    y = be.empty(B * H * W * 64 * 4)
+    L.call("rd_meta_kernel_fwd", be.ptr(x), 64, 0, be.ptr(c), be.ptr(pkd), be.ptr(y), 64, 0, B, H, W, dt, be.stream)
+    got = from_nhwc(be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, W, 64)), dt, 64)
+    # bf16: hidden activations, products and the 576-vector are rounded to bf16 inside (documented deviation) -> ~1 %
+    tol = 1e-4 if dt == F32 else 0.02 * float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_head_out_and_layout(be, dt):
+    rng = np.random.default_rng(2)
+    B, H, W, C = 2, 3, 37, 128
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    if dt == BF16:
+        x = bf16_round(x)
+    L = be.lib
+    src = be.up(x)
+    xin = be.empty(B * H * W * C * 4)
+    L.call("rd_nchw_to_nhwc", be.ptr(src), be.ptr(xin), B, C, H, W, C, 0, 0, dt, be.stream)
+    back = be.empty(B * H * W * C * 4)
+    L.call("rd_nhwc_to_nchw", be.ptr(xin), be.ptr(back), B, C, H, W, C, 0, dt, be.stream)
+    assert np.array_equal(be.down(back, np.float32, (B, C, H, W)), x)
+    N = H * W + 50
+    for nout in (1, 8):
+        w = (rng.standard_normal((nout, C)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(nout).astype(np.float32)
+        out = be.empty(B * N * nout * 4)
+        L.call("rd_head_out", be.ptr(xin), C, 0, be.ptr(be.up(w)), be.ptr(be.up(b)), be.ptr(out), N * nout, 50, B, H, W, C,
+               nout, dt, be.stream)
+        got = be.down(out, np.float32, (B, N, nout))[:, 50:]
+        ref = np.einsum("bchw,oc->bhwo", x, w).reshape(B, H * W, nout) + b
+        assert np.abs(got - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_sorted_foreground(be):
+    rng = np.random.default_rng(0)
+    B, N, k, D = 2, 5000, 1200, 8
+    logit = rng.standard_normal((B, N)).astype(np.float32)
+    logit[:, ::7] = logit[:, 3:4]  # exact ties among positive scores
+    mask = (rng.uniform(size=(B, N)) > 0.4).astype(np.float32)  # > k masked-out zeros: ties at 0 as well
+    delta = rng.standard_normal((B, N, D)).astype(np.float32)
+    pc = rng.standard_normal((B, N, 3)).astype(np.float32)
+    score = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    L = be.lib
+    nb = L.raw("rd_sorted_foreground_workspace_bytes")(N, k)
+    ws = be.empty(nb)
+    o_s, o_d, o_p, o_i = be.empty(B * k * 4), be.empty(B * k * D * 4), be.empty(B * k * 12), be.empty(B * k * 4)
+    L.call("rd_sorted_foreground", be.ptr(be.up(score)), be.ptr(be.up(delta)), be.ptr(be.up(pc)), be.ptr(be.up(mask)), B, N, k,
+           D, 0, be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), be.ptr(o_i), be.ptr(ws), nb, be.stream)
+    rs, rd, rp, ri = O.get_sorted_foreground(score, delta, pc, mask, k)
+    assert np.array_equal(be.down(o_i, np.int32, (B, k)), ri)           # bit-exact index work, incl. tie rule
+    assert np.array_equal(be.down(o_s, np.float32, (B, k)), rs)
+    assert np.array_equal(be.down(o_d, np.float32, (B, k, D)), rd)
+    assert np.array_equal(be.down(o_p, np.float32, (B, k, 3)), rp)
+    # N < k mirrors the reference's assert (get_sorted_foreground.py:65)
+    with pytest.raises(R.RangeDetError) as e:
+        L.call("rd_sorted_foreground", be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), None, 1, 10, 20, D, 0, be.ptr(o_s), be.ptr(o_d),
+               be.ptr(o_p), None, be.ptr(ws), nb, be.stream)
+    assert e.value.code == R.RD_ESHAPE
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_decode3d_bbox(be):
+    rng = np.random.default_rng(3)
+    B, N = 2, 3000
+    d = rng.normal(0, 0.7, (B, N, 8)).astype(np.float32)
+    pc = rng.uniform(-70, 70, (B, N, 3)).astype(np.float32)
+    pc[0, 0] = 0          # point at the origin: atan2(0,0)
+    d[0, 1, :2] = 0       # zero offsets
+    d[0, 2, 2:4] = 3.0    # large log sizes
+    L = be.lib
+    out = be.empty(B * N * 40)
+    L.call("rd_decode3d_bbox", be.ptr(be.up(d)), be.ptr(be.up(pc)), be.ptr(out), B, N, 8, 0, be.stream)
+    ref = O.decode3d(d, pc)
+    # device libm (atan2f/sinf/cosf/expf) differs from glibc by ulps: 1e-4 is the north-star box tolerance
+    assert np.abs(be.down(out, np.float32, (B, N, 10)) - ref).max() < 1e-4
+    d7 = rng.normal(0, 0.5, (B, N, 7)).astype(np.float32)
+    L.call("rd_decode3d_bbox", be.ptr(be.up(d7)), be.ptr(be.up(pc)), be.ptr(out), B, N, 7, 1, be.stream)
+    assert np.abs(be.down(out, np.float32, (B, N, 10)) - O.decode3d(d7, pc, True)).max() < 1e-4
+    with pytest.raises(R.RangeDetError):
+        L.call("rd_decode3d_bbox", be.ptr(out), be.ptr(out), be.ptr(out), B, N, 9, 0, be.stream)
+
+
+def _wnms(be, d, thr, vote, is3d, order=None, cap_extra=5):
+    L = be.lib
+    K = d.shape[0]
+    cap = K + cap_extra
+    dbuf = np.zeros((cap, 12), np.float32)
+    dbuf[:K] = d
+    ob = None
+    if order is not None:
+        ob = np.zeros(cap, np.int32)
+        ob[:K] = order
+    nb = L.raw("rd_wnms_workspace_bytes")(cap)
+    ws, outd, keep, nk = be.empty(nb), be.empty(cap * 48), be.empty(cap * 4), be.empty(16)
+    L.call("rd_wnms_4c", be.ptr(be.up(dbuf)), cap, be.ptr(be.up(np.array([K], np.int32))), be.ptr(be.up(ob)) if ob is not None else None,
+           thr, vote, int(is3d), be.ptr(outd), be.ptr(keep), be.ptr(nk), be.ptr(ws), nb, be.stream)
+    M = int(be.down(nk, np.int32, (1,))[0])
+    return be.down(outd, np.float32, (cap, 12))[:M], be.down(keep, np.int32, (cap,))[:M]
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(12, 6, None, 0), (20, 9, 33, 0), (10, 5, None, 1), (1, 1, None, 0), (1, 2, None, 0), (1, 3, None, 0)])
+def test_wnms_vs_oracle(be, case):
+    """keep indices bit-exact and merged rows bit-equal, with the reference ordering (std::sort on the host, ties
+    included) and with the on-device ordering (score desc, index asc)."""
+    no, rep, quant, is3d = case
+    d = synth.cluster_dets(no, rep, seed=no + rep, quant=quant)
+    order = be.lib.wnms_order_host(d)
+    assert np.array_equal(order, O.wnms_order(d))
+    rows, keep = _wnms(be, d, 0.1, 0.5, is3d, order)
+    flat, rk = O.wnms_4c(d, 0.1, 0.5, bool(is3d), 100)
+    assert keep.tolist() == rk
+    assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
+    rows2, keep2 = _wnms(be, d, 0.1, 0.5, is3d, None)
+    o2 = np.argsort(-d[:, 11], kind="stable").astype(np.int32)
+    flat2, rk2 = O.wnms_4c(d, 0.1, 0.5, bool(is3d), 100, order=o2)
+    assert keep2.tolist() == rk2
+    assert np.array_equal(rows2.view(np.uint32), np.array(flat2, np.float32).reshape(-1, 12).view(np.uint32))
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_score_filter_and_12to8(be):
+    rng = np.random.default_rng(4)
+    n = 3000
+    boxes = (rng.standard_normal((n, 10)) * 10).astype(np.float32)
+    sc = rng.uniform(0, 1, n).astype(np.float32)
+    L = be.lib
+    nb = L.raw("rd_score_filter_workspace_bytes")(n)
+    dets, cnt, ws = be.empty(n * 48), be.empty(16), be.empty(nb)
+    L.call("rd_score_filter_dets", be.ptr(be.up(sc)), be.ptr(be.up(boxes)), n, 0.5, be.ptr(dets), be.ptr(cnt), be.ptr(ws), nb, be.stream)
+    ref = O.score_filter_to_dets(sc, boxes, 0.5)
+    K = int(be.down(cnt, np.int32, (1,))[0])
+    assert K == ref.shape[0]
+    got = be.down(dets, np.float32, (n, 12))[:K]
+    assert np.array_equal(got[:, :8], ref[:, :8]) and np.array_equal(got[:, 9:], ref[:, 9:])  # copies / exact subtract
+    assert np.abs(got[:, 8] - ref[:, 8]).max() < 1e-5                                           # atan2f
+    o8 = be.empty(K * 32)
+    L.call("rd_dets12_to_8", be.ptr(dets), K, be.ptr(cnt), be.ptr(o8), be.stream)
+    assert np.abs(be.down(o8, np.float32, (K, 8)) - O.bbox3d_12dim_to_8dim(got)).max() < 1e-4
+    # nothing above the threshold -> K == 0
+    L.call("rd_score_filter_dets", be.ptr(be.up(sc * 0)), be.ptr(be.up(boxes)), n, 0.5, be.ptr(dets), be.ptr(cnt), be.ptr(ws), nb, be.stream)
+    assert int(be.down(cnt, np.int32, (1,))[0]) == 0
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_rotated_iou_8pt(be):
+    b1 = synth.cluster_dets(8, 6, seed=3)[:, :8].copy()
+    gt = synth.cluster_dets(8, 2, seed=3)[:, :8].copy()
+    gt = np.concatenate([gt, np.tile(np.array([[0, 0, 0, 1e-3, 1e-3, 1e-3, 1e-3, 0]], np.float32), (4, 1))])  # GT padding rows
+    b1 = np.concatenate([b1, b1[:2]])  # identical boxes (winding-dependent degenerate case)
+    L = be.lib
+    io = be.empty(b1.shape[0] * gt.shape[0] * 4)
+    L.call("rd_rotated_iou_8pt", be.ptr(be.up(b1)), be.ptr(be.up(gt)), be.ptr(io), b1.shape[0], gt.shape[0], be.stream)
+    ref = O.rotated_iou_8pt(b1, gt)
+    got = be.down(io, np.float32, ref.shape)
+    assert np.allclose(got, ref, atol=1e-5, equal_nan=True)
+    mx = be.empty(b1.shape[0] * 4)
+    L.call("rd_batch_max_iou", be.ptr(be.up(b1)), 8, be.ptr(be.up(gt)), be.ptr(mx), b1.shape[0], gt.shape[0], be.stream)
+    assert np.abs(be.down(mx, np.float32, (b1.shape[0],)) - O.batch_max_iou(b1, gt)).max() < 1e-5
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_error_conventions(be):
+    """Status codes instead of aborts; messages through rd_last_error_string (SURVEY.md 8b 'Error conventions')."""
+    L = be.lib
+    buf = be.empty(4096)
+    p = be.ptr(buf)
+    rc = L.raw("rd_conv2d_bn_act")(p, 16, 0, p, p, p, None, 0, 0, p, 96, 0, 1, 2, 8, 16, 96, 3, 3, 1, 0, F32, be.stream)
+    assert rc == R.RD_ESHAPE and b"cout" in L.raw("rd_last_error_string")()
+    rc = L.raw("rd_conv2d_bn_act")(p, 16, 0, p, p, p, None, 0, 0, p, 64, 0, 1, 2, 8, 16, 64, 5, 5, 1, 0, F32, be.stream)
+    assert rc == R.RD_ESHAPE
+    rc = L.raw("rd_wnms_4c")(p, 100000, None, None, 0.1, 0.5, 0, p, p, p, p, 4096, be.stream)
+    assert rc == R.RD_ESHAPE
+    rc = L.raw("rd_wnms_4c")(p, 64, None, None, 0.1, 0.5, 0, p, p, p, p, 16, be.stream)
+    assert rc == R.RD_EWORKSPACE
+    rc = L.raw("rd_decode3d_bbox")(None, p, p, 1, 10, 8, 0, be.stream)
+    assert rc == R.RD_EINVAL
+    assert L.raw("rd_version")() >= 100

@@ -1,0 +1,84 @@
+"""Pin the oracle (oracle/oracle.cpp) before trusting it: against the reference's own wnms compiled as-is
+(oracle/_ref, this container; it travels to the GPU box) and against the committed golden vectors those builds made."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ops as O
+from rangedet_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _biteq(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("f", sorted(glob.glob(os.path.join(GOLD, "wnms_*.npz"))))
+def test_wnms_golden(f):
+    g = np.load(f)
+    flat, keep = O.wnms_4c(g["dets"], float(g["thresh"]), float(g["thresh_vote"]), bool(g["is3d"]), int(g["hash_scale"]))
+    assert keep == g["keep"].tolist()
+    assert _biteq(np.array(flat, np.float32), g["rows"].reshape(-1))
+
+
+def test_pair_overlap_golden():
+    g = np.load(os.path.join(GOLD, "pair_overlaps.npz"))
+    got = np.array([O.single_overlap(a, b, False) for a, b in zip(g["a"], g["b"])], np.float32)
+    assert _biteq(got, g["iou"])
+    got3 = np.array([O.single_overlap(a, b, True) for a, b in zip(g["a"], g["b"])], np.float32)
+    assert _biteq(got3, g["iou3d"])
+
+
+def test_golden_present():
+    assert len(glob.glob(os.path.join(GOLD, "wnms_*.npz"))) >= 8
+
+
+@pytest.mark.skipif(O.ref_module() is None, reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed", range(12))
+def test_wnms_vs_compiled_reference(seed):
+    ref = O.ref_module()
+    d = synth.cluster_dets([8, 32, 64][seed % 3], [4, 8, 16][seed % 3], seed=100 + seed, quant=(33 if seed % 4 == 0 else None))
+    for is3d in (False, True):
+        for hs in (100, 10):
+            a, ka = ref.wnms_4c(d, 0.1, 0.5, is3d, hs)
+            b, kb = O.wnms_4c(d, 0.1, 0.5, is3d, hs)
+            assert ka == kb
+            assert _biteq(np.array(a, np.float32), np.array(b, np.float32))
+
+
+@pytest.mark.skipif(O.ref_module() is None, reason="oracle/_ref not built")
+def test_empty_and_tiny_vs_reference():
+    ref = O.ref_module()
+    assert ref.wnms_4c(np.zeros((0, 12), np.float32), 0.1, 0.5, False, 100) == ([], [])
+    assert O.wnms_4c(np.zeros((0, 12), np.float32), 0.1, 0.5) == ([], [])
+    for K in (1, 2, 3):
+        d = synth.cluster_dets(1, K, seed=K)
+        a, ka = ref.wnms_4c(d, 0.1, 0.5, False, 100)
+        b, kb = O.wnms_4c(d, 0.1, 0.5, False, 100)
+        assert ka == kb and _biteq(np.array(a, np.float32), np.array(b, np.float32))
+
+
+def test_decode_oracle_self_consistency():
+    """decode is parity-UNPINNED (no buildable reference, no vectors): check it against an independent float64 formula."""
+    rng = np.random.default_rng(0)
+    n = 4096
+    d = rng.normal(0, 0.5, (1, n, 8)).astype(np.float32)
+    pc = rng.uniform(-60, 60, (1, n, 3)).astype(np.float32)
+    out = O.decode3d(d, pc)[0].astype(np.float64)
+    dd, p = d[0].astype(np.float64), pc[0].astype(np.float64)
+    az = np.arctan2(p[:, 1], p[:, 0])
+    dx, dy = dd[:, 0] * np.abs(dd[:, 0]), dd[:, 1] * np.abs(dd[:, 1])
+    cx = p[:, 0] + dx * np.cos(az) - dy * np.sin(az)
+    cy = p[:, 1] + dx * np.sin(az) + dy * np.cos(az)
+    yaw = np.arctan2(dd[:, 5], dd[:, 4]) + az
+    l, w, h = np.exp(dd[:, 3]), np.exp(dd[:, 2]), np.exp(dd[:, 7])
+    ax = cx + 0.5 * l * np.cos(yaw) + 0.5 * w * np.sin(yaw)
+    ay = cy + 0.5 * l * np.sin(yaw) - 0.5 * w * np.cos(yaw)
+    assert np.abs(out[:, 0] - ax).max() < 2e-4 and np.abs(out[:, 1] - ay).max() < 2e-4
+    assert np.abs(out[:, 8] - dd[:, 6]).max() == 0 and np.abs(out[:, 9] - (dd[:, 6] + h)).max() < 1e-5
+    # centre of the 4 corners is the decoded centre
+    assert np.abs(out[:, 0:8:2].mean(1) - cx).max() < 2e-4
