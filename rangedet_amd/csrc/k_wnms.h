@@ -250,8 +250,9 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
   RD_NOCONTRACT
   const int mrow = blockIdx.x;
   if (mrow >= *d_nkeep) return;
-  __shared__ int nbl[RD_WNMS_MAX_K];
-  __shared__ float yws[RD_WNMS_MAX_K + 1];
+  HIP_DYNAMIC_SHARED(unsigned char, smem);  // (cap + 2) ints + (cap + 2) floats
+  int* nbl = (int*)smem;
+  float* yws = (float*)(smem + (size_t)(cap + 2) * 4);
   const int lane = threadIdx.x;
   const int K = d_count ? min(*d_count, cap) : cap;
   const int nw = (K + 63) >> 6;

@@ -291,7 +291,7 @@ int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order
   hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), 0, st, w.thr, w.vote, Kcap, d_count, w.nwcap, ord, w.keep_q,
                      keep, d_nkeep);
   allow_big_lds(wnms_merge_kernel);
-  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), 0, st, dets, ord, w.vote, Kcap, d_count, w.nwcap, w.keep_q,
+  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, Kcap, d_count, w.nwcap, w.keep_q,
                      d_nkeep, out_dets);
   return check_launch("wnms_4c");
 }
