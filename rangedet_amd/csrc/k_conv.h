@@ -16,6 +16,8 @@
 //     bf16: that IS the v_mfma_f32_32x32x16_bf16 fragment (k = 8*(lane>>5)+j);
 //     f32 : 4 x v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), element e of the slot pairs k = 4*(2ks+hi)+e.
 #pragma once
+#include <cstdlib>
+
 #include "rd_common.h"
 
 namespace rd {
@@ -32,79 +34,107 @@ struct ConvArgs {
   int min_dh, min_dw, RI, CI;
   int flags;
   unsigned long long dh_pack, dw_pack;  // 4 bits per tap, biased by 8 (no dynamically indexed kernarg arrays)
+  int dbg;  // tuning ablations (tools/conv_bench.py): 1 no epilogue stores, 2 one weight slab only, 4 one halo stage, 8 no MFMA
 };
 
-template <int DT, int WN>
-__global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs a) {
+template <int DT, int NT>  // NT = Cout / 32 output-channel tiles per wave (2 or 4)
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvArgs a) {
   using E = Elem<DT>;
   using T = typename E::T;
   HIP_DYNAMIC_SHARED(unsigned char, smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int RO = 4 / WN;
-  constexpr int WCNT = 2 * WN;  // 16-byte slots of one weight slab handled per thread
-  const int wn = wave % WN, wm = wave / WN;
+  constexpr int RO = 4;              // output rows per workgroup = one per wave
+  constexpr int WCNT = NT;           // 16-byte slots of one weight slab handled per thread (Cout*8/256)
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int q0 = blockIdx.x * 64, h0 = blockIdx.y * RO, b = blockIdx.z;
   const int m = lane & 31, hi = lane >> 5;
 
   unsigned char* As = smem;
-  const int w_bytes = a.cout * 128;
-  unsigned char* Ws = smem + a.RI * a.CI * 128;
+  unsigned char* Ws = smem + a.RI * a.CI * 128;  // ONE weight slab [Cout][128 B]; the pipeline depth lives in registers
   const T* x = (const T*)a.x + (size_t)b * a.x_bs;
   const int nchunk = (a.nslots + 7) >> 3;
   const int nsteps = nchunk * a.ntaps;
 
-  int b_row[2], b_swz[2];
+  int b_row[NT], b_swz[NT];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    int n = wn * 64 + nt * 32 + m;
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 32 + m;
     b_row[nt] = n * 128;
     b_swz[nt] = (n >> 1) & 7;
   }
 
-  Slot16 wreg[WCNT];
-#define RD_W_LOAD(step_)                                                              \
+  // weight slabs: global -> registers two steps ahead -> LDS right before use
+  Slot16 wA[WCNT], wB[WCNT];
+#define RD_W_LOAD(dst_, step_)                                                        \
   {                                                                                   \
-    const Slot16* src_ = (const Slot16*)a.w + (size_t)(step_) * a.cout * 8;           \
-    _Pragma("unroll") for (int i_ = 0; i_ < WCNT; ++i_) wreg[i_] = src_[tid + i_ * 256]; \
+    const Slot16* src_ = (const Slot16*)a.w + (size_t)(step_) * (NT * 32 * 8);        \
+    _Pragma("unroll") for (int i_ = 0; i_ < WCNT; ++i_) dst_[i_] = src_[tid + i_ * 256]; \
   }
-#define RD_W_STORE(buf_)                                                              \
+#define RD_W_STORE(src_)                                                              \
   {                                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WCNT; ++i_) {                             \
-      const int idx_ = tid + i_ * 256, n_ = idx_ >> 3, s_ = idx_ & 7;                 \
-      *(Slot16*)(Ws + (buf_) * w_bytes + n_ * 128 + ((s_ ^ ((n_ >> 1) & 7)) << 4)) = wreg[i_]; \
+      const int idx_ = tid + i_ * 256, c_ = idx_ >> 3, s_ = idx_ & 7;                 \
+      const int n_ = (c_ & ~31) | ((c_ & 3) + 8 * ((c_ >> 2) & 3) + 4 * ((c_ >> 4) & 1)); \
+      *(Slot16*)(Ws + n_ * 128 + ((s_ ^ ((n_ >> 1) & 7)) << 4)) = src_[i_];           \
     }                                                                                 \
   }
+  // halo tile: all global loads of a pass are issued before the first LDS write (latency paid once per pass)
+  constexpr int AP = 7;
   auto a_stage = [&](int chunk) {
     const int ns_c = min(8, a.nslots - 8 * chunk);
     const int items = a.RI * a.CI * 8;
-    for (int idx = tid; idx < items; idx += 256) {
-      int px = idx >> 3, s = idx & 7;
-      int r = px / a.CI, cc = px - r * a.CI;
-      int ih = h0 + a.min_dh + r, iw = q0 * a.in_stride + a.min_dw + cc;
-      Slot16 v = {0u, 0u, 0u, 0u};
-      if (s < ns_c && ih >= 0 && ih < a.H && iw >= 0 && iw < a.Win)
-        v = *(const Slot16*)(x + ((size_t)ih * a.Win + iw) * a.x_cs + a.x_co + (chunk * 8 + s) * E::CH);
-      *(Slot16*)(As + px * 128 + ((s ^ ((px >> 1) & 7)) << 4)) = v;
+    for (int base = 0; base < items; base += 256 * AP) {
+      Slot16 v[AP];
+#pragma unroll
+      for (int u = 0; u < AP; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int px = idx >> 3, s = idx & 7;
+        const int r = px / a.CI, cc = px - r * a.CI;
+        const int ih = h0 + a.min_dh + r, iw = q0 * a.in_stride + a.min_dw + cc;
+        v[u] = Slot16{0u, 0u, 0u, 0u};
+        if (idx < items && s < ns_c && ih >= 0 && ih < a.H && iw >= 0 && iw < a.Win)
+          v[u] = *(const Slot16*)(x + ((size_t)ih * a.Win + iw) * a.x_cs + a.x_co + (chunk * 8 + s) * E::CH);
+      }
+#pragma unroll
+      for (int u = 0; u < AP; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int px = idx >> 3, s = idx & 7;
+        if (idx < items) *(Slot16*)(As + px * 128 + ((s ^ ((px >> 1) & 7)) << 4)) = v[u];
+      }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  RD_W_LOAD(0);
+  RD_W_LOAD(wA, 0);
+  if (nsteps > 1) RD_W_LOAD(wB, 1);
+  float* Sc = (float*)(Ws + NT * 32 * 128);  // [scale(Cout) | shift(Cout)] for the epilogue
+  if (tid < NT * 32) {
+    Sc[tid] = a.scale ? a.scale[tid] : 1.f;
+    Sc[NT * 32 + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
   a_stage(0);
-  RD_W_STORE(0);
-  __syncthreads();
 
+  // steps are processed in pairs so that the two register sets are addressed statically
   for (int step = 0; step < nsteps; ++step) {
-    const int chunk = step / a.ntaps, tap = step - chunk * a.ntaps, buf = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) RD_W_LOAD(step + 1);
+    const int chunk = step / a.ntaps, tap = step - chunk * a.ntaps;
+    __syncthreads();  // every wave is done reading the previous slab (and, at a chunk boundary, the halo tile)
+    if (tap == 0 && chunk > 0 && !(a.dbg & 4)) a_stage(chunk);
+    if (!(a.dbg & 2) || step == 0) {
+      if (step & 1) {
+        RD_W_STORE(wB);
+        if (step + 2 < nsteps) RD_W_LOAD(wB, step + 2);
+      } else {
+        RD_W_STORE(wA);
+        if (step + 2 < nsteps) RD_W_LOAD(wA, step + 2);
+      }
+    }
+    __syncthreads();
 
     const int ns_c = min(8, a.nslots - 8 * chunk);
     const int tdh = (int)((a.dh_pack >> (4 * tap)) & 15) - 8, tdw = (int)((a.dw_pack >> (4 * tap)) & 15) - 8;
@@ -116,69 +146,88 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs a) {
       a_off[mt] = px * 128;
       a_swz[mt] = (px >> 1) & 7;
     }
-    const unsigned char* Wb = Ws + buf * w_bytes;
-    for (int ks = 0; ks < (ns_c >> 1); ++ks) {
+    for (int ks = 0; ks < ((a.dbg & 8) ? 0 : (ns_c >> 1)); ++ks) {
       const int slot = 2 * ks + hi;
       if constexpr (DT == RD_BF16) {
-        s16x8 av[2], bv[2];
+        s16x8 av[2], bv[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          av[i] = *(const s16x8*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
-          bv[i] = *(const s16x8*)(Wb + b_row[i] + ((slot ^ b_swz[i]) << 4));
-        }
+        for (int i = 0; i < 2; ++i) av[i] = *(const s16x8*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NT; ++j) bv[j] = *(const s16x8*)(Ws + b_row[j] + ((slot ^ b_swz[j]) << 4));
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
       } else {
-        f32x4 av[2], bv[2];
+        f32x4 av[2], bv[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          av[i] = *(const f32x4*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
-          bv[i] = *(const f32x4*)(Wb + b_row[i] + ((slot ^ b_swz[i]) << 4));
-        }
+        for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = *(const f32x4*)(Ws + b_row[j] + ((slot ^ b_swz[j]) << 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][e], av[i][e], acc[i][j], 0, 0, 0);
       }
     }
-    if (more && (step + 1) % a.ntaps == 0) {  // next step starts a new k-chunk: restage the halo tile
-      __syncthreads();
-      a_stage(chunk + 1);
-    }
-    if (more) RD_W_STORE(buf ^ 1);
-    __syncthreads();
   }
-
 #undef RD_W_LOAD
 #undef RD_W_STORE
-  // ---- epilogue: BN affine, ReLU / residual, store (lane = output channel, regs = 16 pixels) ----------
+
+  // ---- epilogue: BN affine, ReLU / residual, store.  The MFMAs are issued "transposed" (A operand = weights,
+  // B operand = pixels) and the weight rows are permuted in LDS, so lane (px, hi) holds output channels
+  // 32*nt + 16*hi + r (r = 0..15) of its pixel: 16 contiguous channels -> 16-byte residual loads and stores.
   const int oh = h0 + wm;
   if (oh >= a.H) return;
-  T* y = (T*)a.y + (size_t)b * a.y_bs;
-  const T* res = (const T*)a.res + (size_t)b * a.r_bs;
+  T* __restrict__ y = (T*)a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wout * a.y_cs + a.y_co;
+  const T* __restrict__ res = (const T*)a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wout * a.r_cs + a.r_co;
+  const bool relu_pre = a.flags & RD_RELU_PRE, do_add = a.flags & RD_ADD, relu_post = a.flags & RD_RELU_POST;
+  constexpr int SPT = 16 / E::CH;                 // 16-byte slots per 16 channels (2 for bf16, 4 for f32)
+  constexpr int NB = (DT == RD_BF16) ? NT : 1;    // tiles whose residual loads are batched ahead of the math
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int co = wn * 64 + nt * 32 + m;
-    const float sc = a.scale ? a.scale[co] : 1.f;
-    const float sh = a.shift ? a.shift[co] : 0.f;
+  for (int mt = 0; mt < 2; ++mt) {
+    const int q = q0 + mt * 32 + m;
+    const bool live = q < a.Wq;
+    const size_t pix = (size_t)q * a.out_stride + a.out_off;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int nb = 0; nb < NT; nb += NB) {
+      Slot16 rv[NB][SPT];
+      if (do_add && live) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = q0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (q < a.Wq) {
-          const size_t pix = (size_t)oh * a.Wout + (size_t)q * a.out_stride + a.out_off;
-          float v = acc[mt][nt][r] * sc + sh;
-          if (a.flags & RD_RELU_PRE) v = fmaxf(v, 0.f);
-          if (a.flags & RD_ADD) v += E::to_f32(res[pix * a.r_cs + a.r_co + co]);
-          if (a.flags & RD_RELU_POST) v = fmaxf(v, 0.f);
-          y[pix * a.y_cs + a.y_co + co] = E::from_f32(v);
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int u = 0; u < SPT; ++u)
+            rv[j][u] = *(const Slot16*)(res + pix * a.r_cs + (nb + j) * 32 + 16 * hi + u * E::CH);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int nt = nb + j, cb = nt * 32 + 16 * hi;
+        T rr[16];
+        if (do_add && live) memcpy(rr, rv[j], sizeof(rr));
+        T out[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 sc = *(const f32x4*)(Sc + cb + 4 * g);
+          const f32x4 sh = *(const f32x4*)(Sc + NT * 32 + cb + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float v = acc[mt][nt][r] * sc[e] + sh[e];
+            if (relu_pre) v = fmaxf(v, 0.f);
+            if (do_add && live) v += E::to_f32(rr[r]);
+            if (relu_post) v = fmaxf(v, 0.f);
+            out[r] = E::from_f32(v);
+          }
+        }
+        if (live && !(a.dbg & 1)) {
+          Slot16 pk[SPT];
+          memcpy(pk, out, sizeof(out));
+#pragma unroll
+          for (int u = 0; u < SPT; ++u) *(Slot16*)(y + pix * a.y_cs + cb + u * E::CH) = pk[u];
         }
       }
     }
@@ -254,6 +303,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   RD_REQUIRE(x_cs % ch == 0 && x_co % ch == 0, RD_ESHAPE, "conv: x channel stride/offset must be 16-byte multiples");
   RD_REQUIRE(x_co + cin_slots(cin, dt) * ch <= x_cs, RD_ESHAPE, "conv: x buffer narrower than padded cin");
   RD_REQUIRE(!(flags & RD_ADD) || res, RD_EINVAL, "conv: RD_ADD without residual");
+  RD_REQUIRE(y_cs % ch == 0 && y_co % ch == 0 && (!(flags & RD_ADD) || (r_cs % ch == 0 && r_co % ch == 0)), RD_ESHAPE,
+             "conv: y / residual channel stride and offset must be 16-byte multiples");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * Win * x_cs;
@@ -263,6 +314,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   a.H = H; a.Win = Win; a.Wq = Wq; a.Wout = Wout;
   a.nslots = cin_slots(cin, dt); a.cout = cout; a.ntaps = tl.n;
   a.in_stride = in_stride; a.out_stride = out_stride; a.out_off = out_off; a.flags = flags;
+  { const char* e = getenv("RD_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
   int mndh = 99, mxdh = -99, mndw = 99, mxdw = -99;
   for (int t = 0; t < tl.n; ++t) {
     a.dh_pack |= (unsigned long long)(tl.dh[t] + 8) << (4 * t);
@@ -270,20 +322,20 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndh = std::min(mndh, tl.dh[t]); mxdh = std::max(mxdh, tl.dh[t]);
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
-  const int RO = 4 / (cout / 64);
+  const int RO = 4;
   a.min_dh = mndh; a.min_dw = mndw;
   a.RI = RO + (mxdh - mndh);
   a.CI = 63 * in_stride + (mxdw - mndw) + 1;
-  const size_t lds = (size_t)a.RI * a.CI * 128 + 2 * (size_t)cout * 128;
+  const size_t lds = (size_t)a.RI * a.CI * 128 + (size_t)cout * 128 + (size_t)cout * 8;
   RD_REQUIRE(lds <= 160 * 1024, RD_ESHAPE, "conv: LDS tile %zu B too large", lds);
   dim3 grid((Wq + 63) / 64, (H + RO - 1) / RO, B);
   ProfScope ps(RD_PROF_CONV, st);
   if (dt == RD_BF16) {
-    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 1>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 2>), grid, dim3(256), lds, st, a);
+    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 4>), grid, dim3(256), lds, st, a);
   } else {
-    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 1>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 2>), grid, dim3(256), lds, st, a);
+    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 4>), grid, dim3(256), lds, st, a);
   }
   return check_launch("conv_taps_kernel");
 }

@@ -54,63 +54,90 @@ __device__ __forceinline__ bool w_outside(const WEdge& e0, const WEdge& e1, cons
   return w_sgn(w_cross3(p, e0.a, e0.b)) > 0;
 }
 
+// The 8 directed edges and the deque are indexed dynamically (sort, sweep), which would put them in scratch
+// (global memory).  They live in LDS instead, one column per lane: element i of lane t at [i*64 + t] (conflict-free).
+struct EdgeLds {
+  float *ax, *ay, *bx, *by, *an;  // each [8][64]
+  int* dq;                        // [16][64]
+  int t;
+  __device__ __forceinline__ WEdge get(int i) const {
+    WEdge e;
+    e.a = {ax[i * 64 + t], ay[i * 64 + t]};
+    e.b = {bx[i * 64 + t], by[i * 64 + t]};
+    e.ang = an[i * 64 + t];
+    return e;
+  }
+  __device__ __forceinline__ void put(int i, const WEdge& e) const {
+    ax[i * 64 + t] = e.a.x; ay[i * 64 + t] = e.a.y;
+    bx[i * 64 + t] = e.b.x; by[i * 64 + t] = e.b.y;
+    an[i * 64 + t] = e.ang;
+  }
+  __device__ __forceinline__ int& q(int i) const { return dq[i * 64 + t]; }
+};
+constexpr int EDGE_LDS_BYTES = (5 * 8 + 16) * 64 * 4;
+
 // box1 = the earlier (kept candidate) box, box2 = the later one; pre1/pre2 their prepped records.
-__device__ float w_overlap(const float* pre1, const float* pre2, bool is3d) {
+__device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, const EdgeLds& L) {
   RD_NOCONTRACT
-  WEdge l[8];
   // nms.h:210-225: p[0..3] = box2, p[4..7] = box1 ; l[z] from box2, l[z+4] from box1
 #pragma unroll
   for (int z = 0; z < 4; ++z) {
     int z1 = (z + 1) & 3;
-    l[z].a = {pre2[2 * z], pre2[2 * z + 1]};
-    l[z].b = {pre2[2 * z1], pre2[2 * z1 + 1]};
-    l[z].ang = pre2[8 + z];
-    l[z + 4].a = {pre1[2 * z], pre1[2 * z + 1]};
-    l[z + 4].b = {pre1[2 * z1], pre1[2 * z1 + 1]};
-    l[z + 4].ang = pre1[8 + z];
+    WEdge e;
+    e.a = {pre2[2 * z], pre2[2 * z + 1]};
+    e.b = {pre2[2 * z1], pre2[2 * z1 + 1]};
+    e.ang = pre2[8 + z];
+    L.put(z, e);
+    e.a = {pre1[2 * z], pre1[2 * z + 1]};
+    e.b = {pre1[2 * z1], pre1[2 * z1 + 1]};
+    e.ang = pre1[8 + z];
+    L.put(z + 4, e);
   }
   float area1 = pre1[12], area2 = pre2[12];
   // std::sort on 8 elements == libstdc++ __insertion_sort (n <= 16), restated literally because the
   // comparator is not a strict weak order (nms.h:58-64,98)
   for (int i = 1; i < 8; ++i) {
-    WEdge val = l[i];
-    if (w_less(val, l[0])) {
-      for (int j = i; j > 0; --j) l[j] = l[j - 1];
-      l[0] = val;
+    WEdge val = L.get(i);
+    if (w_less(val, L.get(0))) {
+      for (int j = i; j > 0; --j) L.put(j, L.get(j - 1));
+      L.put(0, val);
     } else {
       int j = i;
-      while (w_less(val, l[j - 1])) {
-        l[j] = l[j - 1];
+      while (w_less(val, L.get(j - 1))) {
+        L.put(j, L.get(j - 1));
         --j;
       }
-      l[j] = val;
+      L.put(j, val);
     }
   }
   int i, j;
   for (i = 0, j = 0; i < 8; i++)
-    if (w_sgn(l[i].ang - l[j].ang) > 0) l[++j] = l[i];
+    if (w_sgn(L.an[i * 64 + L.t] - L.an[j * 64 + L.t]) > 0) L.put(++j, L.get(i));
   const int t = j + 1;
-  int dq[16];
-  dq[0] = 0;
-  dq[1] = 1;
+  L.q(0) = 0;
+  L.q(1) = 1;
   int top = 1, bot = 0;
   for (i = 2; i < t; i++) {
-    while (top > bot && w_outside(l[i], l[dq[top]], l[dq[top - 1]])) top--;
-    while (top > bot && w_outside(l[i], l[dq[bot]], l[dq[bot + 1]])) bot++;
-    dq[++top] = i;
+    const WEdge li = L.get(i);
+    while (top > bot && w_outside(li, L.get(L.q(top)), L.get(L.q(top - 1)))) top--;
+    while (top > bot && w_outside(li, L.get(L.q(bot)), L.get(L.q(bot + 1)))) bot++;
+    L.q(++top) = i;
   }
-  while (top > bot && w_outside(l[dq[bot]], l[dq[top]], l[dq[top - 1]])) top--;
-  while (top > bot && w_outside(l[dq[top]], l[dq[bot]], l[dq[bot + 1]])) bot++;
-  dq[++top] = dq[bot];
+  while (top > bot && w_outside(L.get(L.q(bot)), L.get(L.q(top)), L.get(L.q(top - 1)))) top--;
+  while (top > bot && w_outside(L.get(L.q(top)), L.get(L.q(bot)), L.get(L.q(bot + 1)))) bot++;
+  {
+    const int qb = L.q(bot);
+    L.q(++top) = qb;
+  }
   // polygon vertices + fan area (nms.h:147-166), vertices generated on the fly
   const int nv = top - bot;
   float inter = 0.f;
   if (nv >= 3) {
-    WPt p0 = w_meet(l[dq[bot + 1]], l[dq[bot]]);
-    WPt pa = w_meet(l[dq[bot + 2]], l[dq[bot + 1]]);
+    WPt p0 = w_meet(L.get(L.q(bot + 1)), L.get(L.q(bot)));
+    WPt pa = w_meet(L.get(L.q(bot + 2)), L.get(L.q(bot + 1)));
     float area = 0.f;
     for (int k = 2; k < nv; ++k) {
-      WPt pb = w_meet(l[dq[bot + k + 1]], l[dq[bot + k]]);
+      WPt pb = w_meet(L.get(L.q(bot + k + 1)), L.get(L.q(bot + k)));
       area += w_cross3(p0, pa, pb);
       pa = pb;
     }
@@ -167,38 +194,48 @@ __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict_
   o[15] = 0.f;
 }
 
-// grid (nb, nb), 64 threads: tile (row block = blockIdx.y, col block = blockIdx.x), upper triangle only.
+// grid (8*nb, nb), 64 threads: rows 64*blockIdx.y.. x the 8 columns 64*cb + 8*sub.. (cb = blockIdx.x / 8, upper
+// triangle only).  One wave evaluates 64 x 8 pairs and writes ONE BYTE of each row's 64-bit mask word (little endian:
+// byte `sub` holds bits 8*sub..8*sub+7), so K = 1.5k boxes already give ~2.4k waves for the 256 CUs.
+constexpr int WN_CT = 8;
 __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict__ prep, int cap,
                                                         const int* __restrict__ d_count, float thresh, float thresh_vote,
                                                         int is3d, unsigned long long* __restrict__ thr,
                                                         unsigned long long* __restrict__ vote, int nwcap) {
-  const int rb = blockIdx.y, cb = blockIdx.x;
+  const int rb = blockIdx.y, cb = blockIdx.x / WN_CT, sub = blockIdx.x % WN_CT;
   const int K = d_count ? min(*d_count, cap) : cap;
   if (cb < rb || rb * 64 >= K || cb * 64 >= K) return;
-  __shared__ float colp[64 * PREP_F];
+  __shared__ float colp[WN_CT * PREP_F];
+  __shared__ float edges[EDGE_LDS_BYTES / 4];
   const int t = threadIdx.x;
-  {
-    int q2 = cb * 64 + t;
-#pragma unroll
-    for (int k = 0; k < PREP_F; ++k) colp[t * PREP_F + k] = q2 < K ? prep[(size_t)q2 * PREP_F + k] : 0.f;
+  EdgeLds EL;
+  EL.ax = edges; EL.ay = edges + 512; EL.bx = edges + 1024; EL.by = edges + 1536; EL.an = edges + 2048;
+  EL.dq = (int*)(edges + 2560);
+  EL.t = t;
+  const int c0 = cb * 64 + sub * WN_CT;
+  for (int i = t; i < WN_CT * PREP_F; i += 64) {
+    int q2 = c0 + i / PREP_F;
+    colp[i] = q2 < K ? prep[(size_t)q2 * PREP_F + (i % PREP_F)] : 0.f;
   }
   __syncthreads();
   const int q1 = rb * 64 + t;
   if (q1 >= K) return;
-  float mine[PREP_F];
+  unsigned mt = 0u, mv = 0u;
+  if (c0 + WN_CT - 1 > q1) {
+    float mine[PREP_F];
 #pragma unroll
-  for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
-  unsigned long long mt = 0ull, mv = 0ull;
-  for (int c = 0; c < 64; ++c) {
-    int q2 = cb * 64 + c;
-    if (q2 < K && q2 > q1) {
-      float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0);
-      if (ovr >= thresh) mt |= 1ull << c;
-      if (ovr > thresh_vote) mv |= 1ull << c;
+    for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
+    for (int c = 0; c < WN_CT; ++c) {
+      int q2 = c0 + c;
+      if (q2 < K && q2 > q1) {
+        float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0, EL);
+        if (ovr >= thresh) mt |= 1u << c;
+        if (ovr > thresh_vote) mv |= 1u << c;
+      }
     }
   }
-  thr[(size_t)q1 * nwcap + cb] = mt;
-  vote[(size_t)q1 * nwcap + cb] = mv;
+  ((unsigned char*)thr)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mt;
+  ((unsigned char*)vote)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mv;
 }
 
 // one wavefront; supp lives in LDS (cap <= RD_WNMS_MAX_K -> 256 words)

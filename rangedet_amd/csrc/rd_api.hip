@@ -121,9 +121,9 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
   const int pad = (kw - 1) / 2;
   const int Wout = (Win + 2 * pad - kw) / stride_w + 1;  // mx Convolution output size
   TapList tl = conv_taps(kh, kw);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 1>);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 4>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 1>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 4>);
   allow_big_lds(conv_taps_kernel<RD_F32, 2>);
   return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
                      y_coff, B, H, Win, Wout, Wout, cin, cout, stride_w, 1, 0, flags, dtype, (hipStream_t)stream);
@@ -141,9 +141,9 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   const int Wq = (Wout - phase + stride_w - 1) / stride_w;
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "deconv2d: %d taps per phase unsupported", tl.n);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 1>);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 4>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 1>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 4>);
   allow_big_lds(conv_taps_kernel<RD_F32, 2>);
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
                      y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
@@ -286,7 +286,7 @@ int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order
   }
   const int nb = (Kcap + 63) / 64;
   hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep);
-  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb, nb), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d,
+  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d,
                      w.thr, w.vote, w.nwcap);
   hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), 0, st, w.thr, w.vote, Kcap, d_count, w.nwcap, ord, w.keep_q,
                      keep, d_nkeep);

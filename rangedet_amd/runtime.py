@@ -151,18 +151,20 @@ class Executor:
         return b
 
     # ---- execution ------------------------------------------------------------------------------------------------------
-    def forward(self, inputs):
-        """inputs: name -> float32 array/tensor WITH batch dim (the reference's data_name list, config:400-404)."""
+    def forward(self, inputs, only=None, dev=None):
+        """inputs: name -> float32 array/tensor WITH batch dim (the reference's data_name list, config:400-404).
+        `only` (profiling aid): run just that plan step index."""
         L, A, dt, B = self.lib, self.alloc, self.dtype, self.B
         st_ = A.stream
-        dev = {}
+        dev = {} if dev is None else dev
 
         def din(name):
             if name not in dev:
                 dev[name] = A.as_device_f32(inputs[name])
             return dev[name]
 
-        for b in self._bound:
+        steps = self._bound if only is None else [self._bound[only]]
+        for b in steps:
             k = b["kind"]
             if k == "nchw_in":
                 o = b["out"]
@@ -207,6 +209,8 @@ class Executor:
                        b["box_type"], b["is_bin"], st_)
             else:
                 raise RuntimeError("unknown plan step %r" % k)
+        if only is not None:
+            return None
         outs = []
         for kind, v in self.plan.outputs:
             if kind == "flat":

@@ -1,0 +1,48 @@
+"""Per-plan-step timing on the GPU (each step replayed `reps` times back to back, torch events): a tuning aid.
+    python tools/profile_steps.py [bf16|f32] [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rangedet_amd import lib as rdlib, synth  # noqa: E402
+from rangedet_amd.pipeline import RangeDetPipeline  # noqa: E402
+
+dt = rdlib.RD_F32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else rdlib.RD_BF16
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=dt)
+fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_frame(0).items()}
+pipe.enqueue(fr)
+torch.cuda.synchronize()
+ex = pipe.exe
+tot = 0.0
+rows = []
+for i, st in enumerate(pipe.plan.steps):
+    dev = {}
+    ex.forward(fr, only=i, dev=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ex.forward(fr, only=i, dev=dev)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    tot += us
+    k = st["kind"]
+    fl = 0.0
+    desc = ""
+    if k in ("conv", "deconv"):
+        o = st["out"]
+        fl = 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
+        desc = "%s %d->%d k%s W%d->%d s%d" % (st["name"], st["cin"], st["cout"], st["k"], st["x"].W, o.W, st["stride_w"])
+    elif k == "meta":
+        fl = 19.29e9
+        desc = "meta unit"
+    else:
+        desc = st.get("name", "")
+    rows.append((us, k, desc, fl))
+    print("%3d %-9s %-52s %8.1f us %8.1f TFLOP/s" % (i, k, desc[:52], us, fl / us / 1e6 if fl else 0), flush=True)
+print("sum of steps: %.1f us" % tot)
