@@ -34,61 +34,84 @@ struct ConvArgs {
   int min_dh, min_dw, RI, CI;
   int flags;
   unsigned long long dh_pack, dw_pack;  // 4 bits per tap, biased by 8 (no dynamically indexed kernarg arrays)
+  int ncol;  // column tiles (64 output positions each)
+  unsigned ci_magic;  // floor(2^32 / CI) + 1: px / CI == umulhi(px, ci_magic) for the px range of a halo tile
   int dbg;  // tuning ablations (tools/conv_bench.py): 1 no epilogue stores, 2 one weight slab only, 4 one halo stage, 8 no MFMA
 };
 
-template <int DT, int NT>  // NT = Cout / 32 output-channel tiles per wave (2 or 4)
-__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvArgs a) {
+// s_waitcnt immediate (gfx9 encoding) that waits for vmcnt <= n only (expcnt / lgkmcnt left at "no wait")
+#define RD_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+
+template <int DT, int NW, int RING>  // NW waves (= output rows) per workgroup, RING weight slabs in LDS
+__global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   using E = Elem<DT>;
   using T = typename E::T;
   HIP_DYNAMIC_SHARED(unsigned char, smem);
-  constexpr int RO = 4;              // output rows per workgroup = one per wave
-  constexpr int WCNT = NT;           // 16-byte slots of one weight slab handled per thread (Cout*8/256)
-  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
-  const int q0 = blockIdx.x * 64, h0 = blockIdx.y * RO, b = blockIdx.z;
+  constexpr int NTH = NW * 64;
+  constexpr int COUT = 64;                // output channels per workgroup; Cout = 128 runs as two channel-half workgroups
+  constexpr int RO = NW;                  // output rows per workgroup, one wave each
+  constexpr int SLAB = COUT * 128;        // bytes of this workgroup's half of one (k-chunk, tap) weight slab
+  constexpr int IPW = COUT / 8 / NW;      // LDS-DMA instructions (64 x 16 B) per wave per slab
+  constexpr int D = RING - 1;             // prefetch distance in steps
+  static_assert(IPW * NW * 64 * 16 == SLAB && IPW >= 1, "slab must split evenly over the waves");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave;
+  const int nhalf = a.cout >> 6;          // 1 or 2 channel halves
+  const int wc = 0;
+  // XCD-aware tile assignment.  Workgroup ids are dealt round-robin to the 8 XCDs (private L2s), so each XCD gets a
+  // CONTIGUOUS range of the tile list ordered (row block, column tile, channel half): the two channel halves of a
+  // pixel tile run back to back on one XCD (second one hits the halo in L2) and vertically adjacent row blocks, which
+  // share halo rows, live in the same L2.  Pure speed choice; any mapping is correct.
+  int widx;
+  {
+    const int T = gridDim.x, L = blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int qn = T >> 3, rn = T & 7;
+    widx = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + i;
+  }
+  const int chalf = widx % nhalf;
+  const int ct = (widx / nhalf) % a.ncol;
+  const int q0 = ct * 64, h0 = (widx / (nhalf * a.ncol)) * RO, b = blockIdx.z;
   const int m = lane & 31, hi = lane >> 5;
 
   unsigned char* As = smem;
-  unsigned char* Ws = smem + a.RI * a.CI * 128;  // ONE weight slab [Cout][128 B]; the pipeline depth lives in registers
+  unsigned char* Ws = smem + a.RI * a.CI * 128;            // RING slabs
+  float* Sc = (float*)(Ws + RING * SLAB);                  // [scale(Cout) | shift(Cout)]
   const T* x = (const T*)a.x + (size_t)b * a.x_bs;
   const int nchunk = (a.nslots + 7) >> 3;
   const int nsteps = nchunk * a.ntaps;
 
-  int b_row[NT], b_swz[NT];
+  // weight slabs go global -> LDS by LDS-DMA: the destination of one instruction is wave-uniform base + lane*16,
+  // so the LDS image is linear and both the XOR swizzle and the output-channel row permutation are applied to the
+  // per-lane SOURCE address (constant across steps).
+  int goff[IPW];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    int n = nt * 32 + m;
-    b_row[nt] = n * 128;
-    b_swz[nt] = (n >> 1) & 7;
+  for (int j = 0; j < IPW; ++j) {
+    const int p = (wave * IPW + j) * 64 + lane;            // linear 16-byte slot of the LDS slab
+    const int n = p >> 3, sp = p & 7;
+    const int s = sp ^ ((n >> 1) & 7);
+    const int mm = n & 31;
+    const int c = (n & ~31) | (16 * ((mm >> 2) & 1) + 4 * (mm >> 3) + (mm & 3));
+    goff[j] = (c * 8 + s) * 16;
   }
-
-  // weight slabs: global -> registers two steps ahead -> LDS right before use
-  Slot16 wA[WCNT], wB[WCNT];
-#define RD_W_LOAD(dst_, step_)                                                        \
-  {                                                                                   \
-    const Slot16* src_ = (const Slot16*)a.w + (size_t)(step_) * (NT * 32 * 8);        \
-    _Pragma("unroll") for (int i_ = 0; i_ < WCNT; ++i_) dst_[i_] = src_[tid + i_ * 256]; \
-  }
-#define RD_W_STORE(src_)                                                              \
-  {                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < WCNT; ++i_) {                             \
-      const int idx_ = tid + i_ * 256, c_ = idx_ >> 3, s_ = idx_ & 7;                 \
-      const int n_ = (c_ & ~31) | ((c_ & 3) + 8 * ((c_ >> 2) & 3) + 4 * ((c_ >> 4) & 1)); \
-      *(Slot16*)(Ws + n_ * 128 + ((s_ ^ ((n_ >> 1) & 7)) << 4)) = src_[i_];           \
-    }                                                                                 \
-  }
+  auto w_fill = [&](int step) {
+    const unsigned char* src = (const unsigned char*)a.w + ((size_t)step * nhalf + chalf) * SLAB;
+    unsigned char* dst = Ws + (step % RING) * SLAB + wave * IPW * 1024;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j)
+      lds_dma16(src + goff[j], dst + j * 1024);
+  };
   // halo tile: all global loads of a pass are issued before the first LDS write (latency paid once per pass)
-  constexpr int AP = 7;
+  constexpr int AP = (6 * 66 * 8 + NTH - 1) / NTH > 8 ? 8 : (6 * 66 * 8 + NTH - 1) / NTH;
   auto a_stage = [&](int chunk) {
     const int ns_c = min(8, a.nslots - 8 * chunk);
     const int items = a.RI * a.CI * 8;
-    for (int base = 0; base < items; base += 256 * AP) {
+    for (int base = 0; base < items; base += NTH * AP) {
       Slot16 v[AP];
 #pragma unroll
       for (int u = 0; u < AP; ++u) {
-        const int idx = base + u * 256 + tid;
+        const int idx = base + u * NTH + tid;
         const int px = idx >> 3, s = idx & 7;
-        const int r = px / a.CI, cc = px - r * a.CI;
+        const int r = (int)__umulhi((unsigned)px, a.ci_magic), cc = px - r * a.CI;  // px / CI without a divide
         const int ih = h0 + a.min_dh + r, iw = q0 * a.in_stride + a.min_dw + cc;
         v[u] = Slot16{0u, 0u, 0u, 0u};
         if (idx < items && s < ns_c && ih >= 0 && ih < a.H && iw >= 0 && iw < a.Win)
@@ -96,123 +119,158 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < AP; ++u) {
-        const int idx = base + u * 256 + tid;
+        const int idx = base + u * NTH + tid;
         const int px = idx >> 3, s = idx & 7;
         if (idx < items) *(Slot16*)(As + px * 128 + ((s ^ ((px >> 1) & 7)) << 4)) = v[u];
       }
     }
+    // tell hipcc's waitcnt pass explicitly that nothing of this stage is pending any more: the loads above sit in
+    // predicated blocks, and without this it keeps a "maybe pending" state on their registers that costs an
+    // s_waitcnt vmcnt(0) (= a drained weight ring) in every iteration of the tap loop.
+    __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
   };
+  // Workgroup barrier that orders LDS traffic only.  __syncthreads() (and a workgroup fence, even one restricted to
+  // the "local" address space on this compiler) makes hipcc emit s_waitcnt vmcnt(0), which would drain the weight
+  // ring at every step; the hardware only needs this wave's LDS accesses retired (lgkmcnt(0)) before s_barrier.
+  // The empty asm statements stop the compiler from moving LDS accesses across the barrier.
+#define RD_LDS_BARRIER()                                                     \
+  {                                                                          \
+    asm volatile("" ::: "memory");                                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0), vmcnt/expcnt free */   \
+    __builtin_amdgcn_s_barrier();                                            \
+    asm volatile("" ::: "memory");                                           \
+  }
 
-  f32x16 acc[2][NT];
+  // Fragment addresses: a 128-byte LDS row holds 8 XOR-swizzled 16-byte slots; lane (row, hi) reads slot 2*ks + hi, i.e.
+  // byte (row*128) | (((swz ^ hi) ^ 2*ks) << 4) = addr0 ^ (ks << 5): one v_xor per fragment read in the MFMA loop.
+  int b0[2], pbase[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wc * 64 + nt * 32 + m;
+    b0[nt] = (n << 7) | (((((n >> 1) & 7)) ^ hi) << 4);
+    pbase[nt] = wm * a.CI + (nt * 32 + m) * a.in_stride;   // halo pixel of this lane for tap (min_dh, min_dw)
+  }
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  RD_W_LOAD(wA, 0);
-  if (nsteps > 1) RD_W_LOAD(wB, 1);
-  float* Sc = (float*)(Ws + NT * 32 * 128);  // [scale(Cout) | shift(Cout)] for the epilogue
-  if (tid < NT * 32) {
-    Sc[tid] = a.scale ? a.scale[tid] : 1.f;
-    Sc[NT * 32 + tid] = a.shift ? a.shift[tid] : 0.f;
+  a_stage(0);                                   // ordinary loads first: hipcc waits vmcnt(0) for them, nothing else in flight yet
+  if (tid < COUT) {
+    Sc[tid] = a.scale ? a.scale[chalf * 64 + tid] : 1.f;
+    Sc[COUT + tid] = a.shift ? a.shift[chalf * 64 + tid] : 0.f;
   }
-  a_stage(0);
+#pragma unroll
+  for (int s0 = 0; s0 < D; ++s0)
+    if (s0 < nsteps) w_fill(s0);
 
-  // steps are processed in pairs so that the two register sets are addressed statically
-  for (int step = 0; step < nsteps; ++step) {
-    const int chunk = step / a.ntaps, tap = step - chunk * a.ntaps;
-    __syncthreads();  // every wave is done reading the previous slab (and, at a chunk boundary, the halo tile)
-    if (tap == 0 && chunk > 0 && !(a.dbg & 4)) a_stage(chunk);
-    if (!(a.dbg & 2) || step == 0) {
-      if (step & 1) {
-        RD_W_STORE(wB);
-        if (step + 2 < nsteps) RD_W_LOAD(wB, step + 2);
-      } else {
-        RD_W_STORE(wA);
-        if (step + 2 < nsteps) RD_W_LOAD(wA, step + 2);
-      }
+  // Loop nest: k-chunks outside (halo restage = ordinary loads), taps inside (LDS-DMA only).  Keeping the ordinary
+  // loads out of the tap loop matters: hipcc's waitcnt pass otherwise carries "maybe pending load" state of the halo
+  // registers around the loop and drains vmcnt(0) in every iteration.
+  int step = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    if (chunk > 0 && !(a.dbg & 4)) {
+      RD_LDS_BARRIER();  // every wave is done with the previous chunk's halo tile
+      a_stage(chunk);
     }
-    __syncthreads();
+   for (int tap = 0; tap < a.ntaps; ++tap, ++step) {
+    // slab `step` must have landed: at most the younger fills (steps step+1 .. step+D-1) may still be in flight
+    {
+      const int younger = min(D - 1, nsteps - 1 - step);
+      if (younger >= 3) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(3 * IPW));
+      else if (younger == 2) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(2 * IPW));
+      else if (younger == 1) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(1 * IPW));
+      else __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
+    }
+    RD_LDS_BARRIER();  // all parts of slab `step` (and a fresh halo tile) are in LDS; everyone is done with slab step-1
+    if (step + D < nsteps && !(a.dbg & 2)) w_fill(step + D);   // refill the slot slab step-1 just vacated
 
     const int ns_c = min(8, a.nslots - 8 * chunk);
     const int tdh = (int)((a.dh_pack >> (4 * tap)) & 15) - 8, tdw = (int)((a.dw_pack >> (4 * tap)) & 15) - 8;
-    const int trow = wm + (tdh - a.min_dh);
-    int a_off[2], a_swz[2];
+    const int delta = (tdh - a.min_dh) * a.CI + (tdw - a.min_dw);   // wave-uniform halo-pixel shift of this tap
+    int a0[2], bw[2];
+    const int slab_off = (a.RI * a.CI + ((a.dbg & 2) ? 0 : (step % RING)) * (SLAB / 128)) << 7;  // ring slot, bytes from smem
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      int px = trow * a.CI + (mt * 32 + m) * a.in_stride + (tdw - a.min_dw);
-      a_off[mt] = px * 128;
-      a_swz[mt] = (px >> 1) & 7;
+    for (int i = 0; i < 2; ++i) {
+      const int px = pbase[i] + delta;
+      a0[i] = (px << 7) | ((((px >> 1) & 7) ^ hi) << 4);
+      bw[i] = b0[i] + slab_off;
     }
-    for (int ks = 0; ks < ((a.dbg & 8) ? 0 : (ns_c >> 1)); ++ks) {
-      const int slot = 2 * ks + hi;
+    auto kstep = [&](int ks) {
+      const int kx = ks << 5;
       if constexpr (DT == RD_BF16) {
-        s16x8 av[2], bv[NT];
+        s16x8 av[2], bv[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) av[i] = *(const s16x8*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
+        for (int i = 0; i < 2; ++i) {
+          av[i] = *(const s16x8*)(smem + (a0[i] ^ kx));
+          bv[i] = *(const s16x8*)(smem + (bw[i] ^ kx));
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = *(const s16x8*)(Ws + b_row[j] + ((slot ^ b_swz[j]) << 4));
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
       } else {
-        f32x4 av[2], bv[NT];
+        f32x4 av[2], bv[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(As + a_off[i] + ((slot ^ a_swz[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = *(const f32x4*)(Ws + b_row[j] + ((slot ^ b_swz[j]) << 4));
+        for (int i = 0; i < 2; ++i) {
+          av[i] = *(const f32x4*)(smem + (a0[i] ^ kx));
+          bv[i] = *(const f32x4*)(smem + (bw[i] ^ kx));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][e], av[i][e], acc[i][j], 0, 0, 0);
       }
+    };
+    if (!(a.dbg & 8)) {
+      for (int ks = 0; ks < (ns_c >> 1); ++ks) kstep(ks);
     }
+   }
   }
-#undef RD_W_LOAD
-#undef RD_W_STORE
+#undef RD_LDS_BARRIER
 
   // ---- epilogue: BN affine, ReLU / residual, store.  The MFMAs are issued "transposed" (A operand = weights,
   // B operand = pixels) and the weight rows are permuted in LDS, so lane (px, hi) holds output channels
-  // 32*nt + 16*hi + r (r = 0..15) of its pixel: 16 contiguous channels -> 16-byte residual loads and stores.
+  // 64*wc + 32*nt + 16*hi + r (r = 0..15) of its pixel: 16 contiguous channels -> 16-byte residual loads and stores.
   const int oh = h0 + wm;
   if (oh >= a.H) return;
-  T* __restrict__ y = (T*)a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wout * a.y_cs + a.y_co;
-  const T* __restrict__ res = (const T*)a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wout * a.r_cs + a.r_co;
+  T* __restrict__ y = (T*)a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wout * a.y_cs + a.y_co + chalf * 64;
+  const T* __restrict__ res = (const T*)a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wout * a.r_cs + a.r_co + chalf * 64;
   const bool relu_pre = a.flags & RD_RELU_PRE, do_add = a.flags & RD_ADD, relu_post = a.flags & RD_RELU_POST;
   constexpr int SPT = 16 / E::CH;                 // 16-byte slots per 16 channels (2 for bf16, 4 for f32)
-  constexpr int NB = (DT == RD_BF16) ? NT : 1;    // tiles whose residual loads are batched ahead of the math
+  constexpr int NB = (DT == RD_BF16) ? 2 : 1;     // tiles whose residual loads are batched ahead of the math
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int q = q0 + mt * 32 + m;
     const bool live = q < a.Wq;
     const size_t pix = (size_t)q * a.out_stride + a.out_off;
 #pragma unroll
-    for (int nb = 0; nb < NT; nb += NB) {
+    for (int nb = 0; nb < 2; nb += NB) {
       Slot16 rv[NB][SPT];
       if (do_add && live) {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
           for (int u = 0; u < SPT; ++u)
-            rv[j][u] = *(const Slot16*)(res + pix * a.r_cs + (nb + j) * 32 + 16 * hi + u * E::CH);
+            rv[j][u] = *(const Slot16*)(res + pix * a.r_cs + wc * 64 + (nb + j) * 32 + 16 * hi + u * E::CH);
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int nt = nb + j, cb = nt * 32 + 16 * hi;
+        const int nt = nb + j, cb = wc * 64 + nt * 32 + 16 * hi;
         T rr[16];
         if (do_add && live) memcpy(rr, rv[j], sizeof(rr));
         T out[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 sc = *(const f32x4*)(Sc + cb + 4 * g);
-          const f32x4 sh = *(const f32x4*)(Sc + NT * 32 + cb + 4 * g);
+          const f32x4 sh = *(const f32x4*)(Sc + COUT + cb + 4 * g);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
@@ -322,21 +380,28 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndh = std::min(mndh, tl.dh[t]); mxdh = std::max(mxdh, tl.dh[t]);
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
-  const int RO = 4;
+  // Workgroup = NW rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile).
+  // cout 128: 8 waves, one WG per CU, 4-deep weight ring -- unless the halo is too big (stride 2: 129 columns);
+  // otherwise 4 waves, 3-deep ring (two WGs per CU when the halo allows).
+  int RO = (cout == 128 && getenv("RD_CONV_RO8")) ? 8 : 4;
+  int mxw = (mxdw - mndw);
+  if (RO == 8 && (size_t)(8 + mxdh - mndh) * (63 * in_stride + mxw + 1) * 128 + 4 * 64 * 128 + 512 > 160 * 1024) RO = 4;
   a.min_dh = mndh; a.min_dw = mndw;
   a.RI = RO + (mxdh - mndh);
-  a.CI = 63 * in_stride + (mxdw - mndw) + 1;
-  const size_t lds = (size_t)a.RI * a.CI * 128 + (size_t)cout * 128 + (size_t)cout * 8;
+  a.CI = 63 * in_stride + mxw + 1;
+  const size_t halo = (size_t)a.RI * a.CI * 128;
+  const int ring = RO == 8 ? 4 : 3;
+  const size_t lds = halo + (size_t)ring * 64 * 128 + 64 * 8;
   RD_REQUIRE(lds <= 160 * 1024, RD_ESHAPE, "conv: LDS tile %zu B too large", lds);
-  dim3 grid((Wq + 63) / 64, (H + RO - 1) / RO, B);
+  a.ncol = (Wq + 63) / 64;
+  a.ci_magic = (unsigned)((1ull << 32) / (unsigned)a.CI) + 1u;
+  dim3 grid(a.ncol * ((H + RO - 1) / RO) * (cout / 64), 1, B);
   ProfScope ps(RD_PROF_CONV, st);
-  if (dt == RD_BF16) {
-    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<RD_BF16, 4>), grid, dim3(256), lds, st, a);
-  } else {
-    if (cout == 64) hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_taps_kernel<RD_F32, 4>), grid, dim3(256), lds, st, a);
-  }
+#define RD_LAUNCH_CONV(DT_)                                                                            \
+  if (RO == 4) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);         \
+  else hipLaunchKernelGGL((conv_taps_kernel<DT_, 8, 4>), grid, dim3(512), lds, st, a);
+  if (dt == RD_BF16) { RD_LAUNCH_CONV(RD_BF16) } else { RD_LAUNCH_CONV(RD_F32) }
+#undef RD_LAUNCH_CONV
   return check_launch("conv_taps_kernel");
 }
 

@@ -36,6 +36,12 @@ template <class K>
 inline void allow_big_lds(K kernel) {
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+inline void allow_conv_lds() {
+  allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
+  allow_big_lds(conv_taps_kernel<RD_BF16, 8, 4>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 8, 4>);
+}
 }  // namespace rd
 
 extern "C" {
@@ -121,10 +127,7 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
   const int pad = (kw - 1) / 2;
   const int Wout = (Win + 2 * pad - kw) / stride_w + 1;  // mx Convolution output size
   TapList tl = conv_taps(kh, kw);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 4>);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 2>);
+  allow_conv_lds();
   return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
                      y_coff, B, H, Win, Wout, Wout, cin, cout, stride_w, 1, 0, flags, dtype, (hipStream_t)stream);
 }
@@ -141,10 +144,7 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   const int Wq = (Wout - phase + stride_w - 1) / stride_w;
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "deconv2d: %d taps per phase unsupported", tl.n);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 4>);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 2>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 2>);
+  allow_conv_lds();
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
                      y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
                      (hipStream_t)stream);

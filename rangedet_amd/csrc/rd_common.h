@@ -131,4 +131,24 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 typedef unsigned Slot16 __attribute__((ext_vector_type(4)));  // one 16-byte LDS/global granule (register-resident)
 
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst_uniform + lane*16] <- *gsrc (per lane).  Issued through inline asm on the
+// device so that hipcc's waitcnt pass does not see it: seen through the builtin, every later ds_read is preceded by
+// s_waitcnt vmcnt(0) (the compiler cannot tell ring slots apart), which drains the prefetch ring each step.  The
+// caller owns the ordering: counted s_waitcnt vmcnt(N) + workgroup barrier before any ds_read of the destination.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst_uniform);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+#endif
+}
+
 }  // namespace rd

@@ -250,6 +250,14 @@ inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return hipemu::exchange(v, 0); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
+inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+inline void __builtin_amdgcn_fence(int, const char*, ...) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+// LDS-DMA: destination = wave-uniform LDS base + lane * size (the emu copies synchronously)
+template <class SrcPtr, class DstPtr>
+inline void __builtin_amdgcn_global_load_lds(SrcPtr src, DstPtr lds_base, unsigned size, int offset, unsigned) {
+  memcpy((unsigned char*)(uintptr_t)lds_base + offset + (size_t)hipemu::cur()->lane * size, (const void*)(uintptr_t)src, size);
+}
 inline bool isinf(float v) { return std::isinf(v); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __threadfence() {}
@@ -261,6 +269,7 @@ template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; 
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __expf(float x) { return expf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
