@@ -61,10 +61,24 @@ __global__ __launch_bounds__(256) void head_out_kernel(const void* __restrict__ 
     for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
     if (p < HW) {
       const T* px = x + p * cs + coff + sub * per;
-      for (int c = 0; c < per; ++c) {
-        float v = E::to_f32(px[c]);
+      if ((per % E::CH) == 0) {             // 16-byte vector loads (the normal case: per = 16 channels)
+        for (int c0 = 0; c0 < per; c0 += E::CH) {
+          const Slot16 raw = *(const Slot16*)(px + c0);
+          T el[E::CH];
+          memcpy(el, &raw, 16);
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[o] += v * wl[o * cin + sub * per + c];
+          for (int e = 0; e < E::CH; ++e) {
+            const float v = E::to_f32(el[e]);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) acc[o] += v * wl[o * cin + sub * per + c0 + e];
+          }
+        }
+      } else {
+        for (int c = 0; c < per; ++c) {
+          float v = E::to_f32(px[c]);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) acc[o] += v * wl[o * cin + sub * per + c];
+        }
       }
     }
 #pragma unroll

@@ -238,49 +238,66 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
   ((unsigned char*)vote)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mv;
 }
 
-// one wavefront; supp lives in LDS (cap <= RD_WNMS_MAX_K -> 256 words)
+// Greedy scan, one wavefront.  Per 64 sorted rows the needed part of the thr bit-matrix (64 rows x remaining words) is
+// pulled into LDS with all loads in flight at once (one memory latency per 64 rows instead of a dependent load chain per
+// kept row); the rows are then resolved sequentially out of LDS.  For every kept row the suppression state BEFORE it is
+// snapshotted to `snap` (the merge kernel forms the neighbourhood vote[q] & ~snap), so the vote matrix is never read here.
 __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long* __restrict__ thr,
-                                                       unsigned long long* __restrict__ vote, int cap,
+                                                       unsigned long long* __restrict__ snap, int cap,
                                                        const int* __restrict__ d_count, int nwcap,
                                                        const int* __restrict__ order, int* __restrict__ keep_q,
                                                        int* __restrict__ keep, int* __restrict__ d_nkeep) {
-  __shared__ unsigned long long supp[RD_WNMS_MAX_K / 64];
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  unsigned long long* supp = (unsigned long long*)smem;      // [nwcap]
+  unsigned long long* tile = supp + nwcap;                   // [64][nwcap]
   const int lane = threadIdx.x;
   const int K = d_count ? min(*d_count, cap) : cap;
   const int nw = (K + 63) >> 6;
   for (int w = lane; w < nw; w += 64) supp[w] = 0ull;
   __builtin_amdgcn_wave_barrier();
   int M = 0;
-  int q = 0;
-  while (q < K) {
-    const int w0 = q >> 6;
-    unsigned long long avail = ~supp[w0] & (~0ull << (q & 63));
-    if (avail == 0ull) {
-      q = (w0 + 1) << 6;
-      continue;
+  for (int c = 0; c < nw; ++c) {
+    const int rows = min(64, K - (c << 6));
+    for (int w0 = c; w0 < nw; w0 += 64) {                     // batches of 16 independent row loads in flight
+      const int w = w0 + lane;
+      for (int r0 = 0; r0 < rows; r0 += 16) {
+        unsigned long long v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          v[u] = (w < nw && r0 + u < rows) ? thr[(size_t)((c << 6) + r0 + u) * nwcap + w] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (w < nw && r0 + u < rows) tile[(r0 + u) * nwcap + w] = v[u];
+      }
     }
-    q = (w0 << 6) + __ffsll(avail) - 1;
-    if (q >= K) break;
-    for (int w = w0 + lane; w < nw; w += 64) {
-      unsigned long long s = supp[w];
-      unsigned long long tb = thr[(size_t)q * nwcap + w];
-      unsigned long long vb = vote[(size_t)q * nwcap + w];
-      vote[(size_t)q * nwcap + w] = vb & ~s;  // neighbourhood snapshot before this row's suppression
-      supp[w] = s | tb;
-    }
-    if (lane == 0) {
-      keep_q[M] = q;
-      keep[M] = order[q];
-    }
-    ++M;
-    ++q;
     __builtin_amdgcn_wave_barrier();
+    int r = 0;
+    while (r < rows) {
+      unsigned long long avail = ~supp[c] & (~0ull << r);
+      if (rows < 64) avail &= (1ull << rows) - 1ull;
+      if (avail == 0ull) break;
+      r = __ffsll(avail) - 1;
+      const int q = (c << 6) + r;
+      for (int w = c + lane; w < nw; w += 64) {
+        const unsigned long long sw = supp[w];
+        snap[(size_t)M * nwcap + w] = sw;
+        supp[w] = sw | tile[r * nwcap + w];
+      }
+      if (lane == 0) {
+        keep_q[M] = q;
+        keep[M] = order[q];
+      }
+      ++M;
+      ++r;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   if (lane == 0) *d_nkeep = M;
 }
 
 __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict__ dets, const int* __restrict__ order,
-                                                        const unsigned long long* __restrict__ vote, int cap,
+                                                        const unsigned long long* __restrict__ vote,
+                                                        const unsigned long long* __restrict__ snap, int cap,
                                                         const int* __restrict__ d_count, int nwcap,
                                                         const int* __restrict__ keep_q, const int* __restrict__ d_nkeep,
                                                         float* __restrict__ out) {
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
     yws[0] = yaw_i;
   }
   for (int w = q >> 6; w < nw; ++w) {
-    unsigned long long word = vote[(size_t)q * nwcap + w];
+    unsigned long long word = vote[(size_t)q * nwcap + w] & ~snap[(size_t)mrow * nwcap + w];
     if ((word >> lane) & 1ull) {
       int pos = n + __popcll(word & ((1ull << lane) - 1ull));
       int q2 = (w << 6) + lane;
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {
 
 struct WnmsWs {
   float* prep;
-  unsigned long long *thr, *vote;
+  unsigned long long *thr, *vote, *snap;
   int *keep_q, *order;
   void* sort_ws;
   int nwcap;

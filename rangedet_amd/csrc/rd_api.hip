@@ -16,7 +16,7 @@ namespace rd {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t wnms_ws_bytes(int cap) {
   const size_t nw = (size_t)(cap + 63) / 64;
-  return align256((size_t)cap * PREP_F * 4) + 2 * align256((size_t)cap * nw * 8) + 2 * align256((size_t)cap * 4) +
+  return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 2 * align256((size_t)cap * 4) +
          align256(sort_ws_bytes(cap)) + 256;
 }
 inline WnmsWs wnms_ws_carve(void* ws, int cap) {
@@ -27,6 +27,7 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   w.prep = (float*)p; p += align256((size_t)cap * PREP_F * 4);
   w.thr = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
   w.vote = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
+  w.snap = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
   w.keep_q = (int*)p; p += align256((size_t)cap * 4);
   w.order = (int*)p; p += align256((size_t)cap * 4);
   w.sort_ws = p;
@@ -288,11 +289,14 @@ int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order
   hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep);
   hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d,
                      w.thr, w.vote, w.nwcap);
-  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), 0, st, w.thr, w.vote, Kcap, d_count, w.nwcap, ord, w.keep_q,
+  const size_t scan_lds = (size_t)65 * w.nwcap * 8;
+  RD_REQUIRE(scan_lds <= 160 * 1024, RD_ESHAPE, "wnms_4c: Kcap too large for the scan tile");
+  allow_big_lds(wnms_scan_kernel);
+  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord, w.keep_q,
                      keep, d_nkeep);
   allow_big_lds(wnms_merge_kernel);
-  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, Kcap, d_count, w.nwcap, w.keep_q,
-                     d_nkeep, out_dets);
+  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, w.snap, Kcap,
+                     d_count, w.nwcap, w.keep_q, d_nkeep, out_dets);
   return check_launch("wnms_4c");
 }
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {

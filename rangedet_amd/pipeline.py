@@ -36,14 +36,22 @@ class PostProcessor:
         self.keep = A.alloc(self.cap * 4)
         self.nkeep = A.alloc(16, zero=True)
         self.out8 = A.alloc(self.cap * 8 * 4)
+        # the rows reaching WNMS are already in (score desc, index asc) order: get_sorted_foreground sorts and the score
+        # filter is a stable compaction, so the processing order is the identity and the device re-sort is skipped
+        self.identity = A.upload(np.arange(self.cap, dtype=np.int32))
 
-    def enqueue(self, score_ptr, box_ptr, order_ptr=None):
-        L, A, st = self.L, self.A, self.A.stream
+    def enqueue(self, score_ptr, box_ptr, order_ptr=None, stream=None):
+        """Enqueue on `stream` (a side stream from alloc.new_stream(), or None = the current stream).  Returns the event
+        recorded right after the score filter, i.e. the point from which the score / box buffers may be overwritten."""
+        L, A = self.L, self.A
+        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
         L.call("rd_score_filter_dets", score_ptr, box_ptr, self.k, self.min_score, A.ptr(self.dets), A.ptr(self.count),
                A.ptr(self.ws_f), self.ws_f_bytes, st)
-        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr, self.thr_lo, self.thr_hi,
+        ev = A.record_event(stream) if hasattr(A, "record_event") else None
+        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr or A.ptr(self.identity), self.thr_lo, self.thr_hi,
                self.is3d, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, st)
         L.call("rd_dets12_to_8", A.ptr(self.out), self.cap, A.ptr(self.nkeep), A.ptr(self.out8), st)
+        return ev
 
     def collect(self):
         A = self.A
@@ -71,6 +79,8 @@ class RangeDetPipeline:
         cname = General.class_names[0]
         self.k = pre_nms_top_n
         self.batch = batch
+        self._post_stream = None
+        self._filter_done = None
         self.post = [PostProcessor(self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
                                    TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap) for _ in range(batch)]
 
@@ -79,11 +89,23 @@ class RangeDetPipeline:
         return self.exe.forward(inputs)
 
     def enqueue(self, inputs):
+        """forward on the current stream; score filter + WNMS + 12->8 on a side stream so that the (latency-bound,
+        one-CU) greedy scan of frame i overlaps the convolutions of frame i+1."""
+        A = self.alloc
+        side = hasattr(A, "new_stream")
+        if side and self._post_stream is None:
+            self._post_stream = A.new_stream()
+        if side and self._filter_done is not None:
+            A.wait_event(self._filter_done)          # previous frame's filter has consumed the score / box buffers
         outs = self.exe.forward(inputs)
         sc, bx = outs[1], outs[2]
+        if side:
+            A.wait_event(A.record_event(), self._post_stream)
         for b in range(self.batch):
-            self.post[b].enqueue(self.alloc.ptr(sc[b]) if hasattr(sc[b], "data_ptr") else sc[b].ctypes.data,
-                                 self.alloc.ptr(bx[b]) if hasattr(bx[b], "data_ptr") else bx[b].ctypes.data)
+            ev = self.post[b].enqueue(self.alloc.ptr(sc[b]) if hasattr(sc[b], "data_ptr") else sc[b].ctypes.data,
+                                      self.alloc.ptr(bx[b]) if hasattr(bx[b], "data_ptr") else bx[b].ctypes.data,
+                                      stream=self._post_stream)
+        self._filter_done = ev if side else None
         return outs
 
     def run(self, inputs):

@@ -61,6 +61,21 @@ class TorchAllocator:
     def assign(self, dst_view, src):
         dst_view.copy_(src.reshape(dst_view.shape))
 
+    # ---- streams / events (the post-processing of frame i overlaps the forward of frame i+1) ----------------
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def stream_ptr(self, stream):
+        return stream.cuda_stream if stream is not None else self.stream
+
+    def record_event(self, stream=None):
+        ev = self.torch.cuda.Event()
+        ev.record(stream if stream is not None else self.torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait_event(self, ev, stream=None):
+        (stream if stream is not None else self.torch.cuda.current_stream(self.device)).wait_event(ev)
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
