@@ -3,7 +3,9 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one full pass of the hot path over one synthetic 64x2650(pad 2656)x8 range image per rank:
+One "step" = one full pass of the hot path over one batch (--batch, default 8) of synthetic 64x2650(pad 2656)x8 range
+images per rank (BASELINE config 4 runs 64 frames over 8 GPUs = 8 per GPU; frames are independent, batching only fills
+the low-resolution layers' grids):
 DLA backbone + fused Meta-Kernel + 3-level heads + sigmoid/top-50000/sort + 3D box decode + score filter + weighted NMS
 (config `rangedet_veh_wo_aug_4_18e`, bf16 activations/weights with fp32 accumulation; BASELINE configs[1] plus the WNMS
 of configs[2]).  Inputs are resident in HBM before the timed region.  Frames shard across ranks with no data-path
@@ -61,7 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--frames", type=int, default=2, help="distinct synthetic batches cycled through")
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -82,12 +85,14 @@ def main():
     dt = rdlib.RD_BF16 if args.dtype == "bf16" else rdlib.RD_F32
 
     params = synth.make_weights(seed=18)
-    pipe = RangeDetPipeline(params, dtype=dt, wnms_cap=4096)
+    Bf = args.batch
+    pipe = RangeDetPipeline(params, dtype=dt, wnms_cap=4096, batch=Bf)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
-    frames_np = [synth.make_frame(rank + world * i) for i in range(args.frames)]
+    frames_np = [synth.make_batch([(rank + world * (i * Bf + j)) for j in range(Bf)]) for i in range(args.frames)]
     frames = [{k: torch.from_numpy(v).to(dev) for k, v in f.items()} for f in frames_np]
     L = pipe.lib
-    gather_in = torch.zeros(MAX_DET * 12 + 1, device=dev)
+    REC = MAX_DET * 12 + 1
+    gather_in = torch.zeros(Bf * REC, device=dev)
     gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
     post = pipe.post[0]
     A = pipe.alloc
@@ -95,10 +100,11 @@ def main():
     def step(i):
         pipe.enqueue(frames[i % len(frames)])
         if world > 1:
-            rows = A.view_f32(post.out, (post.cap, 12))[:MAX_DET].reshape(-1)
-            gather_in[:-1].copy_(rows)
-            gather_in[-1:].copy_(A.view_i32(post.nkeep, (1,)).float())
-            dist.all_gather(gather_out, gather_in)
+            torch.cuda.current_stream().wait_stream(pipe._post_stream)   # the padded detections of this batch are final
+            for b, pp in enumerate(pipe.post):
+                gather_in[b * REC:(b + 1) * REC - 1].copy_(A.view_f32(pp.out, (pp.cap, 12))[:MAX_DET].reshape(-1))
+                gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(A.view_i32(pp.nkeep, (1,)).float())
+            dist.all_gather(gather_out, gather_in)                         # the ONE collective of the path
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -134,35 +140,36 @@ def main():
         fl, nlaunch = conv_flops(pipe.plan)
         ms, cnt = prof["conv"]
         avg_ms = ms / max(cnt, 1)
-        achieved = (fl / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0
+        achieved = (fl * Bf / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0   # a launch covers the Bf frames of the batch
         roof = {"kernel": "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3, "unit": "TFLOP/s",
                 "frac": achieved / (PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3), "traffic": None,
-                "launches_per_frame": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_frame": fl / 1e9}
+                "launches_per_step": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_launch": fl * Bf / nlaunch / 1e9,
+                "gflop_per_frame": fl / 1e9}
         mms, mcnt = prof["meta"]
         esz = 2 if dt == rdlib.RD_BF16 else 4
-        mbytes = 64 * 2656 * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)
+        mbytes = Bf * 64 * 2656 * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)
         meta_info = {"kernel": "meta_kernel (fused Meta-Kernel unit)", "bound": "hbm",
                      "achieved": mbytes / (mms / max(mcnt, 1) * 1e-3) / 1e9 if mcnt else 0.0, "peak": PEAK_HBM_GBPS,
                      "unit": "GB/s", "avg_launch_ms": mms / max(mcnt, 1), "bytes_per_launch": mbytes,
-                     "tflops": 19.29e9 / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
+                     "tflops": Bf * 19.29e9 / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
         meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
 
     if rank == 0:
         out = {
             "metric": "range-image frames/sec (64x2650, 8ch) at 1/2/4/8 GPU; Meta-Kernel HBM GB/s vs peak",
-            "value": args.steps * world / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * world * Bf / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "rangedet_veh_wo_aug_4_18e: DLA backbone + Meta-Kernel + heads + top-50000 + 3D decode "
-                                   "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, 1 frame per step per GPU, "
-                                   "random-init weights (seed 18)", "frames_per_step": world, "parallelism": "frame-parallel dp%d" % world,
+                                   "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, %d frames per step per GPU, " % Bf + ""
+                                   "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "parallelism": "frame-parallel dp%d" % world,
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"]))},
             "roofline": roof, "meta_kernel": meta_info,
-            "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) for k, v in prof.items()},
+            "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) / Bf for k, v in prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params, frames_np[0])
+            out["cpu_baseline"] = cpu_baseline(params, {k: v[:1] for k, v in frames_np[0].items()})
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

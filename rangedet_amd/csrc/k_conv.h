@@ -180,7 +180,11 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
     // slab `step` must have landed: at most the younger fills (steps step+1 .. step+D-1) may still be in flight
     {
       const int younger = min(D - 1, nsteps - 1 - step);
-      if (younger >= 3) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(3 * IPW));
+      if (younger >= 7) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(7 * IPW));
+      else if (younger == 6) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(6 * IPW));
+      else if (younger == 5) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(5 * IPW));
+      else if (younger == 4) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(4 * IPW));
+      else if (younger == 3) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(3 * IPW));
       else if (younger == 2) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(2 * IPW));
       else if (younger == 1) __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(1 * IPW));
       else __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
@@ -390,7 +394,11 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   a.RI = RO + (mxdh - mndh);
   a.CI = 63 * in_stride + mxw + 1;
   const size_t halo = (size_t)a.RI * a.CI * 128;
-  const int ring = RO == 8 ? 4 : 3;
+  const int nblocks = ((Wq + 63) / 64) * ((H + RO - 1) / RO) * (cout / 64);
+  // few workgroups (low-resolution layers): at most one per CU anyway, so spend the idle LDS on a deeper weight ring --
+  // such layers are a pure latency chain of (k-chunk, tap) steps and run at ring depth / L2 latency.
+  const bool deep = RO == 4 && nblocks * B <= 320 && halo + 8 * 64 * 128 + 512 <= 160 * 1024;
+  const int ring = RO == 8 ? 4 : (deep ? 8 : 3);
   const size_t lds = halo + (size_t)ring * 64 * 128 + 64 * 8;
   RD_REQUIRE(lds <= 160 * 1024, RD_ESHAPE, "conv: LDS tile %zu B too large", lds);
   a.ncol = (Wq + 63) / 64;
@@ -398,7 +406,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   dim3 grid(a.ncol * ((H + RO - 1) / RO) * (cout / 64), 1, B);
   ProfScope ps(RD_PROF_CONV, st);
 #define RD_LAUNCH_CONV(DT_)                                                                            \
-  if (RO == 4) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);         \
+  if (RO == 4 && deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);  \
+  else if (RO == 4) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);    \
   else hipLaunchKernelGGL((conv_taps_kernel<DT_, 8, 4>), grid, dim3(512), lds, st, a);
   if (dt == RD_BF16) { RD_LAUNCH_CONV(RD_BF16) } else { RD_LAUNCH_CONV(RD_F32) }
 #undef RD_LAUNCH_CONV
