@@ -114,6 +114,7 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
                        void* stream);
 
 /* ---- post-processing -------------------------------------------------------------------------------- */
+/* bytes for ONE batch element; pass B times that to let the B independent sorts run side by side */
 size_t rd_sorted_foreground_workspace_bytes(long N, long k);
 /* cls_score (B,N) [logits when apply_sigmoid != 0], bbox_delta (B,N,D), pc (B,N,3), mask (B,N) ->
  * sorted_fg_score (B,k), sorted_fg_bbox_delta (B,k,D), sorted_fg_pc (B,k,3); optional sorted_idx (B,k) int32.

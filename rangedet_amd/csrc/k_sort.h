@@ -23,14 +23,15 @@ __device__ __forceinline__ float key_to_float(unsigned key) {
 
 __global__ __launch_bounds__(256) void sort_keygen_kernel(const float* __restrict__ score, const float* __restrict__ mask,
                                                           long N, int apply_sigmoid, unsigned* __restrict__ keys,
-                                                          unsigned* __restrict__ idx) {
+                                                          unsigned* __restrict__ idx, long ws_stride) {
   long i = blockIdx.x * 256L + threadIdx.x;
   if (i >= N) return;
-  float s = score[i];
+  const long b = blockIdx.y;                       // batch element: independent sort problems run side by side
+  float s = score[b * N + i];
   if (apply_sigmoid) s = 1.0f / (1.0f + expf(-s));
-  if (mask) s = s * mask[i];
-  keys[i] = desc_key(s);
-  idx[i] = (unsigned)i;
+  if (mask) s = s * mask[b * N + i];
+  keys[b * ws_stride + i] = desc_key(s);
+  idx[b * ws_stride + i] = (unsigned)i;
 }
 // keys for the weighted-NMS ordering: rows >= *d_count sort last
 __global__ __launch_bounds__(256) void sort_keygen_dets_kernel(const float* __restrict__ dets, int cap,
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(256) void sort_keygen_dets_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned* __restrict__ keys, long N, int shift,
-                                                        unsigned* __restrict__ hist, unsigned* __restrict__ tot) {
+                                                        unsigned* __restrict__ hist, unsigned* __restrict__ tot,
+                                                        long ws_stride) {
+  keys += blockIdx.y * ws_stride;
+  hist += blockIdx.y * ws_stride;
+  tot += blockIdx.y * ws_stride;
   __shared__ unsigned h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -63,7 +68,12 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned* __res
                                                            const unsigned* __restrict__ idx_in, long N, int shift,
                                                            const unsigned* __restrict__ hist,
                                                            const unsigned* __restrict__ tot,
-                                                           unsigned* __restrict__ keys_out, unsigned* __restrict__ idx_out) {
+                                                           unsigned* __restrict__ keys_out, unsigned* __restrict__ idx_out,
+                                                           long ws_stride) {
+  {
+    const long o = blockIdx.y * ws_stride;
+    keys_in += o; idx_in += o; hist += o; tot += o; keys_out += o; idx_out += o;
+  }
   __shared__ unsigned wcnt[4][256];
   __shared__ unsigned gbase[256];
   __shared__ unsigned scan[256];
@@ -134,9 +144,16 @@ __global__ __launch_bounds__(256) void sort_gather_kernel(const unsigned* __rest
                                                           long k, int D, const float* __restrict__ delta,
                                                           const float* __restrict__ pc, float* __restrict__ out_score,
                                                           float* __restrict__ out_delta, float* __restrict__ out_pc,
-                                                          int* __restrict__ out_idx) {
+                                                          int* __restrict__ out_idx, long ws_stride, long N) {
   long i = blockIdx.x * 256L + threadIdx.x;
   if (i >= k) return;
+  {
+    const long b = blockIdx.y;
+    keys += b * ws_stride; idx += b * ws_stride;
+    delta += b * N * D; pc += b * N * 3;
+    out_score += b * k; out_delta += b * k * D; out_pc += b * k * 3;
+    if (out_idx) out_idx += b * k;
+  }
   unsigned j = idx[i];
   out_score[i] = key_to_float(keys[i]);
   for (int c = 0; c < D; ++c) out_delta[i * D + c] = delta[(size_t)j * D + c];
@@ -168,13 +185,16 @@ inline SortWs sort_ws_carve(void* ws, long N) {
   return s;
 }
 // sorts (keysA, idxA) ascending by key, stable; result back in keysA/idxA (4 passes)
-inline int radix_sort_pairs(const SortWs& s, long N, hipStream_t st) {
-  if (hipMemsetAsync(s.tot, 0, 4 * 256 * 4, st) != hipSuccess) return fail(RD_EHIP, "sort: memset");
+// nb independent problems laid out ws_stride (in 4-byte words) apart in the workspace run as blockIdx.y
+inline int radix_sort_pairs(const SortWs& s, long N, hipStream_t st, int nb = 1, long ws_stride = 0) {
+  for (int b = 0; b < nb; ++b)
+    if (hipMemsetAsync(s.tot + b * ws_stride, 0, 4 * 256 * 4, st) != hipSuccess) return fail(RD_EHIP, "sort: memset");
   unsigned *ki = s.keysA, *ko = s.keysB, *ii = s.idxA, *io = s.idxB;
   for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(s.nblk), dim3(256), 0, st, ki, N, pass * 8, s.hist, s.tot + pass * 256);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(s.nblk), dim3(256), 0, st, ki, ii, N, pass * 8, s.hist,
-                       s.tot + pass * 256, ko, io);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(s.nblk, nb), dim3(256), 0, st, ki, N, pass * 8, s.hist, s.tot + pass * 256,
+                       ws_stride);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(s.nblk, nb), dim3(256), 0, st, ki, ii, N, pass * 8, s.hist,
+                       s.tot + pass * 256, ko, io, ws_stride);
     std::swap(ki, ko);
     std::swap(ii, io);
   }

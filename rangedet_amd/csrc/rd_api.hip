@@ -211,7 +211,7 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
 }
 
 // ---- post-processing -------------------------------------------------------------------------------------------
-size_t rd_sorted_foreground_workspace_bytes(long N, long k) { (void)k; return sort_ws_bytes(N) + 256; }
+size_t rd_sorted_foreground_workspace_bytes(long N, long k) { (void)k; return (sort_ws_bytes(N) + 256 + 255) & ~(size_t)255; }
 int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const float* pc, const float* mask, int B,
                          long N, long k, int D, int apply_sigmoid, float* out_score, float* out_delta, float* out_pc,
                          int* out_idx, void* ws, size_t ws_bytes, void* stream) {
@@ -225,14 +225,21 @@ int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const 
   void* wsa = (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   SortWs s = sort_ws_carve(wsa, N);
   ProfScope ps(RD_PROF_SORT, st);
-  for (int b = 0; b < B; ++b) {
-    hipLaunchKernelGGL(sort_keygen_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, cls_score + (size_t)b * N,
-                       mask ? mask + (size_t)b * N : nullptr, N, apply_sigmoid, s.keysA, s.idxA);
-    int rc = radix_sort_pairs(s, N, st);
+  // the B batch elements are independent sorts: side by side (blockIdx.y) when the workspace holds B problems,
+  // otherwise one after the other in a single-problem workspace
+  const size_t per = rd_sorted_foreground_workspace_bytes(N, k);
+  const bool wide = ws_bytes >= per * (size_t)B;
+  const long stride = wide ? (long)(per / 4) : 0;
+  const int nb = wide ? B : 1;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    hipLaunchKernelGGL(sort_keygen_kernel, dim3((unsigned)((N + 255) / 256), nb), dim3(256), 0, st, cls_score + (size_t)b0 * N,
+                       mask ? mask + (size_t)b0 * N : nullptr, N, apply_sigmoid, s.keysA, s.idxA, stride);
+    int rc = radix_sort_pairs(s, N, st, nb, stride);
     if (rc != RD_OK) return rc;
-    hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, s.keysA, s.idxA, k, D,
-                       bbox_delta + (size_t)b * N * D, pc + (size_t)b * N * 3, out_score + (size_t)b * k,
-                       out_delta + (size_t)b * k * D, out_pc + (size_t)b * k * 3, out_idx ? out_idx + (size_t)b * k : nullptr);
+    hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((k + 255) / 256), nb), dim3(256), 0, st, s.keysA, s.idxA, k, D,
+                       bbox_delta + (size_t)b0 * N * D, pc + (size_t)b0 * N * 3, out_score + (size_t)b0 * k,
+                       out_delta + (size_t)b0 * k * D, out_pc + (size_t)b0 * k * 3, out_idx ? out_idx + (size_t)b0 * k : nullptr,
+                       stride, N);
   }
   return check_launch("sorted_foreground");
 }

@@ -160,7 +160,7 @@ class Executor:
             b["w"] = A.upload(w)
             b["bias"] = A.upload(np.asarray(P[st["name"] + "_bias"], np.float32)[r0:r1])
         elif k == "sorted_fg":
-            nb = L.raw("rd_sorted_foreground_workspace_bytes")(st["N"], st["k"])
+            nb = L.raw("rd_sorted_foreground_workspace_bytes")(st["N"], st["k"]) * self.B
             b["ws"] = A.alloc(nb)
             b["ws_bytes"] = nb
         return b

@@ -170,16 +170,18 @@ def test_sorted_foreground(be):
     pc = rng.standard_normal((B, N, 3)).astype(np.float32)
     score = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
     L = be.lib
-    nb = L.raw("rd_sorted_foreground_workspace_bytes")(N, k)
-    ws = be.empty(nb)
-    o_s, o_d, o_p, o_i = be.empty(B * k * 4), be.empty(B * k * D * 4), be.empty(B * k * 12), be.empty(B * k * 4)
-    L.call("rd_sorted_foreground", be.ptr(be.up(score)), be.ptr(be.up(delta)), be.ptr(be.up(pc)), be.ptr(be.up(mask)), B, N, k,
-           D, 0, be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), be.ptr(o_i), be.ptr(ws), nb, be.stream)
     rs, rd, rp, ri = O.get_sorted_foreground(score, delta, pc, mask, k)
-    assert np.array_equal(be.down(o_i, np.int32, (B, k)), ri)           # bit-exact index work, incl. tie rule
-    assert np.array_equal(be.down(o_s, np.float32, (B, k)), rs)
-    assert np.array_equal(be.down(o_d, np.float32, (B, k, D)), rd)
-    assert np.array_equal(be.down(o_p, np.float32, (B, k, 3)), rp)
+    # workspace for one problem (batch elements sorted one after the other) and for B (sorted side by side)
+    for mult in (1, B):
+        nb = L.raw("rd_sorted_foreground_workspace_bytes")(N, k) * mult
+        ws = be.empty(nb)
+        o_s, o_d, o_p, o_i = be.empty(B * k * 4), be.empty(B * k * D * 4), be.empty(B * k * 12), be.empty(B * k * 4)
+        L.call("rd_sorted_foreground", be.ptr(be.up(score)), be.ptr(be.up(delta)), be.ptr(be.up(pc)), be.ptr(be.up(mask)), B, N,
+               k, D, 0, be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), be.ptr(o_i), be.ptr(ws), nb, be.stream)
+        assert np.array_equal(be.down(o_i, np.int32, (B, k)), ri)           # bit-exact index work, incl. tie rule
+        assert np.array_equal(be.down(o_s, np.float32, (B, k)), rs)
+        assert np.array_equal(be.down(o_d, np.float32, (B, k, D)), rd)
+        assert np.array_equal(be.down(o_p, np.float32, (B, k, 3)), rp)
     # N < k mirrors the reference's assert (get_sorted_foreground.py:65)
     with pytest.raises(R.RangeDetError) as e:
         L.call("rd_sorted_foreground", be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), None, 1, 10, 20, D, 0, be.ptr(o_s), be.ptr(o_d),
