@@ -42,6 +42,32 @@ def conv_flops(plan):
     return fl, n
 
 
+def conv_bytes(plan, esz):
+    """Algorithmic HBM bytes of the conv-family launches of one frame: every layer reads its input once, writes its
+    output once, reads its residual once (BN/ReLU/add fused), weights once (SURVEY.md section 8d bytes model)."""
+    by = 0.0
+    for s in plan.steps:
+        if s["kind"] in ("conv", "deconv"):
+            x, o = s["x"], s["out"]
+            by += (x.H * x.W * s["cin"] + o.H * o.W * s["cout"]) * esz
+            if s.get("res") is not None:
+                by += o.H * o.W * s["cout"] * esz
+            by += s["cin"] * s["cout"] * s["k"][0] * s["k"][1] * esz
+    return by
+
+
+def measured_traffic(kernel_key, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("batch") == batch:
+            return d[kernel_key]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(params, frame, budget_frames=1):
     """The oracle (PyTorch-CPU fp32 restatement + C++ decode/wnms) timed on this box's host cores: reported, not a target."""
     import torch
@@ -143,7 +169,11 @@ def main():
         achieved = (fl * Bf / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0   # a launch covers the Bf frames of the batch
         roof = {"kernel": "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3, "unit": "TFLOP/s",
-                "frac": achieved / (PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3), "traffic": None,
+                "frac": achieved / (PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3),
+                "traffic": measured_traffic("conv_taps_kernel", Bf) if dt == rdlib.RD_BF16 else None,
+                "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes of "
+                                "this command (profiles/r01_pmc_traffic.json)",
+                "algorithmic_bytes_per_launch": conv_bytes(pipe.plan, 2 if dt == rdlib.RD_BF16 else 4) * Bf / nlaunch,
                 "launches_per_step": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_launch": fl * Bf / nlaunch / 1e9,
                 "gflop_per_frame": fl / 1e9}
         mms, mcnt = prof["meta"]
@@ -154,6 +184,7 @@ def main():
                      "unit": "GB/s", "avg_launch_ms": mms / max(mcnt, 1), "bytes_per_launch": mbytes,
                      "tflops": Bf * 19.29e9 / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
         meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
+        meta_info["traffic"] = measured_traffic("meta_kernel", Bf) if dt == rdlib.RD_BF16 else None
 
     if rank == 0:
         out = {

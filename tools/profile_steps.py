@@ -12,8 +12,9 @@ from rangedet_amd.pipeline import RangeDetPipeline  # noqa: E402
 
 dt = rdlib.RD_F32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else rdlib.RD_BF16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=dt)
-fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_frame(0).items()}
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=dt, batch=B)
+fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(B))).items()}
 pipe.enqueue(fr)
 torch.cuda.synchronize()
 ex = pipe.exe
@@ -36,10 +37,10 @@ for i, st in enumerate(pipe.plan.steps):
     desc = ""
     if k in ("conv", "deconv"):
         o = st["out"]
-        fl = 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
+        fl = B * 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
         desc = "%s %d->%d k%s W%d->%d s%d" % (st["name"], st["cin"], st["cout"], st["k"], st["x"].W, o.W, st["stride_w"])
     elif k == "meta":
-        fl = 19.29e9
+        fl = B * 19.29e9
         desc = "meta unit"
     else:
         desc = st.get("name", "")
