@@ -36,6 +36,7 @@ struct ConvArgs {
   unsigned long long dh_pack, dw_pack;  // 4 bits per tap, biased by 8 (no dynamically indexed kernarg arrays)
   int ncol;  // column tiles (64 output positions each)
   unsigned ci_magic;  // floor(2^32 / CI) + 1: px / CI == umulhi(px, ci_magic) for the px range of a halo tile
+  unsigned long long* trace;  // dev tracing (tools/conv_trace.py): 8 timestamps per workgroup, or null
   int dbg;  // tuning ablations (tools/conv_bench.py): 1 no epilogue stores, 2 one weight slab only, 4 one halo stage, 8 no MFMA
 };
 
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   const int ct = (widx / nhalf) % a.ncol;
   const int q0 = ct * 64, h0 = (widx / (nhalf * a.ncol)) * RO, b = blockIdx.z;
   const int m = lane & 31, hi = lane >> 5;
+  int tpt = 0;
+#define RD_TRACE() { if (a.trace && tid == 0 && tpt < 8) a.trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + tpt++] = wall_clock64(); }
+  RD_TRACE()
 
   unsigned char* As = smem;
   unsigned char* Ws = smem + a.RI * a.CI * 128;            // RING slabs
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
 #pragma unroll
   for (int s0 = 0; s0 < D; ++s0)
     if (s0 < nsteps) w_fill(s0);
+  RD_TRACE()
 
   // Loop nest: k-chunks outside (halo restage = ordinary loads), taps inside (LDS-DMA only).  Keeping the ordinary
   // loads out of the tap loop matters: hipcc's waitcnt pass otherwise carries "maybe pending load" state of the halo
@@ -173,8 +178,10 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   int step = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     if (chunk > 0 && !(a.dbg & 4)) {
+      RD_TRACE()
       RD_LDS_BARRIER();  // every wave is done with the previous chunk's halo tile
       a_stage(chunk);
+      RD_TRACE()
     }
    for (int tap = 0; tap < a.ntaps; ++tap, ++step) {
     // slab `step` must have landed: at most the younger fills (steps step+1 .. step+D-1) may still be in flight
@@ -239,12 +246,13 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
    }
   }
 #undef RD_LDS_BARRIER
+  RD_TRACE()
 
   // ---- epilogue: BN affine, ReLU / residual, store.  The MFMAs are issued "transposed" (A operand = weights,
   // B operand = pixels) and the weight rows are permuted in LDS, so lane (px, hi) holds output channels
   // 64*wc + 32*nt + 16*hi + r (r = 0..15) of its pixel: 16 contiguous channels -> 16-byte residual loads and stores.
   const int oh = h0 + wm;
-  if (oh >= a.H) return;
+  if (oh >= a.H) { RD_TRACE() return; }
   T* __restrict__ y = (T*)a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wout * a.y_cs + a.y_co + chalf * 64;
   const T* __restrict__ res = (const T*)a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wout * a.r_cs + a.r_co + chalf * 64;
   const bool relu_pre = a.flags & RD_RELU_PRE, do_add = a.flags & RD_ADD, relu_post = a.flags & RD_RELU_POST;
@@ -294,6 +302,8 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
       }
     }
   }
+  RD_TRACE()
+#undef RD_TRACE
 }
 
 // ---- host side: tap lists, packing, launch -------------------------------------------------------------
@@ -353,6 +363,10 @@ inline void pack_taps(int ntaps, int cin, int cout, int dt, void* out, F get) {
         }
 }
 
+inline bool conv_use_wreg() { static const bool v = getenv("RD_CONV_V2") != nullptr; return v; }
+unsigned long long* conv_trace_buf();
+int launch_conv_wreg(ConvArgs& a, int B, int H, int Wq, int mxdh, int mxdw, hipStream_t st);  // k_conv2.h (bf16)
+
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,
                        int B, int H, int Win, int Wq, int Wout, int cin, int cout, int in_stride,
@@ -384,6 +398,10 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndh = std::min(mndh, tl.dh[t]); mxdh = std::max(mxdh, tl.dh[t]);
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
+  if (dt == RD_BF16 && conv_use_wreg()) {  // experimental bf16 kernel with a register-resident weight stream (k_conv2.h)
+    a.min_dh = mndh; a.min_dw = mndw;
+    return launch_conv_wreg(a, B, H, Wq, mxdh, mxdw, st);
+  }
   // Workgroup = NW rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile).
   // cout 128: 8 waves, one WG per CU, 4-deep weight ring -- unless the halo is too big (stride 2: 129 columns);
   // otherwise 4 waves, 3-deep ring (two WGs per CU when the halo allows).
@@ -404,6 +422,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   a.ncol = (Wq + 63) / 64;
   a.ci_magic = (unsigned)((1ull << 32) / (unsigned)a.CI) + 1u;
   dim3 grid(a.ncol * ((H + RO - 1) / RO) * (cout / 64), 1, B);
+  if (conv_trace_buf() && (size_t)grid.x * B * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV, st);
 #define RD_LAUNCH_CONV(DT_)                                                                            \
   if (RO == 4 && deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);  \

@@ -1,6 +1,6 @@
 // librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
-#include "k_conv.h"
+#include "k_conv2.h"
 #include "k_meta.h"
 #include "k_misc.h"
 #include "k_riou.h"
@@ -38,10 +38,12 @@ inline void allow_big_lds(K kernel) {
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 inline void allow_conv_lds() {
+  allow_big_lds(conv_wreg_kernel<2, 2>);
+  allow_big_lds(conv_wreg_kernel<2, 1>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 8, 4>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_F32, 8, 4>);
 }
@@ -95,9 +97,9 @@ int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, 
   RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_conv: dtype");
   RD_REQUIRE(kh * kw >= 1 && kh * kw <= 9 && (kh & 1) && (kw & 1), RD_ESHAPE, "pack_conv: kernel (%d,%d)", kh, kw);
   TapList tl = conv_taps(kh, kw);
-  pack_taps(tl.n, cin, cout, dtype, out, [&](int co, int ci, int t) {
-    return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]];
-  });
+  auto get = [&](int co, int ci, int t) { return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
+  if (dtype == RD_BF16 && conv_use_wreg()) pack_taps_wreg(tl.n, cin, cout, out, get);
+  else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }
 int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase) {
@@ -112,9 +114,9 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
   RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
-  pack_taps(tl.n, cin, cout, dtype, out, [&](int co, int ci, int t) {
-    return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
-  });
+  auto get = [&](int co, int ci, int t) { return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
+  if (dtype == RD_BF16 && conv_use_wreg()) pack_taps_wreg(tl.n, cin, cout, out, get);
+  else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }
 
@@ -338,6 +340,11 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
 }
 
 // ---- profiling -------------------------------------------------------------------------------------------------
+// dev only (not part of include/rangedet_hip.h): copy the conv phase trace of the last traced launch to the host
+int rd_dev_conv_trace_read(unsigned long long* out, long n) {
+  if (!conv_trace_buf() || n > (long)CONV_TRACE_CAP) return RD_EINVAL;
+  return hipMemcpy(out, conv_trace_buf(), n * 8, hipMemcpyDeviceToHost) == hipSuccess ? RD_OK : RD_EHIP;
+}
 int rd_prof_enable(int on) {
   Prof& p = prof();
   std::lock_guard<std::mutex> g(p.mu);

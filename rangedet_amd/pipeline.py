@@ -40,17 +40,27 @@ class PostProcessor:
         # filter is a stable compaction, so the processing order is the identity and the device re-sort is skipped
         self.identity = A.upload(np.arange(self.cap, dtype=np.int32))
 
-    def enqueue(self, score_ptr, box_ptr, order_ptr=None, stream=None):
-        """Enqueue on `stream` (a side stream from alloc.new_stream(), or None = the current stream).  Returns the event
-        recorded right after the score filter, i.e. the point from which the score / box buffers may be overwritten."""
+    def enqueue_filter(self, score_ptr, box_ptr, stream=None):
+        """Score filter + 10->11 dim conversion only: after this the score / box buffers may be overwritten."""
         L, A = self.L, self.A
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
         L.call("rd_score_filter_dets", score_ptr, box_ptr, self.k, self.min_score, A.ptr(self.dets), A.ptr(self.count),
                A.ptr(self.ws_f), self.ws_f_bytes, st)
-        ev = A.record_event(stream) if hasattr(A, "record_event") else None
+
+    def enqueue_nms(self, order_ptr=None, stream=None):
+        L, A = self.L, self.A
+        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
         L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr or A.ptr(self.identity), self.thr_lo, self.thr_hi,
                self.is3d, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, st)
         L.call("rd_dets12_to_8", A.ptr(self.out), self.cap, A.ptr(self.nkeep), A.ptr(self.out8), st)
+
+    def enqueue(self, score_ptr, box_ptr, order_ptr=None, stream=None):
+        """Enqueue on `stream` (a side stream from alloc.new_stream(), or None = the current stream).  Returns the event
+        recorded right after the score filter, i.e. the point from which the score / box buffers may be overwritten."""
+        A = self.A
+        self.enqueue_filter(score_ptr, box_ptr, stream)
+        ev = A.record_event(stream) if hasattr(A, "record_event") else None
+        self.enqueue_nms(order_ptr, stream)
         return ev
 
     def collect(self):
@@ -101,11 +111,14 @@ class RangeDetPipeline:
         sc, bx = outs[1], outs[2]
         if side:
             A.wait_event(A.record_event(), self._post_stream)
+        # all score filters first: they are what reads the graph's score / box buffers, so the next batch's forward only
+        # has to wait for these few short kernels, not for the weighted NMS of the frames queued before them
+        ptr = lambda t: self.alloc.ptr(t) if hasattr(t, "data_ptr") else t.ctypes.data
         for b in range(self.batch):
-            ev = self.post[b].enqueue(self.alloc.ptr(sc[b]) if hasattr(sc[b], "data_ptr") else sc[b].ctypes.data,
-                                      self.alloc.ptr(bx[b]) if hasattr(bx[b], "data_ptr") else bx[b].ctypes.data,
-                                      stream=self._post_stream)
-        self._filter_done = ev if side else None
+            self.post[b].enqueue_filter(ptr(sc[b]), ptr(bx[b]), stream=self._post_stream)
+        self._filter_done = A.record_event(self._post_stream) if side else None
+        for b in range(self.batch):
+            self.post[b].enqueue_nms(stream=self._post_stream)
         return outs
 
     def run(self, inputs):
