@@ -40,6 +40,9 @@ struct ConvArgs {
   int dbg;  // tuning ablations (tools/conv_bench.py): 1 no epilogue stores, 2 one weight slab only, 4 one halo stage, 8 no MFMA
 };
 
+// weight row held by A-operand lane row mm, so that the D registers of a lane are 16 consecutive output channels
+__host__ __device__ inline int conv_row_perm(int mm) { return 16 * ((mm >> 2) & 1) + 4 * (mm >> 3) + (mm & 3); }
+
 // s_waitcnt immediate (gfx9 encoding) that waits for vmcnt <= n only (expcnt / lgkmcnt left at "no wait")
 #define RD_VMCNT_IMM(n) (((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
@@ -94,11 +97,24 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
     const int n = p >> 3, sp = p & 7;
     const int s = sp ^ ((n >> 1) & 7);
     const int mm = n & 31;
-    const int c = (n & ~31) | (16 * ((mm >> 2) & 1) + 4 * (mm >> 3) + (mm & 3));
-    goff[j] = (c * 8 + s) * 16;
+    if constexpr (DT == RD_BF16) {
+      // bf16 weights are packed in MFMA-fragment order (k_conv3.h pack_taps_frag): [32-ch chunk][tap][ks][Cout/32][lane]
+      const int ncb = a.cout >> 5, cb = chalf * 2 + (n >> 5);
+      goff[j] = (((s >> 2) * a.ntaps * 2 + ((s >> 1) & 1)) * ncb + cb) * 1024 + ((s & 1) * 32 + mm) * 16;
+    } else {
+      const int c = (n & ~31) | conv_row_perm(mm);
+      goff[j] = (c * 8 + s) * 16;
+    }
   }
+  int fch = 0, ftap = 0;                                   // (64-ch chunk, tap) of the next slab to fetch
   auto w_fill = [&](int step) {
-    const unsigned char* src = (const unsigned char*)a.w + ((size_t)step * nhalf + chalf) * SLAB;
+    const unsigned char* src;
+    if constexpr (DT == RD_BF16) {
+      src = (const unsigned char*)a.w + (size_t)((2 * fch * a.ntaps + ftap) * 2 * (a.cout >> 5)) * 1024;
+      if (++ftap == a.ntaps) { ftap = 0; ++fch; }
+    } else {
+      src = (const unsigned char*)a.w + ((size_t)step * nhalf + chalf) * SLAB;
+    }
     unsigned char* dst = Ws + (step % RING) * SLAB + wave * IPW * 1024;
 #pragma unroll
     for (int j = 0; j < IPW; ++j)
@@ -363,9 +379,26 @@ inline void pack_taps(int ntaps, int cin, int cout, int dt, void* out, F get) {
         }
 }
 
-inline bool conv_use_wreg() { static const bool v = getenv("RD_CONV_V2") != nullptr; return v; }
-unsigned long long* conv_trace_buf();
-int launch_conv_wreg(ConvArgs& a, int B, int H, int Wq, int mxdh, int mxdw, hipStream_t st);  // k_conv2.h (bf16)
+// dev tracing: RD_CONV_TRACE=1 allocates a device buffer the kernels stamp with s_memrealtime (100 MHz) per phase
+constexpr size_t CONV_TRACE_CAP = 1 << 20;
+inline unsigned long long* conv_trace_buf() {
+#ifdef HIPEMU
+  return nullptr;
+#else
+  static unsigned long long* buf = [] {
+    unsigned long long* p = nullptr;
+    if (getenv("RD_CONV_TRACE") && hipMalloc((void**)&p, CONV_TRACE_CAP * 8) == hipSuccess) (void)hipMemset(p, 0, CONV_TRACE_CAP * 8);
+    return p;
+  }();
+  return buf;
+#endif
+}
+
+// k_conv3.h: persistent 3x3 stride-1 bf16 kernel
+inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout);
+inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                        const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                        int cout, int flags, hipStream_t st);
 
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,
@@ -398,10 +431,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndh = std::min(mndh, tl.dh[t]); mxdh = std::max(mxdh, tl.dh[t]);
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
-  if (dt == RD_BF16 && conv_use_wreg()) {  // experimental bf16 kernel with a register-resident weight stream (k_conv2.h)
-    a.min_dh = mndh; a.min_dw = mndw;
-    return launch_conv_wreg(a, B, H, Wq, mxdh, mxdw, st);
-  }
+  if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
+    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, st);
   // Workgroup = NW rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile).
   // cout 128: 8 waves, one WG per CU, 4-deep weight ring -- unless the halo is too big (stride 2: 129 columns);
   // otherwise 4 waves, 3-deep ring (two WGs per CU when the halo allows).
@@ -422,7 +453,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   a.ncol = (Wq + 63) / 64;
   a.ci_magic = (unsigned)((1ull << 32) / (unsigned)a.CI) + 1u;
   dim3 grid(a.ncol * ((H + RO - 1) / RO) * (cout / 64), 1, B);
-  if (conv_trace_buf() && (size_t)grid.x * B * 8 <= (1u << 20)) a.trace = conv_trace_buf();
+  if (conv_trace_buf() && (size_t)grid.x * B * 8 <= CONV_TRACE_CAP) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV, st);
 #define RD_LAUNCH_CONV(DT_)                                                                            \
   if (RO == 4 && deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);  \

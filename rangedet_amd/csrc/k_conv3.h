@@ -1,0 +1,406 @@
+// 3x3 / stride-1 / pad-1 bf16 convolution as a persistent, fully asynchronous MFMA pipeline (the bulk of the
+// RangeDet FLOPs: backbone BasicBlocks dla_backbone.py:18-56 and the head towers head/builder.py:221-240).
+//
+// One workgroup (4 waves, one per SIMD, up to 512 registers each) per CU walks a list of output tiles of
+// 4 rows x 126 columns x all Cout.  Wave w owns output row w of the tile: 4 pixel fragments (32 px) x NCT channel
+// fragments (32 ch) = 4*NCT accumulators of 32x32 (cout 128: all 256 accumulation registers).
+//
+//   unit  = (tile, 32-channel k-chunk): one halo image 6 rows x 128 columns x 64 B = 48 KB in LDS, DOUBLE buffered:
+//           the halo of unit u+1 (possibly the next tile) is fetched by LDS-DMA while unit u is computed;
+//   step  = (unit, tap): one weight slab Cout x 32 ch = NCT*2 KB, kept in MFMA-fragment order (a linear copy of the
+//           packed global image) in an R-deep LDS ring filled by LDS-DMA R steps ahead;
+//   one workgroup barrier per step (= 2 k-steps x 4*NCT MFMAs per wave), placed between the two k-steps so that the
+//   LDS reads it retires were issued a whole MFMA block earlier.  Fragments for the next k-step are always read
+//   before the MFMA block of the current one (explicit register double buffer), because with one wave per SIMD
+//   nothing else hides LDS latency.
+//
+// All DMA traffic of a wave retires in order, so "my part of slab g+1 has landed" is a counted s_waitcnt vmcnt(N) with
+// N = DMA instructions issued after it -- a compile-time constant per tap because every step issues exactly IPW slab
+// instructions and every tap-0 step 12 halo instructions (dummy re-fetches keep that true at the end of the list).
+// LDS bytes per MFMA: (4 + NCT) KB / (4*NCT) = 0.5 KB (cout 128), 0.75 KB (cout 64) -- a quarter of ds_read_b128 peak.
+#pragma once
+#include "k_conv.h"
+
+namespace rd {
+
+struct Conv3Args {
+  const bf16_t* x; int x_cs, x_co; long x_bs;
+  const unsigned char* w;
+  const float* scale; const float* shift;
+  const bf16_t* res; int r_cs, r_co; long r_bs;
+  bf16_t* y; int y_cs, y_co; long y_bs;
+  const unsigned char* zero16;  // 16 zero bytes in device memory: DMA source of padding pixels / channels
+  int H, W, B, nslots, nchunk, flags, ncol, nrow, ntiles;
+  unsigned long long* trace;
+};
+
+constexpr int C3_TW = 126;                 // output columns per tile (halo = 128 columns exactly)
+constexpr int C3_HALO = 6 * 128 * 64;      // bytes of one halo image
+template <int NCT> struct C3Cfg {
+  static constexpr int R = NCT == 4 ? 7 : 10;  // ring depth (slabs)
+  static constexpr int IPW = NCT / 2;          // slab DMA instructions per wave per step
+  static constexpr int SLAB = NCT * 2048;
+  static constexpr size_t LDS = 2 * C3_HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
+};
+
+// packed bf16 conv-family weights: [32-ch chunk][tap][ks (2)][Cout/32][64 lanes][8 bf16], lane (mm, hi) of a fragment
+// holds W[co = 32*cb + conv_row_perm(mm)][ci = 32*chunk + 16*ks + 8*hi + j][tap].   get(co, ci, tap) -> float
+template <class F>
+inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
+  const int nchunk = (cin + 31) / 32, ncb = cout / 32;
+  bf16_t* o = (bf16_t*)out;
+  for (int c = 0; c < nchunk; ++c)
+    for (int t = 0; t < ntaps; ++t)
+      for (int ks = 0; ks < 2; ++ks)
+        for (int cb = 0; cb < ncb; ++cb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = cb * 32 + conv_row_perm(lane & 31);
+            for (int j = 0; j < 8; ++j) {
+              const int ci = c * 32 + ks * 16 + (lane >> 5) * 8 + j;
+              *o++ = f32_to_bf16(ci < cin ? get(co, ci, t) : 0.f);
+            }
+          }
+}
+
+// DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (tap T of its unit):
+// the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions and the
+// steps of taps 0..3 three halo pieces each.  At tap 7 the wait must also cover the last halo piece (issued at tap 3):
+// the following step reads the next unit's halo.
+constexpr int c3_halo_pieces(int tap) { return tap <= 3 ? 3 : 0; }
+constexpr int c3_younger(int R, int IPW, int T) {
+  int n = (R - 3) * IPW;
+  for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((T - d) % 9) + 9) % 9);
+  if (T == 7 && n > 3 * IPW) n = 3 * IPW;
+  return n;
+}
+// s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
+#define C3_WAIT_IMM(vm, lgkm) (((vm) & 15) | (((vm) >> 4) << 14) | (7 << 4) | ((lgkm) << 8))
+
+template <int NCT, int DBG = 0>
+__global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
+  using Cfg = C3Cfg<NCT>;
+  constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
+  constexpr int NR = 4 + NCT;                    // fragment reads per k-step
+  constexpr int NM = 4 * NCT;                    // MFMAs per k-step
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  constexpr int RING = 2 * C3_HALO;
+  float* Sc = (float*)(smem + RING + R * SLAB);
+  if (tid < COUT) {
+    Sc[tid] = a.scale ? a.scale[tid] : 1.f;
+    Sc[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
+  int tpt = 0;
+#define C3_TRACE() { if (a.trace && tid == 0 && tpt < 7) a.trace[(size_t)blockIdx.x * 8 + tpt++] = wall_clock64(); }
+  C3_TRACE()
+  const unsigned long long clk0 = __builtin_readcyclecounter();
+
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int ntl = (a.ntiles - wg + G - 1) / G;   // tiles of this workgroup: wg, wg + G, ...  (grid <= ntiles)
+  const int tiles_img = a.ncol * a.nrow;
+
+  // ---- DMA issue -----------------------------------------------------------------------------------------------
+  // halo image: linear 16-B slot P = 4*px + ps of the LDS image holds logical slot s = ps ^ ((px >> 2) & 3) of halo
+  // pixel px = 128*r + cc (conflict-free ds_read_b128 for any tap shift).  Wave w issues the 12
+  // 1-KB pieces q = 12*w .. 12*w+11: px = 16*q + (lane >> 2), so r = q >> 3 and cc = 16*(q & 7) + (lane >> 2).
+  const int hs = (lane & 3) ^ ((lane >> 4) & 3);          // logical slot this lane fetches (same for every piece)
+  int hk = 0, hc = 0;                                     // (tile ordinal, chunk) of the NEXT halo to fetch
+  int hh0 = 0, hw0 = 0;                                   // origin of the halo being fetched
+  const bf16_t* hxb = a.x;
+  bool hsok = false;
+  auto halo_begin = [&]() {                               // decode the unit to fetch, advance the cursor
+    const int t = wg + hk * G;
+    const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
+    hh0 = rb * 4 - 1; hw0 = ct * C3_TW - 1;
+    hxb = a.x + (size_t)b * a.x_bs + a.x_co + (hc * 4 + hs) * 8;
+    hsok = hc * 4 + hs < a.nslots;
+    // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
+    if (hc + 1 < a.nchunk) ++hc;
+    else if (hk + 1 < ntl) { ++hk; hc = 0; }
+  };
+  auto halo_piece = [&](int buf, int j) {
+    const int q = wave * 12 + j;
+    const int ih = hh0 + (q >> 3), iw = hw0 + (q & 7) * 16 + (lane >> 2);
+    const bool ok = hsok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+    const void* src = ok ? (const void*)(hxb + ((size_t)ih * a.W + iw) * a.x_cs) : (const void*)a.zero16;
+    lds_dma16(src, smem + buf * C3_HALO + q * 1024);
+  };
+  int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
+  const int nslab_tile = a.nchunk * 9;
+  const unsigned char* wsrc = a.w + wave * IPW * 1024 + lane * 16;
+  auto slab_piece = [&](int j) {
+    lds_dma16(wsrc + (size_t)fslab * SLAB + j * 1024, smem + RING + fslot * SLAB + (wave * IPW + j) * 1024);
+  };
+  auto slab_advance = [&]() {
+    fslot = fslot + 1 == R ? 0 : fslot + 1;
+    fslab = fslab + 1 == nslab_tile ? 0 : fslab + 1;
+  };
+
+  // ---- fragment addressing -------------------------------------------------------------------------------------
+  // pixel fragment i of tap (dh, dw): halo pixel (wave + 1 + dh, 1 + dw + 32*i + m); byte = px*64 + ((slot ^ (px>>2)) & 3)*16
+  // with slot = 2*ks + hi.  (px >> 2) & 3 only depends on (1 + dw + m), +32 px = +2048 B, ks toggles bit 5.
+  int aoff[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int c = d + m;                                  // 1 + dw + m with dw = d - 1
+    aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * 8192;
+  }
+  const int boff = RING + lane * 16;
+
+  f32x16 acc[4][NCT];
+  s16x8 fa[2][4], fb[2][NCT];
+#define C3_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // fragment read k of a k-step, in the order the MFMA sequence needs them: fa[0], fb[0..NCT-1], fa[1..3]
+#define C3_RD(BUF, K, AADDR, BADDR, KS)                                                                   \
+  {                                                                                                       \
+    if ((K) == 0) fa[BUF][0] = *(const s16x8*)(smem + (AADDR));                                            \
+    else if ((K) <= NCT) fb[BUF][(K) - 1] = *(const s16x8*)(smem + (BADDR) + ((KS) * NCT + (K) - 1) * 1024); \
+    else fa[BUF][(K) - NCT] = *(const s16x8*)(smem + (AADDR) + ((K) - NCT) * 2048);                        \
+    C3_FENCE();                                                                                           \
+  }
+  // MFMA n of a k-step: pixel fragment n / NCT against channel fragment n % NCT (transposed: weights are operand A)
+#define C3_MM(BUF, N)                                                                                     \
+  {                                                                                                       \
+    if (!(DBG & 8))                                                                                       \
+      acc[(N) / NCT][(N) % NCT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
+                                                                          acc[(N) / NCT][(N) % NCT], 0, 0, 0);    \
+    C3_FENCE();                                                                                           \
+  }
+  // workgroup barrier that retires the counted DMA and all LDS reads except the NR youngest (the fragments of the next
+  // step just requested), nothing else (see k_conv.h for why this is not __syncthreads())
+#define C3_SYNC(VMCNT, LGKM)                                      \
+  {                                                               \
+    asm volatile("" ::: "memory");                                \
+    __builtin_amdgcn_s_waitcnt(C3_WAIT_IMM(VMCNT, LGKM));         \
+    if (!(DBG & 2)) __builtin_amdgcn_s_barrier();                 \
+    asm volatile("" ::: "memory");                                \
+    C3_FENCE();                                                   \
+  }
+
+  // ---- prologue: first halo, a full ring ------------------------------------------------------------------------
+  halo_begin();
+#pragma unroll
+  for (int j = 0; j < 12; ++j) halo_piece(0, j);
+#pragma unroll 1
+  for (int s0 = 0; s0 < R; ++s0) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) slab_piece(j);
+    slab_advance();
+  }
+  C3_SYNC(0, 0)
+  C3_TRACE()
+  int rslot = 0;        // ring slot of the slab being consumed
+  int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
+#pragma unroll
+  for (int k = 0; k < NR; ++k) C3_RD(0, k, aoff[0] + abuf, boff + rslot * SLAB, 0)   // fragments of (unit 0, tap 0, ks 0)
+
+  // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
+  //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
+  //   block 1: MFMAs of ks 1, with the reads of (next step, ks 0) interleaved into its first half, then the step's
+  //            barrier (slab g+2 landed everywhere, slab g free), then the DMA issue interleaved into the second half.
+#define C3_STEP(T)                                                                                                   \
+  {                                                                                                                  \
+    constexpr int dh_ = (T) / 3, dw_ = (T) % 3;                                                                      \
+    constexpr int ndh_ = ((T) + 1) % 9 / 3, ndw_ = ((T) + 1) % 3;                                                    \
+    const int acur_ = (aoff[dw_] + abuf + dh_ * 8192) ^ 32;                                                          \
+    const int bcur_ = boff + rslot * SLAB;                                                                           \
+    const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
+    const int anext_ = aoff[ndw_] + ((T) == 8 ? C3_HALO - abuf : abuf) + ndh_ * 8192;                                \
+    const int bnext_ = boff + rnext_ * SLAB;                                                                         \
+    const int hbuf_ = abuf ? 0 : 1;                                                                                  \
+    C3_FENCE();                                                                                                      \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                                 \
+      C3_MM(0, n)                                                                                                    \
+      if (n < NR) C3_RD(1, n, acur_, bcur_, 1)                                                                       \
+    }                                                                                                                \
+    _Pragma("unroll") for (int n = 0; n < NM / 2; ++n) {                                                             \
+      C3_MM(1, n)                                                                                                    \
+      if (n < NR) C3_RD(0, n, anext_, bnext_, 0)                                                                     \
+    }                                                                                                                \
+    if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RD(0, n, anext_, bnext_, 0) }          \
+    C3_SYNC(c3_younger(R, IPW, (T)), NR)                                                                             \
+    if ((T) == 0) halo_begin();                                                                                      \
+    _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
+      C3_MM(1, n)                                                                                                    \
+      if (!(DBG & 4)) {                                                                                              \
+        if (n - NM / 2 < IPW) { slab_piece(n - NM / 2); C3_FENCE(); }                                                \
+        else if ((T) <= 3 && n - NM / 2 - IPW < 3) { halo_piece(hbuf_, 3 * (T) + n - NM / 2 - IPW); C3_FENCE(); }    \
+      }                                                                                                              \
+    }                                                                                                                \
+    slab_advance();                                                                                                  \
+    rslot = rnext_;                                                                                                  \
+  }
+
+  for (int k = 0; k < ntl; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < a.nchunk; ++c) {
+      C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5) C3_STEP(6) C3_STEP(7) C3_STEP(8)
+      abuf = C3_HALO - abuf;
+    }
+    if (k == 0) C3_TRACE()
+
+    // ---- epilogue of tile k: BN affine, ReLU / residual, then a transpose through LDS so that every global store
+    // instruction writes whole pixel rows (1 KB contiguous per wave) instead of 64 scattered 16-byte pieces.
+    // Lane (m, hi) of accumulator (i, j) holds channels 32*j + 16*hi + r (r = 0..15) of pixel 32*i + m of its row.
+    // Scratch: this wave's 8 KB of the halo buffer that is free until the next unit's tap-0 barrier
+    // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
+    const int t = wg + k * G;
+    const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
+    const int oh = rb * 4 + wave;
+    // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
+    // and kept (spilled) across the whole MFMA phase
+    int em = m, ehi = hi, el = lane;
+    asm volatile("" : "+v"(em), "+v"(ehi), "+v"(el));
+    constexpr int ROWB = COUT * 2, SPR = COUT / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
+    unsigned char* scr = smem + (C3_HALO - abuf) + wave * 12288;
+    bf16_t* __restrict__ yrow = a.y + (size_t)b * a.y_bs + (size_t)oh * a.W * a.y_cs + a.y_co;
+    const bf16_t* __restrict__ rrow = a.res + (size_t)b * a.r_bs + (size_t)oh * a.W * a.r_cs + a.r_co;
+    // FL >= 0: the flag combination is a compile-time constant (no per-value selects); FL < 0: read a.flags
+    auto epilogue = [&](auto FL) {
+      constexpr int F = decltype(FL)::value;
+      const bool relu_pre = F >= 0 ? (F & RD_RELU_PRE) != 0 : (a.flags & RD_RELU_PRE) != 0;
+      const bool do_add = F >= 0 ? (F & RD_ADD) != 0 : (a.flags & RD_ADD) != 0;
+      const bool relu_post = F >= 0 ? (F & RD_RELU_POST) != 0 : (a.flags & RD_RELU_POST) != 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tc = 32 * i + em, ow = ct * C3_TW + tc;
+        const bool live = tc < C3_TW && ow < a.W && oh < a.H;
+        // residuals of this pixel fragment: all loads in flight before the first use (dead pixels read pixel 0 of the row)
+        Slot16 rv[NCT][2];
+        if (do_add) {
+          const bf16_t* rp = rrow + (live ? (size_t)ow * a.r_cs : 0) + 16 * ehi;
+#pragma unroll
+          for (int j = 0; j < NCT; ++j) {
+            rv[j][0] = *(const Slot16*)(rp + j * 32);
+            rv[j][1] = *(const Slot16*)(rp + j * 32 + 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+          C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
+          const int cb = j * 32 + 16 * ehi;
+          unsigned pk[8];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 sc = *(const f32x4*)(Sc + cb + 4 * g4);
+            const f32x4 sh = *(const f32x4*)(Sc + COUT + cb + 4 * g4);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g4 + e;
+              v[e] = acc[i][j][r] * sc[e] + sh[e];
+              if (relu_pre) v[e] = fmaxf(v[e], 0.f);
+              if (do_add) {   // bf16 -> f32 is a 16-bit shift of the packed pair
+                const unsigned w2 = rv[j][r >> 3][(r >> 1) & 3];
+                v[e] += __uint_as_float((r & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+              }
+              if (relu_post) v[e] = fmaxf(v[e], 0.f);
+            }
+            pk[2 * g4] = f32x2_to_bf16x2(v[0], v[1]);
+            pk[2 * g4 + 1] = f32x2_to_bf16x2(v[2], v[3]);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            *(Slot16*)(scr + em * ROWB + ((((cb >> 3) + u) ^ (em & (SPR - 1))) << 4)) =
+                Slot16{pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]};
+        }
+        C3_FENCE();
+        __builtin_amdgcn_wave_barrier();   // (the wave runs in lockstep on hardware; this orders the lanes under hipemu)
+        // read back pixel-major and store: lane -> (pixel it*RPI + el / SPR, slot el % SPR)
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int pr = it * RPI + el / SPR, sl = el % SPR;
+          const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
+          const int tcs = 32 * i + pr, ows = ct * C3_TW + tcs;
+          if (tcs < C3_TW && ows < a.W && oh < a.H && (!(DBG & 1) || a.B < 0)) *(Slot16*)(yrow + (size_t)ows * a.y_cs + sl * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        C3_FENCE();
+      }
+    };
+    if (a.flags == RD_RELU_POST) epilogue(std::integral_constant<int, RD_RELU_POST>{});
+    else if (a.flags == (RD_ADD | RD_RELU_POST)) epilogue(std::integral_constant<int, RD_ADD | RD_RELU_POST>{});
+    else epilogue(std::integral_constant<int, -1>{});
+    if (k == 0) C3_TRACE()
+  }
+  // DMA still in flight (the dummy tail fetches) targets this workgroup's LDS: retire it before the LDS is released
+  __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
+  C3_TRACE()
+  if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - clk0;   // shader-clock ticks of the whole life
+#undef C3_STEP
+#undef C3_SYNC
+#undef C3_MM
+#undef C3_RD
+#undef C3_FENCE
+#undef C3_TRACE
+}
+
+// device memory holding 16 zero bytes (allocated once per process)
+inline const unsigned char* conv_zero16() {
+#ifdef HIPEMU
+  static const unsigned char z[16] = {0};
+  return z;
+#else
+  static const unsigned char* p = [] {
+    unsigned char* q = nullptr;
+    if (hipMalloc((void**)&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return (unsigned char*)nullptr;
+    return q;
+  }();
+  return p;
+#endif
+}
+inline int conv_num_cus() {
+#ifdef HIPEMU
+  return 4;
+#else
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+#endif
+}
+
+inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout) {
+  if (dt != RD_BF16 || tl.n != 9 || in_stride != 1 || out_stride != 1 || Wq != Win || Wout != Win) return false;
+  if (cout != 64 && cout != 128) return false;
+  for (int t = 0; t < 9; ++t)
+    if (tl.dh[t] != t / 3 - 1 || tl.dw[t] != t % 3 - 1) return false;
+  return getenv("RD_CONV_V1") == nullptr;
+}
+
+inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                        const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                        int cout, int flags, hipStream_t st) {
+  Conv3Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
+  a.w = (const unsigned char*)w; a.scale = scale; a.shift = shift;
+  a.res = (const bf16_t*)res; a.r_cs = r_cs; a.r_co = r_co; a.r_bs = (long)H * W * r_cs;
+  a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * W * y_cs;
+  a.zero16 = conv_zero16();
+  RD_REQUIRE(a.zero16, RD_EHIP, "conv: zero page allocation failed");
+  a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;
+  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + 3) / 4; a.ntiles = a.ncol * a.nrow * B;
+  const int grid = std::min(a.ntiles, conv_num_cus());
+  if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
+  ProfScope ps(RD_PROF_CONV, st);
+  static const int dbg = getenv("RD_CONV3_DBG") ? atoi(getenv("RD_CONV3_DBG")) : 0;
+#define C3_DBG_CASE(D) else if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); }
+  if (false) {}
+  C3_DBG_CASE(1) C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(6) C3_DBG_CASE(8) C3_DBG_CASE(14)
+#undef C3_DBG_CASE
+  else if (cout == 128) hipLaunchKernelGGL((conv3x3_stream_kernel<4>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a);
+  else hipLaunchKernelGGL((conv3x3_stream_kernel<2>), dim3(grid), dim3(256), C3Cfg<2>::LDS, st, a);
+  return check_launch("conv3x3_stream_kernel");
+}
+
+}  // namespace rd

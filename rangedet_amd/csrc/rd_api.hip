@@ -1,6 +1,6 @@
 // librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
-#include "k_conv2.h"
+#include "k_conv3.h"
 #include "k_meta.h"
 #include "k_misc.h"
 #include "k_riou.h"
@@ -38,8 +38,8 @@ inline void allow_big_lds(K kernel) {
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 inline void allow_conv_lds() {
-  allow_big_lds(conv_wreg_kernel<2, 2>);
-  allow_big_lds(conv_wreg_kernel<2, 1>);
+  allow_big_lds(conv3x3_stream_kernel<4>);
+  allow_big_lds(conv3x3_stream_kernel<2>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 8, 4>);
@@ -98,7 +98,7 @@ int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, 
   RD_REQUIRE(kh * kw >= 1 && kh * kw <= 9 && (kh & 1) && (kw & 1), RD_ESHAPE, "pack_conv: kernel (%d,%d)", kh, kw);
   TapList tl = conv_taps(kh, kw);
   auto get = [&](int co, int ci, int t) { return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
-  if (dtype == RD_BF16 && conv_use_wreg()) pack_taps_wreg(tl.n, cin, cout, out, get);
+  if (dtype == RD_BF16) pack_taps_frag(tl.n, cin, cout, out, get);
   else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }
@@ -115,7 +115,7 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
   auto get = [&](int co, int ci, int t) { return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
-  if (dtype == RD_BF16 && conv_use_wreg()) pack_taps_wreg(tl.n, cin, cout, out, get);
+  if (dtype == RD_BF16) pack_taps_frag(tl.n, cin, cout, out, get);
   else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }

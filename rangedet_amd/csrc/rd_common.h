@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rangedet_hip.h"
@@ -104,6 +105,17 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to n
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
+}
+// two floats -> one dword of packed bf16 (lo = a, hi = b): a single v_cvt_pk_bf16_f32 on gfx950
+__host__ __device__ __forceinline__ unsigned f32x2_to_bf16x2(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+#else
+  return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+#endif
 }
 __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   unsigned u = (unsigned)h << 16;

@@ -261,6 +261,7 @@ inline void __builtin_amdgcn_global_load_lds(SrcPtr src, DstPtr lds_base, unsign
 inline bool isinf(float v) { return std::isinf(v); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline unsigned long long wall_clock64() { return 0; }
+inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
 inline void __threadfence() {}
 
 // sequential blocks, cooperative fibers: plain read-modify-write is atomic enough

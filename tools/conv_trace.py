@@ -1,5 +1,5 @@
-"""Phase trace of the bf16 conv kernel (dev tool): RD_CONV_TRACE=1 python tools/conv_trace.py [W cin cout B]
-Prints, per phase, the mean / p90 duration over workgroups and the launch-relative start spread (s_memrealtime, 10 ns)."""
+"""Phase trace of the persistent 3x3 bf16 conv kernel (dev tool): python tools/conv_trace.py [W cin cout B]
+Per workgroup: prologue, first tile's MFMA phase, first tile's epilogue, total life (s_memrealtime, 10 ns ticks)."""
 import ctypes
 import os
 import sys
@@ -21,24 +21,25 @@ y = torch.empty(B * H * W * cout, device="cuda", dtype=torch.bfloat16)
 w = torch.from_numpy(L.pack_conv_weight(np.random.randn(cout, cin, 3, 3).astype(np.float32) * 0.05, dt)).cuda()
 sc, sh = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for _ in range(3):
+for _ in range(5):
     L.call("rd_conv2d_bn_act", x.data_ptr(), cs, 0, w.data_ptr(), sc.data_ptr(), sh.data_ptr(), 0, cout, 0,
            y.data_ptr(), cout, 0, B, H, W, cin, cout, 3, 3, 1, 4, dt, st)
 torch.cuda.synchronize()
-nwg = ((W + 63) // 64) * (H // 4) * B * (1 if os.environ.get("RD_CONV_V2") else cout // 64)
+ntiles = -(-W // 126) * (H // 4) * B
+nwg = min(ntiles, torch.cuda.get_device_properties(0).multi_processor_count)
 buf = np.zeros(nwg * 8, dtype=np.uint64)
 fn = L.cdll.rd_dev_conv_trace_read
 fn.argtypes = [ctypes.c_void_p, ctypes.c_long]
 assert fn(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(nwg, 8).astype(np.int64)
+clk = t[:, 7].copy(); t[:, 7] = 0
 npt = int((t[0] > 0).sum())
 t0 = t[:, 0].min()
-print("workgroups %d, trace points %d, launch span %.1f us" % (nwg, npt, (t[:, :npt].max() - t0) / 100.0))
-names = ["prologue+stage0", "chunk0 taps", "stage1", "chunk1 taps", "epilogue", "", ""]
-if not os.environ.get("RD_CONV_V2"):
-    names = ["prologue+stage0", "chunk0 taps", "barrier+stage1", "chunk1 taps", "epilogue", "", ""]
+print("tiles %d on %d workgroups (%.2f each), launch span %.1f us" % (ntiles, nwg, ntiles / nwg, (t[:, :npt].max() - t0) / 100.0))
+names = ["prologue", "tile 0 MFMA phase", "tile 0 epilogue", "remaining tiles", "", ""]
 for i in range(npt - 1):
     d = (t[:, i + 1] - t[:, i]) / 100.0
-    print("  %-16s mean %7.2f us   p10 %7.2f  p90 %7.2f" % (names[i], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
-d = (t[:, npt - 1] - t[:, 0]) / 100.0
-print("  %-16s mean %7.2f us   p10 %7.2f  p90 %7.2f" % ("workgroup life", d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+    print("  %-18s mean %8.2f us   p10 %8.2f  p90 %8.2f" % (names[i], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+life = (t[:, npt - 1] - t[:, 0]) / 100.0
+print("  shader clock %.0f MHz (s_memtime ticks / s_memrealtime)" % np.median(clk / life))
+print("  start skew p90 %.2f us" % np.percentile((t[:, 0] - t0) / 100.0, 90))
