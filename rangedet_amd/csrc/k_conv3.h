@@ -64,13 +64,14 @@ inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
 
 // DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (tap T of its unit):
 // the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions and the
-// steps of taps 0..3 three halo pieces each.  At tap 7 the wait must also cover the last halo piece (issued at tap 3):
+// steps of taps 0..C3_HT-1 C3_HP halo pieces each.  At tap 7 the wait must also cover the last halo piece:
 // the following step reads the next unit's halo.
-constexpr int c3_halo_pieces(int tap) { return tap <= 3 ? 3 : 0; }
+constexpr int C3_HT = 6, C3_HP = 2;   // halo pieces: C3_HP per step at taps 0 .. C3_HT-1 (C3_HT * C3_HP = 12)
+constexpr int c3_halo_pieces(int tap) { return tap < C3_HT ? C3_HP : 0; }
 constexpr int c3_younger(int R, int IPW, int T) {
   int n = (R - 3) * IPW;
   for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((T - d) % 9) + 9) % 9);
-  if (T == 7 && n > 3 * IPW) n = 3 * IPW;
+  if (T == 7 && n > (7 - C3_HT) * IPW) n = (7 - C3_HT) * IPW;
   return n;
 }
 // s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
@@ -101,36 +102,64 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   const int tiles_img = a.ncol * a.nrow;
 
   // ---- DMA issue -----------------------------------------------------------------------------------------------
+  // LDS-DMA with a precomputed LDS address in M0 (nothing else in this kernel uses M0).  Issued through inline asm so
+  // that hipcc's waitcnt pass does not see it (k_conv.h / rd_common.h lds_dma16 explain why); hipemu uses the builtin.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+#endif
+  auto dma_s = [&](const unsigned char* sbase, unsigned voff, int lds_off) {   // uniform base + 32-bit lane offset
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds0 + (unsigned)lds_off) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds(sbase + voff, smem + lds_off, 16, 0, 0);
+#endif
+  };
+  auto dma_v = [&](const void* vptr, int lds_off) {                            // per-lane 64-bit address
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(vptr), "s"(lds0 + (unsigned)lds_off) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds(vptr, smem + lds_off, 16, 0, 0);
+#endif
+  };
   // halo image: linear 16-B slot P = 4*px + ps of the LDS image holds logical slot s = ps ^ ((px >> 2) & 3) of halo
   // pixel px = 128*r + cc (conflict-free ds_read_b128 for any tap shift).  Wave w issues the 12
   // 1-KB pieces q = 12*w .. 12*w+11: px = 16*q + (lane >> 2), so r = q >> 3 and cc = 16*(q & 7) + (lane >> 2).
+  // Source of a piece = uniform address of halo pixel (r, 16*(q&7)) + a per-lane constant; lanes outside the image
+  // (or past the last channel slot) read the zero page instead.
   const int hs = (lane & 3) ^ ((lane >> 4) & 3);          // logical slot this lane fetches (same for every piece)
+  const int l4 = lane >> 2;
+  const unsigned hlane = (unsigned)(l4 * a.x_cs + hs * 8) * 2;
   int hk = 0, hc = 0;                                     // (tile ordinal, chunk) of the NEXT halo to fetch
-  int hh0 = 0, hw0 = 0;                                   // origin of the halo being fetched
-  const bf16_t* hxb = a.x;
+  int hh0 = 0, hlo = 0, hlim = 0;                         // first halo row; valid halo columns are hlo <= cc < hlim
+  const unsigned char* hbase = nullptr;                   // uniform: halo pixel (0, 0), channel slot 4*hc
   bool hsok = false;
   auto halo_begin = [&]() {                               // decode the unit to fetch, advance the cursor
     const int t = wg + hk * G;
     const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
-    hh0 = rb * 4 - 1; hw0 = ct * C3_TW - 1;
-    hxb = a.x + (size_t)b * a.x_bs + a.x_co + (hc * 4 + hs) * 8;
+    const int hw0 = ct * C3_TW - 1;
+    hh0 = rb * 4 - 1;
+    hlo = hw0 < 0 ? -hw0 : 0;
+    hlim = a.W - hw0;
+    hbase = (const unsigned char*)(a.x + (size_t)b * a.x_bs + a.x_co + hc * 32) +
+            ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
     hsok = hc * 4 + hs < a.nslots;
     // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
     if (hc + 1 < a.nchunk) ++hc;
     else if (hk + 1 < ntl) { ++hk; hc = 0; }
   };
   auto halo_piece = [&](int buf, int j) {
-    const int q = wave * 12 + j;
-    const int ih = hh0 + (q >> 3), iw = hw0 + (q & 7) * 16 + (lane >> 2);
-    const bool ok = hsok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-    const void* src = ok ? (const void*)(hxb + ((size_t)ih * a.W + iw) * a.x_cs) : (const void*)a.zero16;
-    lds_dma16(src, smem + buf * C3_HALO + q * 1024);
+    const int q = wave * 12 + j, r = q >> 3, c16 = (q & 7) * 16;
+    const int cc = c16 + l4;
+    const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
+    const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
+    dma_v(ok ? (const void*)(sp + hlane) : (const void*)a.zero16, buf * C3_HALO + q * 1024);
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
   const int nslab_tile = a.nchunk * 9;
-  const unsigned char* wsrc = a.w + wave * IPW * 1024 + lane * 16;
   auto slab_piece = [&](int j) {
-    lds_dma16(wsrc + (size_t)fslab * SLAB + j * 1024, smem + RING + fslot * SLAB + (wave * IPW + j) * 1024);
+    dma_s(a.w + (size_t)fslab * SLAB + (wave * IPW + j) * 1024, lane * 16, RING + fslot * SLAB + (wave * IPW + j) * 1024);
   };
   auto slab_advance = [&]() {
     fslot = fslot + 1 == R ? 0 : fslot + 1;
@@ -172,7 +201,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #define C3_SYNC(VMCNT, LGKM)                                      \
   {                                                               \
     asm volatile("" ::: "memory");                                \
-    __builtin_amdgcn_s_waitcnt(C3_WAIT_IMM(VMCNT, LGKM));         \
+    __builtin_amdgcn_s_waitcnt(C3_WAIT_IMM((DBG & 32) ? 63 : (VMCNT), LGKM)); \
     if (!(DBG & 2)) __builtin_amdgcn_s_barrier();                 \
     asm volatile("" ::: "memory");                                \
     C3_FENCE();                                                   \
@@ -224,8 +253,10 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
       C3_MM(1, n)                                                                                                    \
       if (!(DBG & 4)) {                                                                                              \
+        constexpr int HS_ = NM / 2 >= IPW + 2 * C3_HP ? 2 : 1;  /* MFMA slots per halo piece */                      \
+        const int p_ = n - NM / 2 - IPW;                                                                             \
         if (n - NM / 2 < IPW) { slab_piece(n - NM / 2); C3_FENCE(); }                                                \
-        else if ((T) <= 3 && n - NM / 2 - IPW < 3) { halo_piece(hbuf_, 3 * (T) + n - NM / 2 - IPW); C3_FENCE(); }    \
+        else if ((T) < C3_HT && p_ % HS_ == 0 && p_ / HS_ < C3_HP) { halo_piece(hbuf_, C3_HP * (T) + p_ / HS_); C3_FENCE(); } \
       }                                                                                                              \
     }                                                                                                                \
     slab_advance();                                                                                                  \
@@ -268,20 +299,22 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       const bool relu_pre = F >= 0 ? (F & RD_RELU_PRE) != 0 : (a.flags & RD_RELU_PRE) != 0;
       const bool do_add = F >= 0 ? (F & RD_ADD) != 0 : (a.flags & RD_ADD) != 0;
       const bool relu_post = F >= 0 ? (F & RD_RELU_POST) != 0 : (a.flags & RD_RELU_POST) != 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      // residuals: the loads of pixel fragment i+1 are issued before fragment i is processed (dead pixels read pixel 0)
+      Slot16 rv[2][NCT][2];
+      auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
         const int tc = 32 * i + em, ow = ct * C3_TW + tc;
         const bool live = tc < C3_TW && ow < a.W && oh < a.H;
-        // residuals of this pixel fragment: all loads in flight before the first use (dead pixels read pixel 0 of the row)
-        Slot16 rv[NCT][2];
-        if (do_add) {
-          const bf16_t* rp = rrow + (live ? (size_t)ow * a.r_cs : 0) + 16 * ehi;
+        const bf16_t* rp = rrow + (live ? (size_t)ow * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
-          for (int j = 0; j < NCT; ++j) {
-            rv[j][0] = *(const Slot16*)(rp + j * 32);
-            rv[j][1] = *(const Slot16*)(rp + j * 32 + 8);
-          }
+        for (int j = 0; j < NCT; ++j) {
+          dst[j][0] = *(const Slot16*)(rp + j * 32);
+          dst[j][1] = *(const Slot16*)(rp + j * 32 + 8);
         }
+      };
+      if (do_add) res_load(0, rv[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (do_add && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
               v[e] = acc[i][j][r] * sc[e] + sh[e];
               if (relu_pre) v[e] = fmaxf(v[e], 0.f);
               if (do_add) {   // bf16 -> f32 is a 16-bit shift of the packed pair
-                const unsigned w2 = rv[j][r >> 3][(r >> 1) & 3];
+                const unsigned w2 = rv[i & 1][j][r >> 3][(r >> 1) & 3];
                 v[e] += __uint_as_float((r & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
               }
               if (relu_post) v[e] = fmaxf(v[e], 0.f);
@@ -396,7 +429,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   static const int dbg = getenv("RD_CONV3_DBG") ? atoi(getenv("RD_CONV3_DBG")) : 0;
 #define C3_DBG_CASE(D) else if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); }
   if (false) {}
-  C3_DBG_CASE(1) C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(6) C3_DBG_CASE(8) C3_DBG_CASE(14)
+  C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32) C3_DBG_CASE(34)
 #undef C3_DBG_CASE
   else if (cout == 128) hipLaunchKernelGGL((conv3x3_stream_kernel<4>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a);
   else hipLaunchKernelGGL((conv3x3_stream_kernel<2>), dim3(grid), dim3(256), C3Cfg<2>::LDS, st, a);

@@ -95,6 +95,84 @@ __global__ __launch_bounds__(256) void head_out_kernel(const void* __restrict__ 
   }
 }
 
+// bf16 variant on the matrix cores: the op is a [NOUT x cin] x [cin x pixels] GEMM streamed once over the feature map
+// (HBM-bound: cin*2 bytes in, NOUT*4 bytes out per pixel).  One wave owns 32 pixels at a time.  Global loads are whole
+// pixel rows (a wave instruction = 4 pixels x 256 B contiguous), transposed through a wave-private, XOR-swizzled 8 KB
+// LDS image into the MFMA B-operand layout (lane (px, hi) <- 16-byte channel group 2*ks + hi of its pixel).  The A
+// operand is the weight matrix padded to 32 rows, held in registers as a bf16 hi + lo pair per k-step (w = hi + lo to
+// ~2^-17, so fp32 weights keep their precision); D[co][px] leaves lane (px, hi) with co = 4*hi + r in registers r = 0..3.
+template <int NOUT>
+__global__ __launch_bounds__(256) void head_out_mfma_kernel(const bf16_t* __restrict__ x, int cs, int coff,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long out_bs, long n_off, long HW,
+                                                            int cin) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 8192];
+  const int lane = threadIdx.x & 63, m = lane & 31, hi = lane >> 5, wv = threadIdx.x >> 6;
+  unsigned char* img = lds + wv * 8192;
+  const int nks = cin >> 4, nsl = cin >> 3;                     // k-steps (<= 8), 16-byte slots per pixel (<= 16)
+  x += (size_t)blockIdx.y * HW * cs + coff;
+  out += (size_t)blockIdx.y * out_bs + n_off * NOUT;
+  s16x8 wh[8], wl[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (m < NOUT && ks < nks) ? w[m * cin + ks * 16 + hi * 8 + j] : 0.f;
+      h[j] = f32_to_bf16(v);
+      l[j] = f32_to_bf16(v - bf16_to_f32(h[j]));
+    }
+    memcpy(&wh[ks], h, 16);
+    memcpy(&wl[ks], l, 16);
+  }
+  float bs[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bs[r] = 4 * hi + r < NOUT ? bias[4 * hi + r] : 0.f;
+  const long ntile = (HW + 31) / 32;
+  const long wave0 = (long)blockIdx.x * 4 + wv, nwave = (long)gridDim.x * 4;
+  const int lp = lane >> 4, ls = lane & 15;                     // load role: pixel it*4 + lp of the tile, slot ls
+  auto load = [&](long tile, Slot16 (&v)[8]) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long p = min(tile * 32 + it * 4 + lp, HW - 1);      // clamp: dead pixels re-read the last one, never stored
+      v[it] = ls < nsl ? *(const Slot16*)(x + p * cs + ls * 8) : Slot16{0u, 0u, 0u, 0u};
+    }
+  };
+  Slot16 cur[8], nxt[8];
+  if (wave0 < ntile) load(wave0, cur);
+  for (long tile = wave0; tile < ntile; tile += nwave) {
+    const bool more = tile + nwave < ntile;
+    if (more) load(tile + nwave, nxt);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pr = it * 4 + lp;
+      *(Slot16*)(img + pr * 256 + ((ls ^ (pr & 15)) << 4)) = cur[it];
+    }
+    __builtin_amdgcn_wave_barrier();                            // LDS ops of a wave are in order; this orders hipemu's lanes
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const s16x8 b = *(const s16x8*)(img + m * 256 + (((2 * ks + hi) ^ (m & 15)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long p = tile * 32 + m;
+    if (p < HW) {
+      float* o = out + p * NOUT + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * hi + r < NOUT) o[r] = acc[r] + bs[r];
+    }
+    if (more) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) cur[it] = nxt[it];
+    }
+  }
+}
+
 // ---- Decode3DBbox  (decode_3d_bbox-inl.h:64-277) ------------------------------------------------------------
 // One thread per point: 44 B in, 40 B out.  Same operation order as the reference's Map(); the two spots where
 // the reference's float instantiation goes through double (0.5*length, height/2.0) do so here too.

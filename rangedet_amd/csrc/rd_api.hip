@@ -165,6 +165,13 @@ int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const 
   const long HW = (long)H * W;
   dim3 grid((unsigned)std::min<long>((HW + 31) / 32, 4096), B);
   ProfScope ps(RD_PROF_HEAD_OUT, st);
+  if (dtype == RD_BF16 && nout > 1 && cin % 16 == 0 && x_cstride % 8 == 0 && x_coff % 8 == 0) {   // matrix-core streaming variant
+    dim3 g2((unsigned)std::min<long>((HW + 127) / 128, 2048), B);
+#define RD_HOM(NO) hipLaunchKernelGGL((head_out_mfma_kernel<NO>), g2, dim3(256), 0, st, (const bf16_t*)x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
+    if (nout == 7) RD_HOM(7); else RD_HOM(8);
+#undef RD_HOM
+    return check_launch("head_out");
+  }
 #define RD_HO(DT, NO) hipLaunchKernelGGL((head_out_kernel<DT, NO>), grid, dim3(256), 0, st, x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
   if (dtype == RD_BF16) { if (nout == 1) RD_HO(RD_BF16, 1); else if (nout == 7) RD_HO(RD_BF16, 7); else RD_HO(RD_BF16, 8); }
   else { if (nout == 1) RD_HO(RD_F32, 1); else if (nout == 7) RD_HO(RD_F32, 7); else RD_HO(RD_F32, 8); }

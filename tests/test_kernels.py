@@ -148,7 +148,7 @@ def test_head_out_and_layout(be, dt):
     L.call("rd_nhwc_to_nchw", be.ptr(xin), be.ptr(back), B, C, H, W, C, 0, dt, be.stream)
     assert np.array_equal(be.down(back, np.float32, (B, C, H, W)), x)
     N = H * W + 50
-    for nout in (1, 8):
+    for nout in (1, 7, 8):
         w = (rng.standard_normal((nout, C)) * 0.1).astype(np.float32)
         b = rng.standard_normal(nout).astype(np.float32)
         out = be.empty(B * N * nout * 4)
