@@ -128,8 +128,8 @@ def main():
         if world > 1:
             torch.cuda.current_stream().wait_stream(pipe._post_stream)   # the padded detections of this batch are final
             for b, pp in enumerate(pipe.post):
-                gather_in[b * REC:(b + 1) * REC - 1].copy_(A.view_f32(pp.out, (pp.cap, 12))[:MAX_DET].reshape(-1))
-                gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(A.view_i32(pp.nkeep, (1,)).float())
+                gather_in[b * REC:(b + 1) * REC - 1].copy_(pp.out_rows()[:MAX_DET].reshape(-1))
+                gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(pp.nkeep_view().float())
             dist.all_gather(gather_out, gather_in)                         # the ONE collective of the path
 
     def barrier():

@@ -133,6 +133,11 @@ int rd_decode3d_bbox(const float* bbox_delta, const float* pc, float* out, int B
 size_t rd_score_filter_workspace_bytes(long n);
 int rd_score_filter_dets(const float* scores, const float* boxes10, long n, float min_score, float* dets,
                          int* d_count, void* ws, size_t ws_bytes, void* stream);
+/* B frames in one set of launches: frame b reads scores + b*scores_bstride, boxes10 + b*boxes_bstride, writes
+ * dets + b*dets_bstride (strides in floats) and d_count[b]; ws_bytes >= B * rd_score_filter_workspace_bytes(n). */
+int rd_score_filter_dets_batched(const float* scores, long scores_bstride, const float* boxes10, long boxes_bstride,
+                                 long n, float min_score, float* dets, long dets_bstride, int* d_count, void* ws,
+                                 size_t ws_bytes, int B, void* stream);
 
 /* Weighted NMS.  dets (Kcap,12) device; the number of valid rows is *d_count when d_count != NULL, else Kcap.
  * order: device int32 (Kcap) processing order (sorted positions -> row index), or NULL = the library sorts on
@@ -143,11 +148,20 @@ size_t rd_wnms_workspace_bytes(int Kcap);
 int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh,
                float thresh_vote, int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws,
                size_t ws_bytes, void* stream);
+/* B independent frames in one set of launches (the per-frame greedy scan is one latency-bound wavefront: B of them
+ * run side by side instead of back to back).  Frame b uses dets + b*dets_bstride, order + b*order_bstride (stride 0 =
+ * one order shared by all frames; order must not be NULL when B > 1), d_count[b], out_dets + b*out_bstride,
+ * keep + b*keep_bstride, d_nkeep[b]; ws_bytes >= B * rd_wnms_workspace_bytes(Kcap).  Strides in elements. */
+int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int* d_count, const int* order,
+                       long order_bstride, float thresh, float thresh_vote, int is3d, float* out_dets, long out_bstride,
+                       int* keep, long keep_bstride, int* d_nkeep, void* ws, size_t ws_bytes, int B, void* stream);
 /* HOST: the reference's own ordering (std::sort, score descending, unstable) for dets_host (K,12). */
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host);
 
 /* dets12 (M,12) -> (M,8) [cx,cy,cz,l,w,h,heading,score]; count from *d_count when not NULL. */
 int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out8, void* stream);
+int rd_dets12_to_8_batched(const float* dets12, long dets12_bstride, int Mcap, const int* d_count, float* out8,
+                           long out8_bstride, int B, void* stream);
 
 /* 8-point rotated IoU: boxes1 (n1,8) x boxes2 (n2,8) -> ious (n1,n2). */
 int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream);

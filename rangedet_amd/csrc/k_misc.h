@@ -222,8 +222,11 @@ __global__ __launch_bounds__(256) void decode3d_kernel(const float* __restrict__
 
 // ---- score filter + 10->11 dim  (tools/test.py:56-81,200-209) --------------------------------------------------
 // stable compaction of rows with score > min_score: per-block counts -> single-block scan -> scatter.
+// batch: blockIdx.y selects the frame; per-frame buffers sit `*_bs` elements apart
 __global__ __launch_bounds__(256) void filter_count_kernel(const float* __restrict__ scores, long n, float thr,
-                                                           int* __restrict__ blk_cnt) {
+                                                           int* __restrict__ blk_cnt, long sc_bs, long blk_bs) {
+  scores += blockIdx.y * sc_bs;
+  blk_cnt += blockIdx.y * blk_bs;
   long i = blockIdx.x * 256L + threadIdx.x;
   int p = (i < n) && (scores[i] > thr);
   unsigned long long m = __ballot(p);
@@ -232,8 +235,11 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
-__global__ __launch_bounds__(256) void filter_scan_kernel(int* __restrict__ blk_cnt, int nblk, int* __restrict__ total) {
-  // exclusive scan of nblk ints by one workgroup (nblk is a few hundred)
+__global__ __launch_bounds__(256) void filter_scan_kernel(int* __restrict__ blk_cnt, int nblk, int* __restrict__ total,
+                                                          long blk_bs) {
+  // exclusive scan of nblk ints by one workgroup (nblk is a few hundred); one workgroup per frame
+  blk_cnt += blockIdx.x * blk_bs;
+  total += blockIdx.x;
   __shared__ int part[256];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
@@ -259,7 +265,12 @@ __global__ __launch_bounds__(256) void filter_scan_kernel(int* __restrict__ blk_
 }
 __global__ __launch_bounds__(256) void filter_scatter_kernel(const float* __restrict__ scores,
                                                              const float* __restrict__ boxes10, long n, float thr,
-                                                             const int* __restrict__ blk_off, float* __restrict__ dets) {
+                                                             const int* __restrict__ blk_off, float* __restrict__ dets,
+                                                             long sc_bs, long box_bs, long blk_bs, long dets_bs) {
+  scores += blockIdx.y * sc_bs;
+  boxes10 += blockIdx.y * box_bs;
+  blk_off += blockIdx.y * blk_bs;
+  dets += blockIdx.y * dets_bs;
   long i = blockIdx.x * 256L + threadIdx.x;
   int p = (i < n) && (scores[i] > thr);
   unsigned long long m = __ballot(p);
@@ -284,9 +295,11 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const float* __rest
 
 // ---- 12 -> 8 dim  (tools/test.py:43-53; float32 here, the reference's numpy promotes to float64) ---------------
 __global__ __launch_bounds__(256) void dets12_to_8_kernel(const float* __restrict__ d12, int cap, const int* __restrict__ d_count,
-                                                          float* __restrict__ o8) {
+                                                          float* __restrict__ o8, long d12_bs, long o8_bs) {
+  d12 += blockIdx.y * d12_bs;
+  o8 += blockIdx.y * o8_bs;
   int i = blockIdx.x * 256 + threadIdx.x;
-  int n = d_count ? min(*d_count, cap) : cap;
+  int n = d_count ? min(d_count[blockIdx.y], cap) : cap;
   if (i >= n) return;
   const float* d = d12 + (size_t)i * 12;
   float* o = o8 + (size_t)i * 8;

@@ -158,11 +158,18 @@ __device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, cons
   return inter / (area1 + area2 - inter);
 }
 
+// Batched launches: blockIdx.z selects the frame.  WnmsBatch holds the distance between consecutive frames of every
+// buffer, in elements of that buffer (0 = shared by all frames, e.g. an identity order).
+struct WnmsBatch {
+  long dets, order, prep, words, ints, keep, out;   // words: thr / vote / snap;  ints: keep_q;  counts are 1 apart
+};
 __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict__ dets, const int* __restrict__ order,
-                                                        int cap, const int* __restrict__ d_count, float* __restrict__ prep) {
+                                                        int cap, const int* __restrict__ d_count, float* __restrict__ prep,
+                                                        WnmsBatch bs) {
   RD_NOCONTRACT
+  dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; prep += blockIdx.z * bs.prep;
   int q = blockIdx.x * 256 + threadIdx.x;
-  int K = d_count ? min(*d_count, cap) : cap;
+  int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   if (q >= K) return;
   const float* b = dets + (size_t)order[q] * 12;
   WPt p[4];
@@ -201,9 +208,10 @@ constexpr int WN_CT = 8;
 __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict__ prep, int cap,
                                                         const int* __restrict__ d_count, float thresh, float thresh_vote,
                                                         int is3d, unsigned long long* __restrict__ thr,
-                                                        unsigned long long* __restrict__ vote, int nwcap) {
+                                                        unsigned long long* __restrict__ vote, int nwcap, WnmsBatch bs) {
+  prep += blockIdx.z * bs.prep; thr += blockIdx.z * bs.words; vote += blockIdx.z * bs.words;
   const int rb = blockIdx.y, cb = blockIdx.x / WN_CT, sub = blockIdx.x % WN_CT;
-  const int K = d_count ? min(*d_count, cap) : cap;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   if (cb < rb || rb * 64 >= K || cb * 64 >= K) return;
   __shared__ float colp[WN_CT * PREP_F];
   __shared__ float edges[EDGE_LDS_BYTES / 4];
@@ -246,12 +254,14 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
                                                        unsigned long long* __restrict__ snap, int cap,
                                                        const int* __restrict__ d_count, int nwcap,
                                                        const int* __restrict__ order, int* __restrict__ keep_q,
-                                                       int* __restrict__ keep, int* __restrict__ d_nkeep) {
+                                                       int* __restrict__ keep, int* __restrict__ d_nkeep, WnmsBatch bs) {
   HIP_DYNAMIC_SHARED(unsigned char, smem);
+  thr += blockIdx.z * bs.words; snap += blockIdx.z * bs.words; order += blockIdx.z * bs.order;
+  keep_q += blockIdx.z * bs.ints; keep += blockIdx.z * bs.keep; d_nkeep += blockIdx.z;
   unsigned long long* supp = (unsigned long long*)smem;      // [nwcap]
   unsigned long long* tile = supp + nwcap;                   // [64][nwcap]
   const int lane = threadIdx.x;
-  const int K = d_count ? min(*d_count, cap) : cap;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   const int nw = (K + 63) >> 6;
   for (int w = lane; w < nw; w += 64) supp[w] = 0ull;
   __builtin_amdgcn_wave_barrier();
@@ -300,15 +310,17 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
                                                         const unsigned long long* __restrict__ snap, int cap,
                                                         const int* __restrict__ d_count, int nwcap,
                                                         const int* __restrict__ keep_q, const int* __restrict__ d_nkeep,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, WnmsBatch bs) {
   RD_NOCONTRACT
+  dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; vote += blockIdx.z * bs.words; snap += blockIdx.z * bs.words;
+  keep_q += blockIdx.z * bs.ints; out += blockIdx.z * bs.out;
   const int mrow = blockIdx.x;
-  if (mrow >= *d_nkeep) return;
+  if (mrow >= d_nkeep[blockIdx.z]) return;
   HIP_DYNAMIC_SHARED(unsigned char, smem);  // (cap + 2) ints + (cap + 2) floats
   int* nbl = (int*)smem;
   float* yws = (float*)(smem + (size_t)(cap + 2) * 4);
   const int lane = threadIdx.x;
-  const int K = d_count ? min(*d_count, cap) : cap;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   const int nw = (K + 63) >> 6;
   const int q = keep_q[mrow];
   const int irow = order[q];

@@ -267,28 +267,39 @@ int rd_decode3d_bbox(const float* bbox_delta, const float* pc, float* out, int B
 }
 
 size_t rd_score_filter_workspace_bytes(long n) { return (size_t)((n + 255) / 256 + 8) * 4 + 256; }
-int rd_score_filter_dets(const float* scores, const float* boxes10, long n, float min_score, float* dets, int* d_count,
-                         void* ws, size_t ws_bytes, void* stream) {
+int rd_score_filter_dets_batched(const float* scores, long scores_bstride, const float* boxes10, long boxes_bstride,
+                                 long n, float min_score, float* dets, long dets_bstride, int* d_count, void* ws,
+                                 size_t ws_bytes, int B, void* stream) {
   RD_REQUIRE(scores && boxes10 && dets && d_count && ws, RD_EINVAL, "score_filter: null pointer");
-  RD_REQUIRE(n > 0, RD_ESHAPE, "score_filter: empty input");
-  RD_REQUIRE(ws_bytes >= rd_score_filter_workspace_bytes(n), RD_EWORKSPACE, "score_filter: workspace too small");
+  RD_REQUIRE(n > 0 && B > 0, RD_ESHAPE, "score_filter: empty input");
+  const size_t per = rd_score_filter_workspace_bytes(n);
+  RD_REQUIRE(ws_bytes >= per * (size_t)B, RD_EWORKSPACE, "score_filter: workspace %zu < %zu", ws_bytes, per * (size_t)B);
   hipStream_t st = (hipStream_t)stream;
   int* blk = (int*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   const int nblk = (int)((n + 255) / 256);
+  const long blk_bs = nblk + 8;                  // per-frame block-count arrays (ints apart)
   ProfScope ps(RD_PROF_WNMS, st);
-  hipLaunchKernelGGL(filter_count_kernel, dim3(nblk), dim3(256), 0, st, scores, n, min_score, blk);
-  hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(256), 0, st, blk, nblk, d_count);
-  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblk), dim3(256), 0, st, scores, boxes10, n, min_score, blk, dets);
+  hipLaunchKernelGGL(filter_count_kernel, dim3(nblk, B), dim3(256), 0, st, scores, n, min_score, blk, scores_bstride, blk_bs);
+  hipLaunchKernelGGL(filter_scan_kernel, dim3(B), dim3(256), 0, st, blk, nblk, d_count, blk_bs);
+  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblk, B), dim3(256), 0, st, scores, boxes10, n, min_score, blk, dets,
+                     scores_bstride, boxes_bstride, blk_bs, dets_bstride);
   return check_launch("score_filter");
+}
+int rd_score_filter_dets(const float* scores, const float* boxes10, long n, float min_score, float* dets, int* d_count,
+                         void* ws, size_t ws_bytes, void* stream) {
+  return rd_score_filter_dets_batched(scores, 0, boxes10, 0, n, min_score, dets, 0, d_count, ws, ws_bytes, 1, stream);
 }
 
 size_t rd_wnms_workspace_bytes(int Kcap) { return Kcap > 0 ? wnms_ws_bytes(Kcap) : 0; }
-int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh, float thresh_vote,
-               int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws, size_t ws_bytes, void* stream) {
+int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int* d_count, const int* order,
+                       long order_bstride, float thresh, float thresh_vote, int is3d, float* out_dets, long out_bstride,
+                       int* keep, long keep_bstride, int* d_nkeep, void* ws, size_t ws_bytes, int B, void* stream) {
   RD_REQUIRE(dets && out_dets && keep && d_nkeep && ws, RD_EINVAL, "wnms_4c: null pointer");
   RD_REQUIRE(Kcap > 0 && Kcap <= RD_WNMS_MAX_K, RD_ESHAPE, "wnms_4c: Kcap %d not in [1, %d]", Kcap, RD_WNMS_MAX_K);
-  RD_REQUIRE(ws_bytes >= rd_wnms_workspace_bytes(Kcap), RD_EWORKSPACE, "wnms_4c: workspace %zu < %zu", ws_bytes,
-             rd_wnms_workspace_bytes(Kcap));
+  RD_REQUIRE(B > 0, RD_ESHAPE, "wnms_4c: batch %d", B);
+  const size_t per = rd_wnms_workspace_bytes(Kcap);
+  RD_REQUIRE(ws_bytes >= per * (size_t)B, RD_EWORKSPACE, "wnms_4c: workspace %zu < %zu", ws_bytes, per * (size_t)B);
+  RD_REQUIRE(order || B == 1, RD_EINVAL, "wnms_4c: the batched call needs an explicit processing order");
   hipStream_t st = (hipStream_t)stream;
   WnmsWs w = wnms_ws_carve(ws, Kcap);
   ProfScope ps(RD_PROF_WNMS, st);
@@ -302,20 +313,31 @@ int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order
     if (hipMemcpyAsync(w.order, s.idxA, (size_t)Kcap * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return rd::fail(RD_EHIP, "wnms_4c: order copy");
     ord = w.order;
+    order_bstride = 0;
   }
+  // consecutive frames use consecutive `per`-byte workspaces (per is a multiple of 256), so every carved array of
+  // frame b sits b * per bytes after frame 0's
+  WnmsBatch bs;
+  bs.dets = dets_bstride; bs.order = order_bstride; bs.prep = (long)(per / 4); bs.words = (long)(per / 8);
+  bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int nb = (Kcap + 63) / 64;
-  hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep);
-  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d,
-                     w.thr, w.vote, w.nwcap);
+  hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs);
+  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote,
+                     is3d, w.thr, w.vote, w.nwcap, bs);
   const size_t scan_lds = (size_t)65 * w.nwcap * 8;
   RD_REQUIRE(scan_lds <= 160 * 1024, RD_ESHAPE, "wnms_4c: Kcap too large for the scan tile");
   allow_big_lds(wnms_scan_kernel);
-  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord, w.keep_q,
-                     keep, d_nkeep);
+  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
+                     w.keep_q, keep, d_nkeep, bs);
   allow_big_lds(wnms_merge_kernel);
-  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, w.snap, Kcap,
-                     d_count, w.nwcap, w.keep_q, d_nkeep, out_dets);
+  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap, 1, B), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, w.snap, Kcap,
+                     d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs);
   return check_launch("wnms_4c");
+}
+int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh, float thresh_vote,
+               int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws, size_t ws_bytes, void* stream) {
+  return rd_wnms_4c_batched(dets, 0, Kcap, d_count, order, 0, thresh, thresh_vote, is3d, out_dets, 0, keep, 0, d_nkeep, ws,
+                            ws_bytes, 1, stream);
 }
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
   RD_REQUIRE(K >= 0 && (K == 0 || (dets_host && order_host)), RD_EINVAL, "wnms_order_host: bad arguments");
@@ -326,11 +348,16 @@ int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
   return RD_OK;
 }
 
-int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out8, void* stream) {
+int rd_dets12_to_8_batched(const float* dets12, long dets12_bstride, int Mcap, const int* d_count, float* out8,
+                           long out8_bstride, int B, void* stream) {
   RD_REQUIRE(dets12 && out8, RD_EINVAL, "dets12_to_8: null pointer");
-  RD_REQUIRE(Mcap > 0, RD_ESHAPE, "dets12_to_8: empty input");
-  hipLaunchKernelGGL(dets12_to_8_kernel, dim3((Mcap + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets12, Mcap, d_count, out8);
+  RD_REQUIRE(Mcap > 0 && B > 0, RD_ESHAPE, "dets12_to_8: empty input");
+  hipLaunchKernelGGL(dets12_to_8_kernel, dim3((Mcap + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dets12, Mcap, d_count,
+                     out8, dets12_bstride, out8_bstride);
   return check_launch("dets12_to_8");
+}
+int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out8, void* stream) {
+  return rd_dets12_to_8_batched(dets12, 0, Mcap, d_count, out8, 0, 1, stream);
 }
 
 int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream) {

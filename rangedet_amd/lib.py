@@ -48,7 +48,12 @@ SIGNATURES = {
     "rd_decode3d_bbox": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "rd_score_filter_workspace_bytes": (c_size_t, [c_long]),
     "rd_score_filter_dets": (c_int, [c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rd_score_filter_dets_batched": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_float, c_void_p, c_long, c_void_p,
+                                             c_void_p, c_size_t, c_int, c_void_p]),
     "rd_wnms_workspace_bytes": (c_size_t, [c_int]),
+    "rd_wnms_4c_batched": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p,
+                                   c_long, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "rd_dets12_to_8_batched": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rd_wnms_4c": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
     "rd_wnms_order_host": (c_int, [c_void_p, c_int, c_void_p]),

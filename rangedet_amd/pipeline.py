@@ -76,6 +76,75 @@ class PostProcessor:
         return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
 
 
+class BatchPostProcessor:
+    """The same post-processing for all frames of a batch in ONE set of launches (rd_*_batched): the greedy NMS scan is a
+    single latency-bound wavefront per frame, so B of them run side by side instead of back to back.  Per-frame buffers
+    are slices of contiguous allocations; frame b's results are read back with collect(b)."""
+
+    def __init__(self, B, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096):
+        self.B, self.k, self.cap = B, k, min(cap, rdlib.RD_WNMS_MAX_K)
+        self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
+        self.L, self.A = lib, alloc
+        A, L = alloc, lib
+        self.dets = A.alloc(B * k * 12 * 4)
+        self.count = A.alloc(max(16, 4 * B), zero=True)
+        self.ws_f_bytes = L.raw("rd_score_filter_workspace_bytes")(k) * B
+        self.ws_f = A.alloc(self.ws_f_bytes)
+        self.ws_w_bytes = L.raw("rd_wnms_workspace_bytes")(self.cap) * B
+        self.ws_w = A.alloc(self.ws_w_bytes)
+        self.out = A.alloc(B * self.cap * 12 * 4)
+        self.keep = A.alloc(B * self.cap * 4)
+        self.nkeep = A.alloc(max(16, 4 * B), zero=True)
+        self.out8 = A.alloc(B * self.cap * 8 * 4)
+        self.identity = A.upload(np.arange(self.cap, dtype=np.int32))   # see PostProcessor: rows arrive sorted
+
+    def enqueue_filter(self, score_ptr, score_bs, box_ptr, box_bs, stream=None):
+        L, A = self.L, self.A
+        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
+        L.call("rd_score_filter_dets_batched", score_ptr, score_bs, box_ptr, box_bs, self.k, self.min_score, A.ptr(self.dets),
+               self.k * 12, A.ptr(self.count), A.ptr(self.ws_f), self.ws_f_bytes, self.B, st)
+
+    def enqueue_nms(self, stream=None):
+        L, A = self.L, self.A
+        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
+        L.call("rd_wnms_4c_batched", A.ptr(self.dets), self.k * 12, self.cap, A.ptr(self.count), A.ptr(self.identity), 0,
+               self.thr_lo, self.thr_hi, self.is3d, A.ptr(self.out), self.cap * 12, A.ptr(self.keep), self.cap,
+               A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, self.B, st)
+        L.call("rd_dets12_to_8_batched", A.ptr(self.out), self.cap * 12, self.cap, A.ptr(self.nkeep), A.ptr(self.out8),
+               self.cap * 8, self.B, st)
+
+    def collect(self, b=0):
+        A = self.A
+        A.sync()
+        K = int(A.to_numpy(A.view_i32(self.count, (self.B,)))[b])
+        M = int(A.to_numpy(A.view_i32(self.nkeep, (self.B,)))[b])
+        if K > self.cap:
+            raise rdlib.RangeDetError(rdlib.RD_EWORKSPACE, "%d detections above min_score exceed the WNMS capacity %d" % (K, self.cap))
+        rows = A.to_numpy(A.view_f32(self.out, (self.B, self.cap, 12)))[b, :M].copy()
+        keep = A.to_numpy(A.view_i32(self.keep, (self.B, self.cap)))[b, :M].copy()
+        d8 = A.to_numpy(A.view_f32(self.out8, (self.B, self.cap, 8)))[b, :M].copy()
+        return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
+
+
+class _FrameView:
+    """pipe.post[b]: frame b of the batched post-processor behind the single-frame PostProcessor interface."""
+
+    def __init__(self, bp, b):
+        self.bp, self.b = bp, b
+        self.cap = bp.cap
+
+    def collect(self):
+        return self.bp.collect(self.b)
+
+    def out_rows(self):
+        A = self.bp.A
+        return A.view_f32(self.bp.out, (self.bp.B, self.bp.cap, 12))[self.b]
+
+    def nkeep_view(self):
+        A = self.bp.A
+        return A.view_i32(self.bp.nkeep, (self.bp.B,))[self.b:self.b + 1]
+
+
 class RangeDetPipeline:
     def __init__(self, params, dtype=rdlib.RD_BF16, feat_size=(64, 2650), pad_field=(64, 2656), batch=1,
                  pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None):
@@ -91,8 +160,9 @@ class RangeDetPipeline:
         self.batch = batch
         self._post_stream = None
         self._filter_done = None
-        self.post = [PostProcessor(self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
-                                   TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap) for _ in range(batch)]
+        self.bpost = BatchPostProcessor(batch, self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
+                                        TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap)
+        self.post = [_FrameView(self.bpost, b) for b in range(batch)]
 
     def forward(self, inputs):
         """Graph outputs only: [rec_id, fg_cls_score (B,k), decoded_bbox (B,k,10), zeros, gt_bbox_imu, gt_class]."""
@@ -111,14 +181,14 @@ class RangeDetPipeline:
         sc, bx = outs[1], outs[2]
         if side:
             A.wait_event(A.record_event(), self._post_stream)
-        # all score filters first: they are what reads the graph's score / box buffers, so the next batch's forward only
-        # has to wait for these few short kernels, not for the weighted NMS of the frames queued before them
+        # one batched score filter (it is what reads the graph's score / box buffers: the next batch's forward only has
+        # to wait for these three short kernels), then one batched weighted NMS for all frames
         ptr = lambda t: self.alloc.ptr(t) if hasattr(t, "data_ptr") else t.ctypes.data
-        for b in range(self.batch):
-            self.post[b].enqueue_filter(ptr(sc[b]), ptr(bx[b]), stream=self._post_stream)
+        sc_bs = (ptr(sc[1]) - ptr(sc[0])) // 4 if self.batch > 1 else 0
+        bx_bs = (ptr(bx[1]) - ptr(bx[0])) // 4 if self.batch > 1 else 0
+        self.bpost.enqueue_filter(ptr(sc[0]), sc_bs, ptr(bx[0]), bx_bs, stream=self._post_stream)
         self._filter_done = A.record_event(self._post_stream) if side else None
-        for b in range(self.batch):
-            self.post[b].enqueue_nms(stream=self._post_stream)
+        self.bpost.enqueue_nms(stream=self._post_stream)
         return outs
 
     def run(self, inputs):

@@ -274,6 +274,55 @@ def test_score_filter_and_12to8(be):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_postprocess_batched(be):
+    """rd_score_filter_dets_batched + rd_wnms_4c_batched + rd_dets12_to_8_batched over 3 ragged frames (one of them with
+    nothing above the threshold) against the oracle frame by frame: counts, keep indices and merged rows bit-exact."""
+    L = be.lib
+    B, n, cap = 3, 700, 512
+    frames = [synth.cluster_dets(20, 9, seed=5), synth.cluster_dets(7, 30, seed=6, quant=True), synth.cluster_dets(4, 3, seed=7)]
+    sc = np.zeros((B, n), np.float32)
+    bx = np.zeros((B, n, 10), np.float32)
+    for b, d in enumerate(frames):
+        o = np.argsort(-d[:, 11], kind="stable")
+        d = d[o]
+        k = d.shape[0]
+        sc[b, :k] = d[:, 11] if b < 2 else 0.01          # frame 2: everything below min_score
+        bx[b, :k, :8] = d[:, :8]
+        bx[b, :k, 8] = d[:, 9]
+        bx[b, :k, 9] = d[:, 9] + d[:, 10]
+    fb = L.raw("rd_score_filter_workspace_bytes")(n) * B
+    wb = L.raw("rd_wnms_workspace_bytes")(cap) * B
+    dets, cnt, wsf, wsw = be.empty(B * n * 48), be.empty(16), be.empty(fb), be.empty(wb)
+    out, keep, nk, o8 = be.empty(B * cap * 48), be.empty(B * cap * 4), be.empty(16), be.empty(B * cap * 32)
+    ident = be.up(np.arange(cap, dtype=np.int32))
+    L.call("rd_score_filter_dets_batched", be.ptr(be.up(sc)), n, be.ptr(be.up(bx)), n * 10, n, 0.5, be.ptr(dets), n * 12,
+           be.ptr(cnt), be.ptr(wsf), fb, B, be.stream)
+    L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), be.ptr(ident), 0, 0.1, 0.5, 0, be.ptr(out), cap * 12,
+           be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+    L.call("rd_dets12_to_8_batched", be.ptr(out), cap * 12, cap, be.ptr(nk), be.ptr(o8), cap * 8, B, be.stream)
+    K = be.down(cnt, np.int32, (4,))[:B]
+    M = be.down(nk, np.int32, (4,))[:B]
+    rows = be.down(out, np.float32, (B, cap, 12))
+    kp = be.down(keep, np.int32, (B, cap))
+    d8 = be.down(o8, np.float32, (B, cap, 8))
+    alld = be.down(dets, np.float32, (B, n, 12))
+    for b in range(B):
+        ref = O.score_filter_to_dets(sc[b], bx[b], 0.5)
+        assert K[b] == ref.shape[0]
+        if K[b] == 0:
+            assert M[b] == 0
+            continue
+        got = alld[b, :K[b]]
+        flat, rk = O.wnms_4c(got, 0.1, 0.5, False, 100, order=np.arange(K[b], dtype=np.int32))
+        assert kp[b, :M[b]].tolist() == rk
+        assert np.array_equal(rows[b, :M[b]].view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
+        assert np.abs(d8[b, :M[b]] - O.bbox3d_12dim_to_8dim(rows[b, :M[b]])).max() < 1e-4
+    with pytest.raises(Exception):   # B > 1 needs an explicit order
+        L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), None, 0, 0.1, 0.5, 0, be.ptr(out), cap * 12,
+               be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_rotated_iou_8pt(be):
     b1 = synth.cluster_dets(8, 6, seed=3)[:, :8].copy()
     gt = synth.cluster_dets(8, 2, seed=3)[:, :8].copy()
