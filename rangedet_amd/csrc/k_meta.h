@@ -57,7 +57,9 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
         if (dt == RD_BF16) {
           for (int ks = 0; ks < 2; ++ks)
             for (int e = 0; e < 8; ++e) {
-              int j = 16 * ks + 8 * hi + e;
+              // hidden unit seen by B-operand element (ks, hi, e): the bf16 kernel computes the hidden layer with an
+              // MFMA whose D register r = 8*ks + e of lane (px, hi) is hidden unit (r&3) + 8*(r>>2) + 4*hi
+              int j = (e & 3) + 8 * (2 * ks + (e >> 2)) + 4 * hi;
               put(L.w1s, ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 8 + e, s * w1[ch * 32 + j]);
             }
         } else {
@@ -90,9 +92,18 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
       ft1[k * 64 + c] = t1[c * 9 + k];
     }
   float* fw0 = (float*)(base + L.w0p);
+  if (dt == RD_BF16) {
+    // A operands of the two v_mfma_f32_32x32x2_f32 that compute the hidden layer: row m = hidden unit m,
+    // k = (x, y | z, 1): instr 0 lane (m, hi) = W0[m][hi]; instr 1 lane (m, hi) = hi ? b0[m] : W0[m][2]
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lane & 31, hi = lane >> 5;
+      fw0[lane] = w0[m * 3 + hi];
+      fw0[64 + lane] = hi ? b0[m] : w0[m * 3 + 2];
+    }
+  } else
   for (int hi = 0; hi < 2; ++hi)
     for (int i = 0; i < 16; ++i) {
-      int j = dt == RD_BF16 ? 16 * (i >> 3) + 8 * hi + (i & 7) : 2 * i + hi;
+      int j = 2 * i + hi;
       fw0[(hi * 16 + i) * 4 + 0] = w0[j * 3 + 0];
       fw0[(hi * 16 + i) * 4 + 1] = w0[j * 3 + 1];
       fw0[(hi * 16 + i) * 4 + 2] = w0[j * 3 + 2];
@@ -298,6 +309,193 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
         memcpy(pk, tmp, sizeof(tmp));
 #pragma unroll
         for (int i = 0; i < (int)sizeof(T); ++i) *(Slot16*)(yp + ob + i * E::CH) = pk[i];
+      }
+    }
+  }
+}
+
+
+// ---- bf16 production kernel ----------------------------------------------------------------------------------------
+// Same math as meta_kernel<RD_BF16>, restructured so that the vector ALU is no longer the bottleneck:
+//   * the 3 -> 32 hidden layer runs on the matrix cores in exact fp32 (two v_mfma_f32_32x32x2_f32, k = x,y | z,1);
+//     its D layout IS the B operand of MFMA #1 (the hidden-unit permutation is baked into the packed W1);
+//   * the element-wise stage uses packed fp32 FMAs, packed bf16 conversion and an integer packed max as ReLU;
+//   * point coordinates come from an LDS halo (one coalesced fetch per tile instead of 27 global loads per pixel);
+//   * the next tile's data / coordinate halo is fetched into registers while the current tile is computed.
+// LDS: weights 108 KiB + constants 5.5 KiB + data halo 42.5 KiB + coordinate halo 4 KiB = 160 KiB, one workgroup per CU.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  constexpr int PXB = 128, SPP = 8, HC = 34, HR = WAVES + 2, NT = WAVES * 64;
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  constexpr size_t W1S_B = 9 * 2 * 2 * 64 * 16, A2_B = 9 * 2 * 2 * 2 * 64 * 16, WB = W1S_B + A2_B;
+  constexpr size_t CONST_B = 9 * 64 * 4 * 2 + 512 + 512;
+  unsigned char* lw = smem;
+  unsigned char* lc = smem + WB;
+  unsigned char* halo = lc + CONST_B;
+  float* chalo = (float*)(halo + HR * HC * PXB);  // [3][HR][HC]
+  const float* cb1 = (const float*)lc;            // [9][64]
+  const float* ct1 = cb1 + 9 * 64;                // [9][64]
+  const float* cw0 = ct1 + 9 * 64;                // [2][64] MFMA #0 A operands
+  const float* cs2 = cw0 + 2 * 16 * 4;            // [64] s2, [64] t2
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int px = lane & 31, hi = lane >> 5;
+
+  for (size_t i = tid; i < WB / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)a.packed)[i];
+  for (size_t i = tid; i < CONST_B / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + WB))[i];
+  const unsigned char* w1s = lw;
+  const unsigned char* a2w = lw + W1S_B;
+  const bf16_t* data = (const bf16_t*)a.data;
+  bf16_t* yout = (bf16_t*)a.y;
+  const long HW = (long)a.H * a.W;
+
+  // halo prefetch registers: data slots idx = u*NT + tid (u < DU), coordinate floats idx = u*NT + tid (u < CU)
+  constexpr int DITEMS = HR * HC * SPP, DU = (DITEMS + NT - 1) / NT;
+  constexpr int CITEMS = 3 * HR * HC, CU = (CITEMS + NT - 1) / NT;
+  Slot16 dreg[DU];
+  float creg[CU];
+  auto fetch = [&](int tile) {
+    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
+    const int h0 = th * WAVES, w0 = tw * 32;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
+      const int r = pl / HC, c = pl - r * HC;
+      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      dreg[u] = Slot16{0u, 0u, 0u, 0u};
+      if (idx < DITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        dreg[u] = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int idx = u * NT + tid, ch = idx / (HR * HC), pl = idx - ch * (HR * HC);
+      const int r = pl / HC, c = pl - r * HC;
+      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      creg[u] = 0.f;                              // im2col zero padding: outside the image the coordinate is 0
+      if (idx < CITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        creg[u] = a.coord[((size_t)b * 3 + ch) * HW + (long)ih * a.W + iw];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
+      if (idx < DITEMS) *(Slot16*)(halo + pl * PXB + ((s ^ ((pl >> 1) & 7)) << 4)) = dreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int idx = u * NT + tid;
+      if (idx < CITEMS) chalo[idx] = creg[u];
+    }
+  };
+
+  const f32x2* a0p = (const f32x2*)nullptr;
+  (void)a0p;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) fetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
+    const int h0 = th * WAVES, w0 = tw * 32;
+    __syncthreads();          // every wave is done with the previous tile's halos (and the weights are in place)
+    commit();
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);   // in flight during this tile's math
+
+    const int h = h0 + wv, w = w0 + px;
+    const bool live = (h < a.H) && (w < a.W);
+    const int cpl = (wv + 1) * HC + (px + 1);
+    const float c0 = chalo[cpl], c1 = chalo[HR * HC + cpl], c2 = chalo[2 * HR * HC + cpl];
+    const float a0 = cw0[lane], a1 = cw0[64 + lane];
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+      const int dh = k / 3 - 1, dw = k % 3 - 1;
+      const int pl = (wv + 1 + dh) * HC + (px + 1 + dw);
+      const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
+      // MFMA #0 (exact fp32): pre[j][px] = W0[j][0..2] . rel + b0[j]
+      f32x16 pre;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pre[r] = 0.f;
+      pre = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, hi ? r1 : r0, pre, 0, 0, 0);
+      pre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, hi ? 1.0f : r2, pre, 0, 0, 0);
+      // MFMA #1: D1[ch][px] = (s1 W1)[ch][:] . relu(pre)[:] + s1*b1
+      f32x16 d1[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *(const f32x4*)(cb1 + k * 64 + 32 * mt + 16 * hi + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d1[mt][4 * g + e] = bq[e];
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned v = f32x2_to_bf16x2(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
+          // ReLU on the packed pair: as signed 16-bit integers negative bf16 values are negative
+          pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+        }
+        s16x8 bfrag;
+        memcpy(&bfrag, pk, 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const s16x8 af = *(const s16x8*)(w1s + ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 16);
+          d1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, d1[mt], 0, 0, 0);
+        }
+      }
+      // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
+      const unsigned char* hp = halo + pl * PXB;
+      const int swz = (pl >> 1) & 7;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const Slot16 dv = *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+          const f32x4 t0 = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2);
+          const f32x4 t1v = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2 + 4);
+          unsigned pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 x2 = {__uint_as_float(dv[e] << 16), __uint_as_float(dv[e] & 0xffff0000u)};
+            const f32x2 w2 = {d1[mt][8 * s2 + 2 * e], d1[mt][8 * s2 + 2 * e + 1]};
+            const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
+            const f32x2 v2 = x2 * w2 + b2;
+            const unsigned v = f32x2_to_bf16x2(v2[0], v2[1]);
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+          }
+          s16x8 bfrag;
+          memcpy(&bfrag, pk, 16);
+          // MFMA #2: acc2[o][px] += A[o][(ch,k)] . a[ch]
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot) {
+            const s16x8 af = *(const s16x8*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 2 + s2) * 64 + lane) * 16);
+            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
+    if (live) {
+      bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int ob = 32 * ot + 16 * hi;
+        unsigned pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          pk[r >> 1] = f32x2_to_bf16x2(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
+                                       fmaxf(acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1], 0.f));
+        *(Slot16*)(yp + ob) = Slot16{pk[0], pk[1], pk[2], pk[3]};
+        *(Slot16*)(yp + ob + 8) = Slot16{pk[4], pk[5], pk[6], pk[7]};
       }
     }
   }

@@ -208,9 +208,9 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   const size_t consts = 9 * 64 * 4 * 2 + 1024;
   ProfScope ps(RD_PROF_META, st);
   if (dtype == RD_BF16) {
-    const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128;
-    allow_big_lds(meta_kernel<RD_BF16, WAVES>);
-    hipLaunchKernelGGL((meta_kernel<RD_BF16, WAVES>), dim3(std::min(a.ntiles, 256)), dim3(WAVES * 64), lds, st, a);
+    const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
+    allow_big_lds(meta_bf16_kernel<WAVES>);
+    hipLaunchKernelGGL((meta_bf16_kernel<WAVES>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
   } else {
     const size_t lds = consts + (size_t)(WAVES + 2) * 34 * 256;
     allow_big_lds(meta_kernel<RD_F32, WAVES>);
