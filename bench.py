@@ -28,26 +28,31 @@ PEAK_HBM_GBPS = 8000.0
 MAX_DET = 200               # rpn_post_nms_top_n / padded gather rows (config:139)
 
 
-def conv_flops(plan):
+def is_conv3(s):
+    """Plan steps served by the persistent 3x3 stride-1 bf16 kernel (csrc/k_conv3.h conv3_eligible)."""
+    return s["kind"] == "conv" and tuple(s["k"]) == (3, 3) and s["stride_w"] == 1
+
+
+def conv_flops(plan, only_conv3=False):
     """Algorithmic FLOPs of the conv-family launches of one frame, and the number of launches (from the lowered plan)."""
     fl, n = 0.0, 0
     for s in plan.steps:
-        if s["kind"] == "conv":
+        if s["kind"] == "conv" and (not only_conv3 or is_conv3(s)):
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
             n += 1
-        elif s["kind"] == "deconv":
+        elif s["kind"] == "deconv" and not only_conv3:
             # every output pixel sums kh*kw/stride taps
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1] / s["stride_w"]
             n += s["stride_w"]
     return fl, n
 
 
-def conv_bytes(plan, esz):
+def conv_bytes(plan, esz, only_conv3=False):
     """Algorithmic HBM bytes of the conv-family launches of one frame: every layer reads its input once, writes its
     output once, reads its residual once (BN/ReLU/add fused), weights once (SURVEY.md section 8d bytes model)."""
     by = 0.0
     for s in plan.steps:
-        if s["kind"] in ("conv", "deconv"):
+        if s["kind"] in ("conv", "deconv") and (not only_conv3 or is_conv3(s)):
             x, o = s["x"], s["out"]
             by += (x.H * x.W * s["cin"] + o.H * o.W * s["cout"]) * esz
             if s.get("res") is not None:
@@ -163,19 +168,26 @@ def main():
         torch.cuda.synchronize(dev)
         prof = L.prof()
         L.call("rd_prof_enable", 0)
-        fl, nlaunch = conv_flops(pipe.plan)
-        ms, cnt = prof["conv"]
+        bf = dt == rdlib.RD_BF16
+        # dominant kernel: bf16 = the persistent 3x3 stride-1 kernel (own profiling kind); f32 = the generic tap kernel
+        fl, nlaunch = conv_flops(pipe.plan, only_conv3=bf)
+        ms, cnt = prof["conv3" if bf else "conv"]
         avg_ms = ms / max(cnt, 1)
         achieved = (fl * Bf / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0   # a launch covers the Bf frames of the batch
-        roof = {"kernel": "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
-                "achieved": achieved, "peak": PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3, "unit": "TFLOP/s",
-                "frac": achieved / (PEAK_BF16_TFLOPS if dt == rdlib.RD_BF16 else 157.3),
-                "traffic": measured_traffic("conv_taps_kernel", Bf) if dt == rdlib.RD_BF16 else None,
+        fl_all, n_all = conv_flops(pipe.plan)
+        ms_all = prof["conv"][0] + prof["conv3"][0]
+        roof = {"kernel": "conv3x3_stream_kernel (persistent 3x3 stride-1 implicit-GEMM conv + BN + ReLU + residual)" if bf
+                else "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
+                "achieved": achieved, "peak": PEAK_BF16_TFLOPS if bf else 157.3, "unit": "TFLOP/s",
+                "frac": achieved / (PEAK_BF16_TFLOPS if bf else 157.3),
+                "traffic": measured_traffic("conv3x3_stream_kernel", Bf) if bf else None,
                 "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes of "
                                 "this command (profiles/r01_pmc_traffic.json)",
-                "algorithmic_bytes_per_launch": conv_bytes(pipe.plan, 2 if dt == rdlib.RD_BF16 else 4) * Bf / nlaunch,
+                "algorithmic_bytes_per_launch": conv_bytes(pipe.plan, 2 if bf else 4, only_conv3=bf) * Bf / nlaunch,
                 "launches_per_step": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_launch": fl * Bf / nlaunch / 1e9,
-                "gflop_per_frame": fl / 1e9}
+                "share_of_conv_flops": fl / fl_all,
+                "all_conv_family": {"launches_per_step": n_all, "gflop_per_frame": fl_all / 1e9,
+                                    "tflops": fl_all * Bf * nprof / (ms_all * 1e-3) / 1e12 if ms_all else 0.0}}
         mms, mcnt = prof["meta"]
         esz = 2 if dt == rdlib.RD_BF16 else 4
         mbytes = Bf * 64 * 2656 * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)

@@ -177,7 +177,8 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
 #define RD_PROF_DECODE 4
 #define RD_PROF_WNMS 5
 #define RD_PROF_LAYOUT 6
-#define RD_PROF_NKINDS 7
+#define RD_PROF_CONV3 7 /* the persistent 3x3 stride-1 bf16 kernel (its launches are NOT counted in RD_PROF_CONV) */
+#define RD_PROF_NKINDS 8
 int rd_prof_enable(int on);
 int rd_prof_reset(void);
 /* synchronises the recorded events; total_ms / launches per kind */

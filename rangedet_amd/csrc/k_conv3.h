@@ -425,7 +425,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + 3) / 4; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus());
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
-  ProfScope ps(RD_PROF_CONV, st);
+  ProfScope ps(RD_PROF_CONV3, st);
   static const int dbg = getenv("RD_CONV3_DBG") ? atoi(getenv("RD_CONV3_DBG")) : 0;
 #define C3_DBG_CASE(D) else if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); }
   if (false) {}

@@ -14,7 +14,7 @@ RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
 RD_F32, RD_BF16 = 0, 1
 RD_RELU_PRE, RD_ADD, RD_RELU_POST = 1, 2, 4
 RD_WNMS_MAX_K = 16384
-PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6}
+PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "librangedet_hip.so")
