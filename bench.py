@@ -29,8 +29,9 @@ MAX_DET = 200               # rpn_post_nms_top_n / padded gather rows (config:13
 
 
 def is_conv3(s):
-    """Plan steps served by the persistent 3x3 stride-1 bf16 kernel (csrc/k_conv3.h conv3_eligible)."""
-    return s["kind"] == "conv" and tuple(s["k"]) == (3, 3) and s["stride_w"] == 1
+    """Plan steps served by the persistent 3x3 bf16 kernel (csrc/k_conv3.h conv3_eligible): stride 1, and stride 2 computed as
+    stride 1 with only the even columns stored (the roofline counts the ALGORITHMIC flops of the strided conv)."""
+    return s["kind"] == "conv" and tuple(s["k"]) == (3, 3)
 
 
 def conv_flops(plan, only_conv3=False):
@@ -40,7 +41,7 @@ def conv_flops(plan, only_conv3=False):
         if s["kind"] == "conv" and (not only_conv3 or is_conv3(s)):
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
             n += 1
-        elif s["kind"] == "deconv" and not only_conv3:
+        elif s["kind"] == "deconv":   # bf16: every phase runs on the persistent kernel too (3x3 tap embedding)
             # every output pixel sums kh*kw/stride taps
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1] / s["stride_w"]
             n += s["stride_w"]
@@ -52,7 +53,7 @@ def conv_bytes(plan, esz, only_conv3=False):
     output once, reads its residual once (BN/ReLU/add fused), weights once (SURVEY.md section 8d bytes model)."""
     by = 0.0
     for s in plan.steps:
-        if s["kind"] in ("conv", "deconv") and (not only_conv3 or is_conv3(s)):
+        if s["kind"] == "deconv" or (s["kind"] == "conv" and (not only_conv3 or is_conv3(s))):
             x, o = s["x"], s["out"]
             by += (x.H * x.W * s["cin"] + o.H * o.W * s["cout"]) * esz
             if s.get("res") is not None:
@@ -176,7 +177,7 @@ def main():
         achieved = (fl * Bf / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0   # a launch covers the Bf frames of the batch
         fl_all, n_all = conv_flops(pipe.plan)
         ms_all = prof["conv"][0] + prof["conv3"][0]
-        roof = {"kernel": "conv3x3_stream_kernel (persistent 3x3 stride-1 implicit-GEMM conv + BN + ReLU + residual)" if bf
+        roof = {"kernel": "conv3x3_stream_kernel (persistent 3x3 implicit-GEMM conv / transposed-conv phase + BN + ReLU + residual)" if bf
                 else "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS if bf else 157.3, "unit": "TFLOP/s",
                 "frac": achieved / (PEAK_BF16_TFLOPS if bf else 157.3),

@@ -398,7 +398,7 @@ inline unsigned long long* conv_trace_buf() {
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, hipStream_t st);
+                        int cout, int flags, int sw, hipStream_t st);
 
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,
@@ -432,7 +432,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
   if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
-    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, st);
+    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st);
   // Workgroup = NW rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile).
   // cout 128: 8 waves, one WG per CU, 4-deep weight ring -- unless the halo is too big (stride 2: 129 columns);
   // otherwise 4 waves, 3-deep ring (two WGs per CU when the halo allows).

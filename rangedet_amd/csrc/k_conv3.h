@@ -31,6 +31,7 @@ struct Conv3Args {
   bf16_t* y; int y_cs, y_co; long y_bs;
   const unsigned char* zero16;  // 16 zero bytes in device memory: DMA source of padding pixels / channels
   int H, W, B, nslots, nchunk, flags, ncol, nrow, ntiles;
+  int sw, Wo;   // column stride (1 or 2) and output width: a stride-2 conv is the stride-1 conv with only the even columns stored
   unsigned long long* trace;
 };
 
@@ -291,8 +292,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     asm volatile("" : "+v"(em), "+v"(ehi), "+v"(el));
     constexpr int ROWB = COUT * 2, SPR = COUT / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + (C3_HALO - abuf) + wave * 12288;
-    bf16_t* __restrict__ yrow = a.y + (size_t)b * a.y_bs + (size_t)oh * a.W * a.y_cs + a.y_co;
-    const bf16_t* __restrict__ rrow = a.res + (size_t)b * a.r_bs + (size_t)oh * a.W * a.r_cs + a.r_co;
+    bf16_t* __restrict__ yrow = a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wo * a.y_cs + a.y_co;
+    const bf16_t* __restrict__ rrow = a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wo * a.r_cs + a.r_co;
+    const int sh = a.sw - 1;   // stride 2: shift by 1, keep even columns
     // FL >= 0: the flag combination is a compile-time constant (no per-value selects); FL < 0: read a.flags
     auto epilogue = [&](auto FL) {
       constexpr int F = decltype(FL)::value;
@@ -303,8 +305,8 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       Slot16 rv[2][NCT][2];
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
         const int tc = 32 * i + em, ow = ct * C3_TW + tc;
-        const bool live = tc < C3_TW && ow < a.W && oh < a.H;
-        const bf16_t* rp = rrow + (live ? (size_t)ow * a.r_cs : 0) + 16 * ehi;
+        const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh);
+        const bf16_t* rp = rrow + (live ? (size_t)(ow >> sh) * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           dst[j][0] = *(const Slot16*)(rp + j * 32);
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
           const int pr = it * RPI + el / SPR, sl = el % SPR;
           const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
           const int tcs = 32 * i + pr, ows = ct * C3_TW + tcs;
-          if (tcs < C3_TW && ows < a.W && oh < a.H && (!(DBG & 1) || a.B < 0)) *(Slot16*)(yrow + (size_t)ows * a.y_cs + sl * 8) = v;
+          if (tcs < C3_TW && ows < a.W && oh < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
+            *(Slot16*)(yrow + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
         }
         __builtin_amdgcn_wave_barrier();
         C3_FENCE();
@@ -403,7 +406,8 @@ inline int conv_num_cus() {
 }
 
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout) {
-  if (dt != RD_BF16 || tl.n != 9 || in_stride != 1 || out_stride != 1 || Wq != Win || Wout != Win) return false;
+  if (dt != RD_BF16 || tl.n != 9 || (in_stride != 1 && in_stride != 2) || out_stride != 1) return false;
+  if (Wq != (Win - 1) / in_stride + 1 || Wout != Wq) return false;   // pad 1, kernel 3
   if (cout != 64 && cout != 128) return false;
   for (int t = 0; t < 9; ++t)
     if (tl.dh[t] != t / 3 - 1 || tl.dw[t] != t % 3 - 1) return false;
@@ -412,13 +416,14 @@ inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int
 
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, hipStream_t st) {
+                        int cout, int flags, int sw, hipStream_t st) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
+  a.sw = sw; a.Wo = (W - 1) / sw + 1;
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
   a.w = (const unsigned char*)w; a.scale = scale; a.shift = shift;
-  a.res = (const bf16_t*)res; a.r_cs = r_cs; a.r_co = r_co; a.r_bs = (long)H * W * r_cs;
-  a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * W * y_cs;
+  a.res = (const bf16_t*)res; a.r_cs = r_cs; a.r_co = r_co; a.r_bs = (long)H * a.Wo * r_cs;
+  a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * a.Wo * y_cs;
   a.zero16 = conv_zero16();
   RD_REQUIRE(a.zero16, RD_EHIP, "conv: zero page allocation failed");
   a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;

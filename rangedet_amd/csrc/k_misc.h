@@ -23,6 +23,24 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     dst[(b * HW + p) * cs + coff + c] = E::from_f32(v);
   }
 }
+// few channels (the 8-channel range image): one thread per pixel gathers its channels (plane reads stay coalesced across
+// the threads) and writes them as whole 16-byte slots -- the per-element kernel above writes 2 bytes per thread.
+template <int DT, int NSLOT>   // NSLOT 16-byte slots = C + zero padding
+__global__ __launch_bounds__(256) void nchw_to_nhwc_px_kernel(const float* __restrict__ src, void* __restrict__ dst_, int C,
+                                                              long HW, int cs, int coff, long npix) {
+  using E = Elem<DT>;
+  typename E::T* dst = (typename E::T*)dst_;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const long b = i / HW, p = i - b * HW;
+    typename E::T v[NSLOT * E::CH];
+#pragma unroll
+    for (int c = 0; c < NSLOT * E::CH; ++c) v[c] = E::from_f32(c < C ? src[(b * C + c) * HW + p] : 0.f);
+    Slot16 pk[NSLOT];
+    memcpy(pk, v, sizeof(pk));
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) *(Slot16*)(dst + i * cs + coff + u * E::CH) = pk[u];
+  }
+}
 template <int DT>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src_, float* __restrict__ dst, int C,
                                                            long HW, int cs, int coff, long total) {

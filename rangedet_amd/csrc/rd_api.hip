@@ -64,6 +64,18 @@ int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int
   const long HW = (long)H * W, total = (long)B * (C + zero_pad) * HW;
   const int grid = (int)std::min<long>((total + 255) / 256, 8192);
   ProfScope ps(RD_PROF_LAYOUT, st);
+  {  // few channels, slot-aligned destination: pixel-per-thread variant with 16-byte stores
+    const int ch = ch_per_slot(dst_dtype), ctot = C + zero_pad;
+    if ((dst_dtype == RD_BF16 || dst_dtype == RD_F32) && ctot % ch == 0 && ctot / ch <= 2 && dst_cstride % ch == 0 && dst_coff % ch == 0) {
+      const long npix = (long)B * HW;
+      const int g2 = (int)std::min<long>((npix + 255) / 256, 8192);
+#define RD_PX(DT, NS) hipLaunchKernelGGL((nchw_to_nhwc_px_kernel<DT, NS>), dim3(g2), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, npix)
+      if (dst_dtype == RD_BF16) { if (ctot / ch == 1) RD_PX(RD_BF16, 1); else RD_PX(RD_BF16, 2); }
+      else { if (ctot / ch == 1) RD_PX(RD_F32, 1); else RD_PX(RD_F32, 2); }
+#undef RD_PX
+      return check_launch("nchw_to_nhwc");
+    }
+  }
   if (dst_dtype == RD_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_BF16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
   else if (dst_dtype == RD_F32)
@@ -102,10 +114,19 @@ int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, 
   else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }
+// A phase whose taps all lie inside the 3x3 window (every transposed conv of the RangeDet graph) is packed and run as a
+// 3x3 tap list with zero weights for the absent taps: the persistent 3x3 kernel then serves it, writing the phase's pixels
+// of the output viewed as [H][Win][stride_w * Cstride].
+static bool deconv_embeds_3x3(const TapList& tl) {
+  for (int t = 0; t < tl.n; ++t)
+    if (tl.dh[t] < -1 || tl.dh[t] > 1 || tl.dw[t] < -1 || tl.dw[t] > 1) return false;
+  return tl.n >= 1 && tl.n <= 9;
+}
 int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase) {
   if (stride_w < 1 || phase < 0 || phase >= stride_w) return RD_EINVAL;
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
-  return tl.n > 9 ? RD_ESHAPE : tl.n;
+  if (tl.n > 9) return RD_ESHAPE;
+  return deconv_embeds_3x3(tl) ? 9 : tl.n;
 }
 int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
                                int phase, int dtype, void* out) {
@@ -114,9 +135,20 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
   RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
-  auto get = [&](int co, int ci, int t) { return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
-  if (dtype == RD_BF16) pack_taps_frag(tl.n, cin, cout, out, get);
-  else pack_taps(tl.n, cin, cout, dtype, out, get);
+  const bool emb = deconv_embeds_3x3(tl);
+  auto get = [&](int co, int ci, int t) -> float {
+    if (emb) {  // t indexes the 3x3 window (dh, dw) = (t/3 - 1, t%3 - 1): the phase's tap there, or zero
+      int src = -1;
+      for (int u = 0; u < tl.n; ++u)
+        if (tl.dh[u] == t / 3 - 1 && tl.dw[u] == t % 3 - 1) src = u;
+      if (src < 0) return 0.f;
+      t = src;
+    }
+    return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
+  };
+  const int nt = emb ? 9 : tl.n;
+  if (dtype == RD_BF16) pack_taps_frag(nt, cin, cout, out, get);
+  else pack_taps(nt, cin, cout, dtype, out, get);
   return RD_OK;
 }
 
@@ -150,6 +182,16 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "deconv2d: %d taps per phase unsupported", tl.n);
   allow_conv_lds();
+  if (deconv_embeds_3x3(tl)) {
+    tl = conv_taps(3, 3);   // the weights were packed as a 3x3 window (rd_pack_deconv_weight_host)
+    if (dtype == RD_BF16 && Wout == stride_w * Win && (cout == 64 || cout == 128) && getenv("RD_CONV_V1") == nullptr) {
+      // phase pixels of the output seen as [H][Win][stride_w * Cstride]: channel offset phase * Cstride
+      const bf16_t* r = (const bf16_t*)residual;
+      return launch_conv3(x, x_cstride, x_coff, w_packed_phase, scale, shift, r, r_cstride * stride_w,
+                          r_coff + phase * r_cstride, y, y_cstride * stride_w, y_coff + phase * y_cstride, B, H, Win, cin,
+                          cout, flags, 1, (hipStream_t)stream);
+    }
+  }
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
                      y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
                      (hipStream_t)stream);

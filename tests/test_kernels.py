@@ -147,6 +147,19 @@ def test_head_out_and_layout(be, dt):
     back = be.empty(B * H * W * C * 4)
     L.call("rd_nhwc_to_nchw", be.ptr(xin), be.ptr(back), B, C, H, W, C, 0, dt, be.stream)
     assert np.array_equal(be.down(back, np.float32, (B, C, H, W)), x)
+    # few channels into a wider zero-padded buffer (the 8-channel range image next to the 64 agg channels: lower.py concat)
+    x8 = x[:, :8].copy()
+    cs, co, pad = 80, 16, 8 if dt == BF16 else 0
+    esz = 2 if dt == BF16 else 4
+    wide = be.up(np.full(B * H * W * cs * esz, 0x5A, np.uint8))
+    L.call("rd_nchw_to_nhwc", be.ptr(be.up(x8)), be.ptr(wide), B, 8, H, W, cs, co, pad, dt, be.stream)
+    got = be.down(wide, np.uint16 if dt == BF16 else np.float32, (B, H, W, cs))
+    ref8 = np.transpose(x8, (0, 2, 3, 1))
+    if dt == BF16:
+        assert np.array_equal(got[..., co:co + 8], (ref8.view(np.uint32) >> 16).astype(np.uint16))
+        assert not got[..., co + 8:co + 16].any() and (got[..., :co] == 0x5A5A).all() and (got[..., co + 16:] == 0x5A5A).all()
+    else:
+        assert np.array_equal(got[..., co:co + 8], ref8)
     N = H * W + 50
     for nout in (1, 7, 8):
         w = (rng.standard_normal((nout, C)) * 0.1).astype(np.float32)
