@@ -1,20 +1,25 @@
-// Implicit-GEMM convolution over channels-last range images for gfx950 (MFMA), with the BatchNorm affine,
+// Generic implicit-GEMM convolution over channels-last range images for gfx950 (MFMA), with the BatchNorm affine,
 // ReLU and residual add fused into the epilogue.  One kernel serves every conv-shaped layer of the RangeDet
 // graph through a *tap list*:  y[h, q*out_stride+out_off, co] = sum_t sum_ci x[h+dh_t, q*in_stride+dw_t, ci] * W_t[ci][co]
 //   3x3 / 1x1 convs, stride (1,1) or (1,2)        dla_backbone.py:18-56, head/builder.py:221-240 (reference)
 //   transposed convs k(3,8)s(1,4) / k(3,4)s(1,2)  dla_backbone.py:117-127  -> one launch per output phase
+// It runs the whole graph in fp32 (the parity mode) and, in bf16, what the persistent 3x3 kernel (k_conv3.h) does not
+// take: the 1x1 convs.
 //
-// Work decomposition (wave64, 256-thread workgroups):
-//   workgroup tile = RO output rows x 64 output columns x all Cout; each wave owns 64 px (one row, two 32-px
-//   MFMA tiles) x 64 output channels (two 32-wide tiles) -> 4 accumulators of 32x32.
-//   The input halo tile (RO+2 rows x 66 columns x one 128-byte k-chunk) is staged ONCE per k-chunk in LDS and
-//   re-read by all taps (9x reuse for a 3x3); the per-(chunk,tap) weight slab [Cout][128 B] is double-buffered
-//   in LDS (global loads issued before the MFMA block, LDS write after it).
+// Work decomposition (wave64, 256-thread workgroups, two per CU):
+//   workgroup tile = 4 output rows x 64 output columns x 64 output channels (Cout = 128: two channel-half workgroups
+//   per pixel tile, adjacent in the XCD-aware tile order); each wave owns one row = two 32-px MFMA tiles x two 32-channel
+//   tiles -> 4 accumulators of 32x32.
+//   The input halo tile (6 rows x 66 columns x one 128-byte k-chunk for a 3x3) is staged ONCE per k-chunk in LDS
+//   (global -> registers -> LDS) and re-read by all taps; the per-(chunk,tap) weight slab [64 Cout][128 B] arrives by
+//   LDS-DMA into a 3-deep ring (8-deep for launches with few workgroups) with counted s_waitcnt vmcnt(N) and a raw
+//   s_barrier per step -- see the comments at RD_LDS_BARRIER for why not __syncthreads().
 //   LDS rows are 128 B (= 8 slots of 16 B = 64 bf16 / 32 f32 channels); slot index is XOR-swizzled with
 //   ((row>>1)&7) so the 16-lane groups of ds_read_b128 hit 16 distinct slots (conflict-free for stride-1 pixels).
 //   MFMA operands: lanes 0-31 read slot 2*ks, lanes 32-63 slot 2*ks+1 of their pixel / output channel:
 //     bf16: that IS the v_mfma_f32_32x32x16_bf16 fragment (k = 8*(lane>>5)+j);
 //     f32 : 4 x v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), element e of the slot pairs k = 4*(2ks+hi)+e.
+//   bf16 weights come packed in MFMA-fragment order (k_conv3.h pack_taps_frag); the slab fill gathers from it.
 #pragma once
 #include <cstdlib>
 
@@ -37,7 +42,6 @@ struct ConvArgs {
   int ncol;  // column tiles (64 output positions each)
   unsigned ci_magic;  // floor(2^32 / CI) + 1: px / CI == umulhi(px, ci_magic) for the px range of a halo tile
   unsigned long long* trace;  // dev tracing (tools/conv_trace.py): 8 timestamps per workgroup, or null
-  int dbg;  // tuning ablations (tools/conv_bench.py): 1 no epilogue stores, 2 one weight slab only, 4 one halo stage, 8 no MFMA
 };
 
 // weight row held by A-operand lane row mm, so that the D registers of a lane are 16 consecutive output channels
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   // registers around the loop and drains vmcnt(0) in every iteration.
   int step = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    if (chunk > 0 && !(a.dbg & 4)) {
+    if (chunk > 0) {
       RD_TRACE()
       RD_LDS_BARRIER();  // every wave is done with the previous chunk's halo tile
       a_stage(chunk);
@@ -213,13 +217,13 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
       else __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
     }
     RD_LDS_BARRIER();  // all parts of slab `step` (and a fresh halo tile) are in LDS; everyone is done with slab step-1
-    if (step + D < nsteps && !(a.dbg & 2)) w_fill(step + D);   // refill the slot slab step-1 just vacated
+    if (step + D < nsteps) w_fill(step + D);   // refill the slot slab step-1 just vacated
 
     const int ns_c = min(8, a.nslots - 8 * chunk);
     const int tdh = (int)((a.dh_pack >> (4 * tap)) & 15) - 8, tdw = (int)((a.dw_pack >> (4 * tap)) & 15) - 8;
     const int delta = (tdh - a.min_dh) * a.CI + (tdw - a.min_dw);   // wave-uniform halo-pixel shift of this tap
     int a0[2], bw[2];
-    const int slab_off = (a.RI * a.CI + ((a.dbg & 2) ? 0 : (step % RING)) * (SLAB / 128)) << 7;  // ring slot, bytes from smem
+    const int slab_off = (a.RI * a.CI + (step % RING) * (SLAB / 128)) << 7;  // ring slot, bytes from smem
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int px = pbase[i] + delta;
@@ -256,9 +260,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][e], av[i][e], acc[i][j], 0, 0, 0);
       }
     };
-    if (!(a.dbg & 8)) {
-      for (int ks = 0; ks < (ns_c >> 1); ++ks) kstep(ks);
-    }
+    for (int ks = 0; ks < (ns_c >> 1); ++ks) kstep(ks);
    }
   }
 #undef RD_LDS_BARRIER
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
             out[r] = E::from_f32(v);
           }
         }
-        if (live && !(a.dbg & 1)) {
+        if (live) {
           Slot16 pk[SPT];
           memcpy(pk, out, sizeof(out));
 #pragma unroll
@@ -423,7 +425,6 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   a.H = H; a.Win = Win; a.Wq = Wq; a.Wout = Wout;
   a.nslots = cin_slots(cin, dt); a.cout = cout; a.ntaps = tl.n;
   a.in_stride = in_stride; a.out_stride = out_stride; a.out_off = out_off; a.flags = flags;
-  { const char* e = getenv("RD_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
   int mndh = 99, mxdh = -99, mndw = 99, mxdw = -99;
   for (int t = 0; t < tl.n; ++t) {
     a.dh_pack |= (unsigned long long)(tl.dh[t] + 8) << (4 * t);
@@ -433,12 +434,10 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   }
   if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
     return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st);
-  // Workgroup = NW rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile).
-  // cout 128: 8 waves, one WG per CU, 4-deep weight ring -- unless the halo is too big (stride 2: 129 columns);
-  // otherwise 4 waves, 3-deep ring (two WGs per CU when the halo allows).
-  int RO = (cout == 128 && getenv("RD_CONV_RO8")) ? 8 : 4;
-  int mxw = (mxdw - mndw);
-  if (RO == 8 && (size_t)(8 + mxdh - mndh) * (63 * in_stride + mxw + 1) * 128 + 4 * 64 * 128 + 512 > 160 * 1024) RO = 4;
+  // Workgroup = 4 rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile),
+  // 4 waves, 3-deep weight ring, two workgroups per CU when the halo allows.
+  constexpr int RO = 4;
+  const int mxw = (mxdw - mndw);
   a.min_dh = mndh; a.min_dw = mndw;
   a.RI = RO + (mxdh - mndh);
   a.CI = 63 * in_stride + mxw + 1;
@@ -446,8 +445,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   const int nblocks = ((Wq + 63) / 64) * ((H + RO - 1) / RO) * (cout / 64);
   // few workgroups (low-resolution layers): at most one per CU anyway, so spend the idle LDS on a deeper weight ring --
   // such layers are a pure latency chain of (k-chunk, tap) steps and run at ring depth / L2 latency.
-  const bool deep = RO == 4 && nblocks * B <= 320 && halo + 8 * 64 * 128 + 512 <= 160 * 1024;
-  const int ring = RO == 8 ? 4 : (deep ? 8 : 3);
+  const bool deep = nblocks * B <= 320 && halo + 8 * 64 * 128 + 512 <= 160 * 1024;
+  const int ring = deep ? 8 : 3;
   const size_t lds = halo + (size_t)ring * 64 * 128 + 64 * 8;
   RD_REQUIRE(lds <= 160 * 1024, RD_ESHAPE, "conv: LDS tile %zu B too large", lds);
   a.ncol = (Wq + 63) / 64;
@@ -456,9 +455,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   if (conv_trace_buf() && (size_t)grid.x * B * 8 <= CONV_TRACE_CAP) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV, st);
 #define RD_LAUNCH_CONV(DT_)                                                                            \
-  if (RO == 4 && deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);  \
-  else if (RO == 4) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);    \
-  else hipLaunchKernelGGL((conv_taps_kernel<DT_, 8, 4>), grid, dim3(512), lds, st, a);
+  if (deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);             \
+  else hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);
   if (dt == RD_BF16) { RD_LAUNCH_CONV(RD_BF16) } else { RD_LAUNCH_CONV(RD_F32) }
 #undef RD_LAUNCH_CONV
   return check_launch("conv_taps_kernel");

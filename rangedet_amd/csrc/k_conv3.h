@@ -431,12 +431,13 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   const int grid = std::min(a.ntiles, conv_num_cus());
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);
+#ifdef RD_CONV3_DEV   // ablation variants (DBG bits: 2 no barrier, 4 no DMA after the prologue, 16 halo from the zero page, 32 no vmcnt wait)
   static const int dbg = getenv("RD_CONV3_DBG") ? atoi(getenv("RD_CONV3_DBG")) : 0;
-#define C3_DBG_CASE(D) else if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); }
-  if (false) {}
-  C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32) C3_DBG_CASE(34)
+#define C3_DBG_CASE(D) if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); return check_launch("conv3x3_stream_kernel"); }
+  C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
-  else if (cout == 128) hipLaunchKernelGGL((conv3x3_stream_kernel<4>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a);
+#endif
+  if (cout == 128) hipLaunchKernelGGL((conv3x3_stream_kernel<4>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a);
   else hipLaunchKernelGGL((conv3x3_stream_kernel<2>), dim3(grid), dim3(256), C3Cfg<2>::LDS, st, a);
   return check_launch("conv3x3_stream_kernel");
 }

@@ -12,7 +12,8 @@
 // per 32-channel block (wide LDS reads / global stores).
 //   workgroup = WAVES waves = WAVES rows x 32 columns, persistent over tiles; LDS: bf16 weights (108 KiB),
 //   per-tap constants, and the (WAVES+2) x 34 data halo (XOR-swizzled 16-byte slots).
-//   f32 variant (parity mode): same code, v_mfma_f32_32x32x2_f32, weights streamed from L2 (220 KiB > LDS).
+//   meta_kernel<RD_F32> (parity mode): v_mfma_f32_32x32x2_f32, hidden layer on the VALU, weights streamed from L2
+//   (220 KiB > LDS).  meta_bf16_kernel (production, end of this file): hidden layer on the matrix cores too.
 #pragma once
 #include "rd_common.h"
 
@@ -129,7 +130,8 @@ template <int DT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
   using E = Elem<DT>;
   using T = typename E::T;
-  constexpr bool BF = (DT == RD_BF16);
+  static_assert(DT == RD_F32, "bf16 runs meta_bf16_kernel (its packed W0 / W1 layouts differ); this is the fp32 parity kernel");
+  constexpr bool BF = false;   // (the bf16 branches below document the shared structure; they are not instantiated)
   constexpr int PXB = BF ? 128 : 256;  // bytes per pixel (64 channels)
   constexpr int SPP = PXB / 16;        // 16-byte slots per pixel
   constexpr int HC = 34;               // halo columns

@@ -42,10 +42,8 @@ inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<2>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 8, 4>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 8, 4>);
 }
 }  // namespace rd
 

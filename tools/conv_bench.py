@@ -1,5 +1,5 @@
 """Conv micro-benchmark on the GPU (tuning aid): selected layer shapes of the RangeDet graph, us + TFLOP/s.
-   RD_CONV_DBG=<bits> python tools/conv_bench.py"""
+   [B=<frames>] [ONLY=<substring>] python tools/conv_bench.py"""
 import os
 import sys
 
