@@ -10,7 +10,7 @@ DLA backbone + fused Meta-Kernel + 3-level heads + sigmoid/top-50000/sort + 3D b
 (config `rangedet_veh_wo_aug_4_18e`, bf16 activations/weights with fp32 accumulation; BASELINE configs[1] plus the WNMS
 of configs[2]).  Inputs are resident in HBM before the timed region.  Frames shard across ranks with no data-path
 collective (weak scaling); for N > 1 every step ends with the one RCCL all_gather of the padded detections
-(SURVEY.md 8e).  Rank 0 prints ONE JSON line.
+(SURVEY.md 8e), enqueued on the post-processing stream.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -107,8 +107,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    gather = world > 1 or bool(os.environ.get("RD_BENCH_GATHER"))   # the env switch exercises the collective path on one GPU
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -125,22 +129,24 @@ def main():
     L = pipe.lib
     REC = MAX_DET * 12 + 1
     gather_in = torch.zeros(Bf * REC, device=dev)
-    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
+    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if gather else None
     post = pipe.post[0]
     A = pipe.alloc
 
     def step(i):
         pipe.enqueue(frames[i % len(frames)])
-        if world > 1:
-            torch.cuda.current_stream().wait_stream(pipe._post_stream)   # the padded detections of this batch are final
-            for b, pp in enumerate(pipe.post):
-                gather_in[b * REC:(b + 1) * REC - 1].copy_(pp.out_rows()[:MAX_DET].reshape(-1))
-                gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(pp.nkeep_view().float())
-            dist.all_gather(gather_out, gather_in)                         # the ONE collective of the path
+        if gather:
+            # the ONE collective of the path, enqueued behind this batch's post-processing on the side stream: the next
+            # batch's forward (main stream) overlaps it, nothing on the main stream waits for it
+            with torch.cuda.stream(pipe._post_stream):
+                for b, pp in enumerate(pipe.post):
+                    gather_in[b * REC:(b + 1) * REC - 1].copy_(pp.out_rows()[:MAX_DET].reshape(-1))
+                    gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(pp.nkeep_view().float())
+                dist.all_gather(gather_out, gather_in)
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if gather:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -152,7 +158,7 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if gather:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -214,10 +220,13 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, {k: v[:1] for k, v in frames_np[0].items()})
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    if gather:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)   # after the process group is gone: RCCL prints its own banner lines at teardown
 
 
 if __name__ == "__main__":
