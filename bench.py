@@ -225,8 +225,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL writes a version banner through C stdio, which would otherwise be flushed at exit, AFTER this line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
-        print(line, flush=True)   # after the process group is gone: RCCL prints its own banner lines at teardown
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
