@@ -153,6 +153,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    if gather:   # RCCL prints a version banner through C stdio when the communicator comes up: get it out of the way now
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -229,6 +232,8 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
+        if world > 1:
+            time.sleep(1.0)   # let the other ranks' exit-time output drain first: this line should be the last one
         print(line, flush=True)
 
 
