@@ -18,6 +18,7 @@
  *   rd_dets12_to_8            bbox3d_12dim_to_8dim                                tools/test.py:43-53
  *   rd_rotated_iou_8pt        _contrib_RotatedIOU (8-point boxes)                 operator_cxx/contrib/rotated_iou-inl.h:509-547
  *   rd_batch_max_iou          Custom op 'batch_rotated_iou' ('bev')               operator_py/batch_rotated_iou.py:11-49
+ *   rd_input_transform        test-time input transform chain                     rangedet/core/input.py:14-42,89-229,522-624
  *
  * Conventions
  *   - every function returns an int status (RD_OK == 0, negative = error); nothing aborts or exits.
@@ -170,6 +171,25 @@ int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, lo
 /* per proposal: max over gt of the cleaned IoU (NaN/Inf/>1/<0 -> 0).  proposals (n, p_stride>=8) */
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt,
                      void* stream);
+
+/* ---- test-time input transform chain on the device (the step before the path) ----
+ * rangedet/core/input.py:14-42,89-229,522-624 (LoadRecord, ProcessMissValue, SepAndClipData, GetUnnormalizedRange,
+ * NormData, GetCoordinates, CombineData, PadData, TransposeData, GenerateFPNTarget, TransAndReshape) fused into one
+ * kernel: raw record arrays in, the graph's named float32 tensors out.
+ * Channel order of clip/mean/sd: range, intensity, elongation, x, y, z, inclination, azimuth (config:269-282; azimuth is
+ * not clipped).  sd = sqrt(var) as float.  Level l uses stride 2^l and keeps range in [interval_lo[l], interval_hi[l]). */
+typedef struct {
+  float clip_lo[7], clip_hi[7];
+  float mean[8], sd[8];
+  float interval_lo[3], interval_hi[3];
+} rd_input_norm_t;
+/* range_image (B,H,W,4), pc_vehicle_frame (B,H,W,3), inclination (B,H)  ->  input_data (B,8,Hp,Wp), coord_s1 (B,3,Hp,Wp),
+ * pc_vehicle_frame_s{1,2,4} (B,Hp*Wp/s,3), range_image_mask_s{1,2,4} (B,Hp*Wp/s); Hp >= H, Wp >= W, Wp % 4 == 0.
+ * norm_host is read on the host at call time. */
+int rd_input_transform(const float* range_image, const float* pc_vehicle_frame, const float* inclination,
+                       const rd_input_norm_t* norm_host, int B, int H, int W, int Hp, int Wp, float* input_data,
+                       float* coord_s1, float* pc_s1, float* pc_s2, float* pc_s4, float* mask_s1, float* mask_s2,
+                       float* mask_s4, void* stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline block) --------- */
 #define RD_PROF_CONV 0

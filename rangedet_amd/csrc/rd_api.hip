@@ -1,6 +1,7 @@
 // librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
 #include "k_conv3.h"
+#include "k_input.h"
 #include "k_meta.h"
 #include "k_misc.h"
 #include "k_riou.h"
@@ -411,6 +412,28 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
   RD_REQUIRE(n > 0 && n_gt > 0 && n_gt <= 256 && p_stride >= 8, RD_ESHAPE, "batch_max_iou: n_gt %d (<=256), p_stride %d (>=8)", n_gt, p_stride);
   hipLaunchKernelGGL(batch_max_iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, proposals, p_stride, gt8, out, n, n_gt);
   return check_launch("batch_max_iou");
+}
+
+// ---- input transform chain ----------------------------------------------------------------------------------------
+int rd_input_transform(const float* range_image, const float* pc_vehicle_frame, const float* inclination,
+                       const rd_input_norm_t* norm_host, int B, int H, int W, int Hp, int Wp, float* input_data,
+                       float* coord_s1, float* pc_s1, float* pc_s2, float* pc_s4, float* mask_s1, float* mask_s2,
+                       float* mask_s4, void* stream) {
+  RD_REQUIRE(range_image && pc_vehicle_frame && inclination && norm_host && input_data && coord_s1 && pc_s1 && pc_s2 && pc_s4 &&
+                 mask_s1 && mask_s2 && mask_s4, RD_EINVAL, "input_transform: null pointer");
+  RD_REQUIRE(B > 0 && H > 2 && W > 2 && Hp >= H && Wp >= W && Wp % 4 == 0, RD_ESHAPE,
+             "input_transform: shape (%d,%d,%d) -> (%d,%d)", B, H, W, Hp, Wp);
+  InputArgs a;
+  a.ri = range_image; a.pc = pc_vehicle_frame; a.incl = inclination;
+  a.data = input_data; a.coord = coord_s1;
+  a.pcs[0] = pc_s1; a.pcs[1] = pc_s2; a.pcs[2] = pc_s4;
+  a.msk[0] = mask_s1; a.msk[1] = mask_s2; a.msk[2] = mask_s4;
+  a.B = B; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
+  a.n = *norm_host;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(RD_PROF_LAYOUT, st);
+  hipLaunchKernelGGL(input_transform_kernel, dim3((unsigned)(((long)Hp * Wp + 255) / 256), B), dim3(256), 0, st, a);
+  return check_launch("input_transform");
 }
 
 // ---- profiling -------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ SIGNATURES = {
     "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "rd_batch_max_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "rd_input_transform": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "rd_prof_enable": (c_int, [c_int]),
     "rd_prof_reset": (c_int, []),
     "rd_prof_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_long)]),

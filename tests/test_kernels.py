@@ -287,6 +287,49 @@ def test_score_filter_and_12to8(be):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_input_transform(be):
+    """rd_input_transform against the numpy restatement of the reference's transform chain (synth.transform; parity
+    unpinned: the reference chain needs mxnet/numba to import).  Everything is selection / copy / one IEEE subtract and
+    divide, hence bit-exact, except the azimuth channel (atan2f)."""
+    from rangedet_amd.input_transform import make_norm
+    import ctypes
+    L = be.lib
+    H, W, Hp, Wp = 9, 53, 12, 56
+    recs = [synth.raw_record(i, H, W) for i in (3, 4)]
+    for r in recs:   # make the wrap-around, still-missing and car-window branches all occur
+        r['range_image'][0, -1, 0] = -1; r['range_image'][0, 0, 0] = -1
+        r['range_image'][4:9, 20:27, 0] = -1
+        r['range_image'][2, 40:43, 0] = -1
+        r['pc_vehicle_frame'][r['range_image'][..., 0] == -1] = 0
+    B, npx = len(recs), Hp * Wp
+    ri = be.up(np.stack([r['range_image'] for r in recs]))
+    pc = be.up(np.stack([r['pc_vehicle_frame'] for r in recs]))
+    inc = be.up(np.stack([r['inclination'] for r in recs]))
+    names = ['input_data', 'coord_s1', 'pc_vehicle_frame_s1', 'pc_vehicle_frame_s2', 'pc_vehicle_frame_s4',
+             'range_image_mask_s1', 'range_image_mask_s2', 'range_image_mask_s4']
+    shapes = {'input_data': (B, 8, Hp, Wp), 'coord_s1': (B, 3, Hp, Wp)}
+    for s in (1, 2, 4):
+        shapes['pc_vehicle_frame_s%d' % s] = (B, npx // s, 3)
+        shapes['range_image_mask_s%d' % s] = (B, npx // s)
+    bufs = {k: be.empty(int(np.prod(shapes[k])) * 4) for k in names}
+    norm = make_norm()
+    L.call("rd_input_transform", be.ptr(ri), be.ptr(pc), be.ptr(inc), ctypes.addressof(norm), B, H, W, Hp, Wp,
+           *[be.ptr(bufs[k]) for k in names], be.stream)
+    ref = [synth.transform(r, (Hp, Wp)) for r in recs]
+    assert any((r['range_image'][..., 0] == -1).any() for r in recs)
+    for k in names:
+        got = be.down(bufs[k], np.float32, shapes[k])
+        want = np.concatenate([f[k] for f in ref], 0)
+        if k == 'input_data':
+            assert np.array_equal(got[:, :7], want[:, :7])
+            assert np.abs(got[:, 7] - want[:, 7]).max() < 1e-6
+        else:
+            assert np.array_equal(got, want), k
+    m = np.concatenate([f['range_image_mask_s4'] for f in ref], 0)
+    assert 0 < m.sum() < m.size
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_postprocess_batched(be):
     """rd_score_filter_dets_batched + rd_wnms_4c_batched + rd_dets12_to_8_batched over 3 ragged frames (one of them with
     nothing above the threshold) against the oracle frame by frame: counts, keep indices and merged rows bit-exact."""
