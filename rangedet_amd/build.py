@@ -21,7 +21,7 @@ def build(force=False, verbose=True):
     if not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [SRC, "-o", OUT]
+    cmd = [hipcc] + FLAGS + os.environ.get("RD_EXTRA_HIPCC_FLAGS", "").split() + [SRC, "-o", OUT]   # e.g. -DRD_CONV3_DEV
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -41,5 +41,8 @@ for i in range(npt - 1):
     d = (t[:, i + 1] - t[:, i]) / 100.0
     print("  %-18s mean %8.2f us   p10 %8.2f  p90 %8.2f" % (names[i], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
 life = (t[:, npt - 1] - t[:, 0]) / 100.0
-print("  shader clock %.0f MHz (s_memtime ticks / s_memrealtime)" % np.median(clk / life))
+mhz = np.median(clk / life)
+print("  shader clock %.0f MHz (s_memtime ticks / s_memrealtime)" % mhz)
+print("  in shader cycles: MFMA phase %.1fk, epilogue %.1fk per tile" % ((t[:, 2] - t[:, 1]).mean() / 100.0 * mhz / 1e3,
+                                                                          (t[:, 3] - t[:, 2]).mean() / 100.0 * mhz / 1e3))
 print("  start skew p90 %.2f us" % np.percentile((t[:, 0] - t0) / 100.0, 90))
