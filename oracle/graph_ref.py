@@ -117,8 +117,9 @@ def backbone(data, coord, P, cfg=Cfg):
                                                  agg2=agg2, agg1=agg1, agg2a=agg2a)
 
 
-def head(feats, P, cfg=Cfg):
-    """get_fpn_output + sep_level_type(concat) (builder.py:198-266,99-154): logits (B,N), deltas (B,N,8)."""
+def head(feats, P, cfg=Cfg, per_class=False):
+    """get_fpn_output + sep_level_type(concat) (builder.py:198-266,99-154): logits (B,N), deltas (B,N,8) of class 0,
+    or with per_class a list of them, one per class."""
     logits, deltas = [], []
     for lvl, f in enumerate(feats):
         c = r = f
@@ -131,9 +132,12 @@ def head(feats, P, cfg=Cfg):
         lg = conv(c, P, 'rpn_cls_logit_lvl_%d' % lvl, 1, bias=True)
         dl = conv(r, P, 'rpn_reg_delta_lvl_%d' % lvl, 1, bias=True)
         B = lg.shape[0]
-        logits.append(lg.reshape(B, cfg.num_classes, -1)[:, 0])
-        deltas.append(dl.reshape(B, cfg.num_classes, cfg.num_reg_delta, -1)[:, 0].transpose(1, 2))
-    return torch.cat(logits, 1), torch.cat(deltas, 1)
+        logits.append(lg.reshape(B, cfg.num_classes, -1))
+        deltas.append(dl.reshape(B, cfg.num_classes, cfg.num_reg_delta, -1).transpose(2, 3))
+    lg, dl = torch.cat(logits, 2), torch.cat(deltas, 2)       # (B, classes, N), (B, classes, N, 8)
+    if per_class:
+        return [(lg[:, i], dl[:, i]) for i in range(cfg.num_classes)]   # builder.py:134-142: one slice per class
+    return lg[:, 0], dl[:, 0]
 
 
 def forward(inputs, P, cfg=Cfg, num_fgs=None, stages=False):
@@ -147,9 +151,19 @@ def forward(inputs, P, cfg=Cfg, num_fgs=None, stages=False):
         pc = np.concatenate([inputs["pc_vehicle_frame_s%d" % s] for s in cfg.fpn_strides], 1)
         mask = np.concatenate([inputs["range_image_mask_s%d" % s] for s in cfg.fpn_strides], 1)
         k = num_fgs or cfg.pre_nms_top_n[cfg.class_names[0]]
+        if isinstance(k, dict):
+            k = k[cfg.class_names[0]]
         sc, dl, pp, idx = cpu_ops.get_sorted_foreground(score.numpy(), delta.numpy(), pc, mask, k)
         boxes = cpu_ops.decode3d(dl, pp, False)
     out = dict(fg_cls_score=sc, decoded_bbox=boxes, logit=logit.numpy(), delta=delta.numpy(), sorted_idx=idx)
+    if cfg.num_classes > 1:   # builder.py:467-478: the same three ops per class, each with its own top-k
+        out["classes"] = {}
+        with torch.no_grad():
+            for cname, (lg_c, dl_c) in zip(cfg.class_names, head(feats, P, cfg, per_class=True)):
+                kc = (num_fgs or cfg.pre_nms_top_n)[cname] if isinstance(num_fgs or cfg.pre_nms_top_n, dict) else num_fgs
+                s_c, d_c, p_c, i_c = cpu_ops.get_sorted_foreground(torch.sigmoid(lg_c).numpy(), dl_c.numpy(), pc, mask, kc)
+                out["classes"][cname] = dict(fg_cls_score=s_c, decoded_bbox=cpu_ops.decode3d(d_c, p_c, False),
+                                             logit=lg_c.numpy(), delta=dl_c.numpy(), sorted_idx=i_c)
     if stages:
         out["feats"] = [f.numpy() for f in feats]
         out["inter"] = {k_: v.numpy() for k_, v in inter.items()}

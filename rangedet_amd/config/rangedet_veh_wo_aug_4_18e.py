@@ -14,7 +14,12 @@ from ..symbol.head.builder import RangeRpnHead as RpnHead
 _VARIANTS = {
     "veh": dict(label_set=[1], class_names=('veh',), filter_class=['TYPE_VEHICLE']),
     "ped": dict(label_set=[2], class_names=('ped',), filter_class=['TYPE_PEDESTRIAN']),
+    # BASELINE config 5: KITTI range images (datasets/create_range_image_in_kitti.py:121,126: 64 x 2048 x 5 = range, x, y, z,
+    # intensity) with a mixed vehicle + pedestrian head (builder.py:134-142,467-478 per-class slicing / top-k).  The
+    # reference ships no KITTI config file; call get_config(variant="kitti", feat_size=(64, 2048), pad_field=(64, 2048)).
+    "kitti": dict(label_set=[1, 2], class_names=('veh', 'ped'), filter_class=['Car', 'Pedestrian']),
 }
+KITTI_INPUT_CHANNELS = 5
 
 
 def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(64, 2656), fp16=True, batch_image=1,

@@ -27,6 +27,7 @@ class TRef:
     W: int
     cs: int
     co: int = 0
+    cmap: tuple = None   # physical channel -> logical channel (-1 = zero padding) when a concat had to align its parts
 
 
 @dataclass
@@ -171,7 +172,7 @@ class Lowering:
             raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
         out = self._out(cout, x.H, Wout, dest)
         self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual, cin=x.C,
-                  cout=cout, k=k, stride_w=sw, flags=flags)
+                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap)
         return out
 
     def _residual_block(self, add, dest):
@@ -237,13 +238,25 @@ class Lowering:
                 ref_hw = (d[1], d[2])
         if ref_hw is None:
             raise NotImplementedError("concat without a variable input: spatial size unknown before emission")
-        out = self.new_act(Ctot, ref_hw[0], ref_hw[1], persistent=True, zero=True)
-        co = 0
-        for p, c in zip(parts, cs_list):
-            r = self.emit_act(p, dest=(out.buf, out.cs, co))
+        # every part must start on a 16-byte slot boundary (aligned stores of its producer): parts that do not are
+        # followed by zero channels, and the consumer conv gets zero weight columns there (cmap)
+        offs, cmap, co = [], [], 0
+        align = max(1, self.gran // 2)
+        for c in cs_list:
+            pad = -co % align
+            cmap += [-1] * pad
+            co += pad
+            offs.append(co)
+            cmap += list(range(len([m for m in cmap if m >= 0]), len([m for m in cmap if m >= 0]) + c))
+            co += c
+        Cphys = co
+        out = self.new_act(Cphys, ref_hw[0], ref_hw[1], persistent=True, zero=True)
+        if Cphys != Ctot:
+            out.cmap = tuple(cmap)
+        for p, c, o in zip(parts, cs_list, offs):
+            r = self.emit_act(p, dest=(out.buf, out.cs, o))
             if (r.H, r.W) != ref_hw:
                 raise ValueError("concat %s: spatial mismatch" % s.name)
-            co += c
         return out
 
     # ---- Meta-Kernel unit ------------------------------------------------------------------------------------------

@@ -139,7 +139,14 @@ class Executor:
         k = st["kind"]
         b = dict(st)
         if k == "conv":
-            b["w"] = A.upload(L.pack_conv_weight(P[st["name"] + "_weight"], dt))
+            w = np.asarray(P[st["name"] + "_weight"], np.float32)
+            if st.get("cmap"):   # the input is a concat buffer with alignment padding: zero weight columns there
+                wp = np.zeros((w.shape[0], len(st["cmap"])) + w.shape[2:], np.float32)
+                for pc, lc in enumerate(st["cmap"]):
+                    if lc >= 0:
+                        wp[:, pc] = w[:, lc]
+                w = wp
+            b["w"] = A.upload(L.pack_conv_weight(w, dt))
             s, t = bn_affine(P, st["bn"], st["eps"])
             b["scale"], b["shift"] = A.upload(s), A.upload(t)
         elif k == "deconv":

@@ -126,6 +126,105 @@ def test_e2e_small_f32(be):
     assert outs[0] is None and outs[3].shape == (1,)
 
 
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_e2e_kitti_two_class_f32(be):
+    """BASELINE config 5 shape: 5-channel KITTI range image (range, x, y, z, intensity), mixed veh + ped head.  The same
+    lowering serves it (per-class weight rows of the 1x1 output convs, per-class top-k); logits / deltas / sorted scores /
+    boxes of BOTH classes against the graph oracle.  emu: depth-reduced graph, hip: full depth at 16 x 256."""
+    emu = be.name == "emu"
+    H, W = (8, 32) if emu else (16, 256)
+    ks = {'veh': 120, 'ped': 40} if emu else {'veh': 1500, 'ped': 300}
+
+    class Cfg(G.Cfg):
+        num_classes = 2
+        class_names = ('veh', 'ped')
+    cfg = cfgmod.get_config(False, variant="kitti", feat_size=(H, W), pad_field=(H, W), pre_nms_top_n=ks)
+    assert cfg[0].num_classes == 2 and cfg[0].class_names == ('veh', 'ped')
+    if emu:
+        Cfg.num_block = dict({kk: 1 for kk in G.Cfg.num_block}, res1=2)
+        Cfg.head_layers = 1
+        from rangedet_amd.symbol.backbone.dla_backbone import DLABackbone
+        from rangedet_amd.symbol.head.builder import RangeRCNN, RangeRpnHead
+        RP = cfg[2]
+        bp = type("BackboneParam", (), dict(fp16=True, normalizer=RP.normalizer, fpn_strides=(1, 2, 4), batch_image=1,
+                                            range_image_shape_hw=(H, W), add_data_sc=True, num_block=Cfg.num_block,
+                                            num_filter=G.Cfg.num_filter,
+                                            meta_kernel_units={'res1_unit2': dict(stride=1, meta_func_param='meta_baseline_bias',
+                                                                                  data_channels=64, coord_channels=3,
+                                                                                  channel_list=[32, 64], kernel_size=3)}))
+        RP.head.cls_conv_layers = RP.head.reg_conv_layers = 1
+        dp = type("DetParam", (), dict(fpn_strides=(1, 2, 4), class_names=('veh', 'ped')))
+        sym = RangeRCNN(dp).get_test_symbol(DLABackbone(bp), RangeRpnHead(RP))
+    else:
+        sym = cfg[6].test_symbol
+    shapes = small_shapes(H, W)
+    shapes['input_data'] = (cfgmod.KITTI_INPUT_CHANNELS, H, W)
+    plan = lower(sym, shapes, R.RD_F32, 1)
+    P = synth.make_weights(seed=5, width=W, in_ch=cfgmod.KITTI_INPUT_CHANNELS, cls_bias=-0.5, num_classes=2)
+    fr = synth.make_frame(1, W=W, pad_W=W, H=H)
+    fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])     # range, x, y, z, intensity
+    ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
+    outs = ex.forward(fr)
+    ref = G.forward(fr, P, cfg=Cfg, num_fgs=ks)
+    be.alloc.sync()
+    sfgs = [s for s in plan.steps if s["kind"] == "sorted_fg"]
+    assert len(sfgs) == 2 and [s["k"] for s in sfgs] == [ks['veh'], ks['ped']]
+    assert len(outs) == 9   # rec_id + (score, boxes, zeros) per class + gt_bbox_imu, gt_class  (builder.py:54-77)
+    for ci, cname in enumerate(('veh', 'ped')):
+        rc = ref["classes"][cname]
+        logit, delta = ex.read_flat(sfgs[ci]["score"]), ex.read_flat(sfgs[ci]["delta"])
+        assert np.abs(logit - rc["logit"]).max() < 1e-4
+        assert np.abs(delta - rc["delta"]).max() < 1e-4
+        sc = np.array(be.alloc.to_numpy(outs[1 + 3 * ci]))
+        bx = np.array(be.alloc.to_numpy(outs[2 + 3 * ci]))
+        assert sc.shape == (1, ks[cname]) and bx.shape == (1, ks[cname], 10)
+        assert np.abs(sc - rc["fg_cls_score"]).max() < 1e-5
+        gap = np.abs(np.diff(rc["fg_cls_score"][0]))
+        ok = np.ones(ks[cname], bool)
+        ok[1:] &= gap > 1e-5
+        ok[:-1] &= gap > 1e-5
+        ok &= rc["fg_cls_score"][0] > 1e-6
+        assert ok.sum() > ks[cname] // 10
+        assert np.abs(bx[0][ok] - rc["decoded_bbox"][0][ok]).max() < 1e-3
+    # the two classes really are different heads
+    assert np.abs(ref["classes"]['veh']["logit"] - ref["classes"]['ped']["logit"]).max() > 1e-2
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_kitti_full_size_bf16_properties(be):
+    """BASELINE config 5 at its full size (64 x 2048 x 5, veh + ped heads, bf16): size-independent properties of the graph
+    outputs -- per-class scores sorted and inside (0, 1), exactly k rows per class, finite boxes with positive extent,
+    and the fp32 plan on the same frame agrees on the logits within the bf16 tolerance of test_e2e_bf16_tolerance."""
+    H, W = 64, 2048
+    ks = {'veh': 50000, 'ped': 5000}
+    cfg = cfgmod.get_config(False, variant="kitti", feat_size=(H, W), pad_field=(H, W))
+    shapes = small_shapes(H, W)
+    shapes['input_data'] = (cfgmod.KITTI_INPUT_CHANNELS, H, W)
+    P = synth.make_weights(seed=5, width=W, in_ch=cfgmod.KITTI_INPUT_CHANNELS, num_classes=2)
+    fr = synth.make_frame(2, W=W, pad_W=W, H=H)
+    fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])
+    logits = {}
+    for dt in (R.RD_BF16, R.RD_F32):
+        plan = lower(cfg[6].test_symbol, shapes, dt, 1)
+        ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
+        outs = ex.forward(fr)
+        be.alloc.sync()
+        sfgs = [s for s in plan.steps if s["kind"] == "sorted_fg"]
+        logits[dt] = [ex.read_flat(s["score"]).copy() for s in sfgs]
+        if dt == R.RD_BF16:
+            for ci, cname in enumerate(('veh', 'ped')):
+                sc = np.array(be.alloc.to_numpy(outs[1 + 3 * ci]))[0]
+                bx = np.array(be.alloc.to_numpy(outs[2 + 3 * ci]))[0]
+                assert sc.shape == (ks[cname],) and bx.shape == (ks[cname], 10)
+                assert np.all(np.diff(sc) <= 0) and sc[0] < 1 and sc[-1] >= 0
+                assert np.isfinite(bx).all() and np.all(bx[:, 9] > bx[:, 8])
+        del ex
+    for a, b in zip(logits[R.RD_BF16], logits[R.RD_F32]):
+        el = np.abs(a - b).max() / b.std()
+        print("kitti bf16 vs fp32 plan: logit maxerr/std %.3f" % el)
+        assert el < 0.25
+
+
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_pipeline_postprocess_matches_oracle(be):
     """forward + score filter + WNMS + 12->8 on the device == tools/test.py:184-224 restated on the same stage inputs."""
