@@ -396,6 +396,11 @@ inline unsigned long long* conv_trace_buf() {
 #endif
 }
 
+// k_conv1.h: streaming 1x1 bf16 kernel
+inline bool conv1_eligible(const TapList& tl, int in_stride, int out_stride, int cin, int cout, int dt, int Win, int Wq, int Wout);
+inline int launch_conv1(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                        const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int Win, int Wout,
+                        int cin, int cout, int flags, int sw, hipStream_t st);
 // k_conv3.h: persistent 3x3 stride-1 bf16 kernel
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
@@ -432,6 +437,8 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
     mndh = std::min(mndh, tl.dh[t]); mxdh = std::max(mxdh, tl.dh[t]);
     mndw = std::min(mndw, tl.dw[t]); mxdw = std::max(mxdw, tl.dw[t]);
   }
+  if (conv1_eligible(tl, in_stride, out_stride, cin, cout, dt, Win, Wq, Wout) && x_co + 16 * ((cin + 15) / 16) <= x_cs)
+    return launch_conv1(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, Wout, cin, cout, flags, in_stride, st);
   if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
     return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st);
   // Workgroup = 4 rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile),

@@ -1,6 +1,6 @@
 // librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
-#include "k_conv3.h"
+#include "k_conv1.h"
 #include "k_input.h"
 #include "k_meta.h"
 #include "k_misc.h"

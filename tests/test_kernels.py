@@ -66,6 +66,17 @@ CONV_CASES = [
     (BF16, 1, 2, 20, 72, 128, 3, 1, 4),    # head level 0: 72 channels in an 80-wide buffer (partial k-chunk)
     (F32, 1, 2, 21, 64, 128, 1, 2, 0),     # projection shortcut 1x1 stride 2, no activation
     (F32, 1, 2, 64, 128, 64, 3, 1, 1),     # relu before (no) add
+    # persistent 3x3 kernel (k_conv3.h): several tiles per workgroup (emu: 4 "CUs"), column tiles 126 wide, batch, residual
+    (BF16, 2, 9, 300, 64, 128, 3, 1, 6),
+    (BF16, 1, 6, 127, 128, 64, 3, 1, 5),   # W = 127: a second column tile of one pixel; relu before + relu after
+    (BF16, 3, 4, 126, 8, 64, 3, 1, 4),     # one 32-channel unit per tile (every unit starts a new tile)
+    (BF16, 2, 5, 260, 64, 64, 3, 2, 6),    # stride 2 = stride 1 with the even columns stored
+    (BF16, 1, 4, 131, 128, 128, 3, 2, 4),  # stride 2, odd width
+    # streaming 1x1 kernel (k_conv1.h)
+    (BF16, 2, 5, 77, 64, 128, 1, 2, 0),    # projection shortcut, stride 2, odd width
+    (BF16, 1, 3, 40, 8, 64, 1, 1, 0),      # 8 input channels (one 16-channel k-step)
+    (BF16, 1, 4, 33, 128, 128, 1, 1, 6),   # residual + relu, single-buffered variant
+    (BF16, 2, 3, 50, 64, 64, 1, 2, 4),
 ]
 
 

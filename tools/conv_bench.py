@@ -20,6 +20,8 @@ CASES = [  # name, W, cin, cout, k, stride, flags
     ("head_l1 128->128", 1328, 128, 128, 3, 1, 4), ("res2 128->128 W664", 664, 128, 128, 3, 1, 4),
     ("res3a 128->128 W332", 332, 128, 128, 3, 1, 4), ("res3 128->128 W166", 166, 128, 128, 3, 1, 4),
     ("res3 +add W166", 166, 128, 128, 3, 1, 6), ("sc 64->128 s2", 1328, 64, 128, 1, 2, 0), ("conv 8->64", 2656, 8, 64, 3, 1, 4),
+    ("sc 64->64 s1", 2656, 64, 64, 1, 1, 0), ("sc 8->64 s1", 2656, 8, 64, 1, 1, 0), ("sc 64->64 s2", 2656, 64, 64, 1, 2, 0),
+    ("sc 128->128 s2 W664", 664, 128, 128, 1, 2, 0), ("sc 128->128 s1 W664", 664, 128, 128, 1, 1, 0),
 ]
 st = torch.cuda.current_stream().cuda_stream
 ONLY = os.environ.get("ONLY")
