@@ -314,32 +314,50 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         }
       };
       if (do_add) res_load(0, rv[0]);
+      // ReLU placement: a ReLU that is the last operation before the bf16 conversion is applied AFTER it, as a packed signed
+      // 16-bit max (negative bf16 values are negative integers); only relu-then-add needs the fp32 form.
+      const bool relu_f32 = relu_pre && do_add;
+      const bool relu_i16 = relu_post || (relu_pre && !do_add);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      // scale / shift of channel block j: read from LDS one (i, j) block ahead of its use
+      f32x4 scq[2][4], shq[2][4];
+      auto sc_load = [&](int j, f32x4 (&sc)[4], f32x4 (&sh)[4]) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          sc[g4] = *(const f32x4*)(Sc + j * 32 + 16 * ehi + 4 * g4);
+          sh[g4] = *(const f32x4*)(Sc + COUT + j * 32 + 16 * ehi + 4 * g4);
+        }
+      };
+      sc_load(0, scq[0], shq[0]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (do_add && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
+          const int cur = (i * NCT + j) & 1;
+          sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
           const int cb = j * 32 + 16 * ehi;
           unsigned pk[8];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 sc = *(const f32x4*)(Sc + cb + 4 * g4);
-            const f32x4 sh = *(const f32x4*)(Sc + COUT + cb + 4 * g4);
-            float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g4 + e;
-              v[e] = acc[i][j][r] * sc[e] + sh[e];
-              if (relu_pre) v[e] = fmaxf(v[e], 0.f);
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const int r = 4 * g4 + 2 * h2;
+              const f32x2 av = {acc[i][j][r], acc[i][j][r + 1]};
+              const f32x2 s2 = {scq[cur][g4][2 * h2], scq[cur][g4][2 * h2 + 1]};
+              const f32x2 t2 = {shq[cur][g4][2 * h2], shq[cur][g4][2 * h2 + 1]};
+              f32x2 v = av * s2 + t2;                                  // v_pk_fma_f32
+              if (relu_f32) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
               if (do_add) {   // bf16 -> f32 is a 16-bit shift of the packed pair
                 const unsigned w2 = rv[i & 1][j][r >> 3][(r >> 1) & 3];
-                v[e] += __uint_as_float((r & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+                v += f32x2{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)};
               }
-              if (relu_post) v[e] = fmaxf(v[e], 0.f);
+              unsigned p2 = f32x2_to_bf16x2(v[0], v[1]);
+              if (relu_i16) p2 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
+              pk[2 * g4 + h2] = p2;
             }
-            pk[2 * g4] = f32x2_to_bf16x2(v[0], v[1]);
-            pk[2 * g4 + 1] = f32x2_to_bf16x2(v[2], v[3]);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u)
