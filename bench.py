@@ -219,6 +219,15 @@ def main():
                                    "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "parallelism": "frame-parallel dp%d" % world,
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"]))},
             "roofline": roof, "meta_kernel": meta_info,
+            # the whole path against both roofs: algorithmic conv-family bytes / flops of a frame + the
+            # Meta-Kernel's, over the measured wall time per frame (everything included: NMS, launches, side stream)
+            "path_roofline": (lambda sec, gb, gf: {"ms_per_frame": sec * 1e3, "algorithmic_gb_per_frame": gb,
+                                                   "hbm_gbps": gb / sec, "frac_hbm_peak": gb / sec / PEAK_HBM_GBPS,
+                                                   "gflop_per_frame": gf, "tflops": gf / sec / 1e3,
+                                                   "frac_mfma_peak": gf / sec / 1e3 / PEAK_BF16_TFLOPS})(
+                elapsed / (args.steps * world * Bf) * world,
+                (conv_bytes(pipe.plan, 2 if dt == rdlib.RD_BF16 else 4) + 64 * 2656 * 262) / 1e9,
+                (conv_flops(pipe.plan)[0] + 19.29e9) / 1e9),
             "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) / Bf for k, v in prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:

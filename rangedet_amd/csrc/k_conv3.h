@@ -396,30 +396,32 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #undef C3_TRACE
 }
 
-// device memory holding 16 zero bytes (allocated once per process)
+// device memory holding zero bytes: one small allocation per device, made on first use (never on the hot path again)
 inline const unsigned char* conv_zero16() {
 #ifdef HIPEMU
   static const unsigned char z[16] = {0};
   return z;
 #else
-  static const unsigned char* p = [] {
+  static std::mutex mu;
+  static unsigned char* page[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> g(mu);
+  if (!page[dev]) {
     unsigned char* q = nullptr;
-    if (hipMalloc((void**)&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return (unsigned char*)nullptr;
-    return q;
-  }();
-  return p;
+    if (hipMalloc((void**)&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
+    page[dev] = q;
+  }
+  return page[dev];
 #endif
 }
 inline int conv_num_cus() {
 #ifdef HIPEMU
   return 4;
 #else
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return v;
-  }();
-  return n;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  return v;
 #endif
 }
 
