@@ -93,6 +93,14 @@ class Lib:
                 "%s not found: the HIP extension is not built (run `python -m rangedet_amd.build`). "
                 "There is no CPU fallback." % path)
         self.path = path
+        # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library is dlopen'ed first it pulls in /opt/rocm's
+        # copy, torch then loads its own, and the process ends up with two runtimes -- the second one sees no device
+        # ("no ROCm-capable device is detected").  Loading torch first makes both resolve to the same runtime.
+        if os.path.basename(path) == os.path.basename(DEFAULT_PATH):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.cdll = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
