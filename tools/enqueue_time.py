@@ -1,0 +1,17 @@
+"""Host-side enqueue cost of one 8-frame step vs its wall time (dev tool): the path must not be launch-bound.
+   python tools/enqueue_time.py   ->  CPU enqueue ms/step, wall ms/step   (measured: 4.0 vs 13.4)"""
+import sys, time; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import numpy as np, torch
+from rangedet_amd import lib as rdlib, synth
+from rangedet_amd.pipeline import RangeDetPipeline
+P = synth.make_weights(seed=18)
+pipe = RangeDetPipeline(P, dtype=rdlib.RD_BF16, wnms_cap=4096, batch=8)
+fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(8))).items()}
+for _ in range(3): pipe.enqueue(fr)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): pipe.enqueue(fr)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("CPU enqueue %.2f ms/step; wall %.2f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
