@@ -191,6 +191,38 @@ def test_e2e_kitti_two_class_f32(be):
 
 
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_full_size_bf16_properties(be):
+    """BASELINE config 2 + 3 at full size (64 x 2650 pad 2656, 8 ch, bf16, top-50000, weighted NMS), batch of 3 with frame 0
+    repeated: size-independent properties.  Sorted scores in [0, 1]; the repeated frame gives bit-identical graph outputs
+    and detections (the persistent kernels, the LDS-DMA pipeline and the batched NMS are deterministic and frames do not
+    leak into each other); a second run reproduces the first bit for bit; kept rows are a subset of the candidates with
+    scores above min_score; the (M, 8) boxes have positive extents."""
+    from rangedet_amd.pipeline import RangeDetPipeline
+    P = synth.make_weights(seed=18)
+    pipe = RangeDetPipeline(P, dtype=R.RD_BF16, wnms_cap=4096, batch=3, lib=be.lib, alloc=be.alloc)
+    fr = synth.make_batch([0, 1, 0])
+    r1 = pipe.run(fr)
+    sc1 = np.array(be.alloc.to_numpy(r1["fg_cls_score"]))
+    bx1 = np.array(be.alloc.to_numpy(r1["decoded_bbox"]))
+    assert sc1.shape == (3, 50000) and bx1.shape == (3, 50000, 10)
+    assert np.all(np.diff(sc1, axis=1) <= 0) and sc1.max() <= 1 and sc1.min() >= 0
+    assert np.array_equal(sc1[0], sc1[2]) and np.array_equal(bx1[0], bx1[2]) and not np.array_equal(sc1[0], sc1[1])
+    f1 = r1["frames"]
+    assert f1[0]["keep_inds"].tolist() == f1[2]["keep_inds"].tolist()
+    assert np.array_equal(f1[0]["wnms_rows"], f1[2]["wnms_rows"])
+    r2 = pipe.run(fr)
+    assert np.array_equal(sc1, np.array(be.alloc.to_numpy(r2["fg_cls_score"])))
+    for a, b in zip(f1, r2["frames"]):
+        assert a["keep_inds"].tolist() == b["keep_inds"].tolist() and np.array_equal(a["wnms_rows"], b["wnms_rows"])
+    for b_, f in enumerate(f1):
+        K, keep = f["num_candidates"], f["keep_inds"]
+        assert K == int((sc1[b_] > 0.5).sum()) and 0 < len(keep) <= K
+        assert np.all(keep >= 0) and np.all(keep < K) and len(set(keep.tolist())) == len(keep)
+        d8 = f["det_xyzlwhyaws"]
+        assert np.isfinite(d8).all() and np.all(d8[:, 3:6] > 0) and np.all(d8[:, 7] > 0.5)
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_kitti_full_size_bf16_properties(be):
     """BASELINE config 5 at its full size (64 x 2048 x 5, veh + ped heads, bf16): size-independent properties of the graph
     outputs -- per-class scores sorted and inside (0, 1), exactly k rows per class, finite boxes with positive extent,
