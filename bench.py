@@ -96,13 +96,14 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic batches cycled through")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (pipelines on separate streams)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from rangedet_amd import lib as rdlib, synth
-    from rangedet_amd.pipeline import RangeDetPipeline
+    from rangedet_amd.pipeline import InterleavedPipelines
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,27 +123,31 @@ def main():
 
     params = synth.make_weights(seed=18)
     Bf = args.batch
-    pipe = RangeDetPipeline(params, dtype=dt, wnms_cap=4096, batch=Bf)
+    multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=4096, batch=Bf)
+    pipe = multi.pipes[0]   # (per-kernel profiling replay and the roofline figures use one pipeline on the default stream)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
     frames_np = [synth.make_batch([(rank + world * (i * Bf + j)) for j in range(Bf)]) for i in range(args.frames)]
     frames = [{k: torch.from_numpy(v).to(dev) for k, v in f.items()} for f in frames_np]
     L = pipe.lib
     REC = MAX_DET * 12 + 1
-    gather_in = torch.zeros(Bf * REC, device=dev)
-    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if gather else None
+    gather_in = [torch.zeros(Bf * REC, device=dev) for _ in multi.pipes]
+    gather_out = [[torch.zeros_like(gather_in[0]) for _ in range(world)] for _ in multi.pipes] if gather else None
     post = pipe.post[0]
     A = pipe.alloc
 
     def step(i):
-        pipe.enqueue(frames[i % len(frames)])
+        # one step = one batch of Bf frames through the whole path; successive steps alternate between the pipelines
+        # (two batches in flight: the other batch's launches fill the tails / launch gaps of this one)
+        j, _ = multi.enqueue(frames[i % len(frames)])
         if gather:
-            # the ONE collective of the path, enqueued behind this batch's post-processing on the side stream: the next
-            # batch's forward (main stream) overlaps it, nothing on the main stream waits for it
-            with torch.cuda.stream(pipe._post_stream):
-                for b, pp in enumerate(pipe.post):
-                    gather_in[b * REC:(b + 1) * REC - 1].copy_(pp.out_rows()[:MAX_DET].reshape(-1))
-                    gather_in[(b + 1) * REC - 1:(b + 1) * REC].copy_(pp.nkeep_view().float())
-                dist.all_gather(gather_out, gather_in)
+            # the ONE collective of the path, enqueued behind this batch's post-processing on its side stream: the next
+            # batch's forward overlaps it, nothing on a launch stream waits for it
+            pj = multi.pipes[j]
+            with torch.cuda.stream(pj._post_stream):
+                for b, pp in enumerate(pj.post):
+                    gather_in[j][b * REC:(b + 1) * REC - 1].copy_(pp.out_rows()[:MAX_DET].reshape(-1))
+                    gather_in[j][(b + 1) * REC - 1:(b + 1) * REC].copy_(pp.nkeep_view().float())
+                dist.all_gather(gather_out[j], gather_in[j])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -216,7 +221,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "rangedet_veh_wo_aug_4_18e: DLA backbone + Meta-Kernel + heads + top-50000 + 3D decode "
                                    "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, %d frames per step per GPU, " % Bf + ""
-                                   "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "parallelism": "frame-parallel dp%d" % world,
+                                   "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "batches_in_flight_per_gpu": len(multi.pipes), "parallelism": "frame-parallel dp%d" % world,
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"]))},
             "roofline": roof, "meta_kernel": meta_info,
             # the whole path against both roofs: algorithmic conv-family bytes / flops of a frame + the

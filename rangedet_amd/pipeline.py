@@ -197,3 +197,33 @@ class RangeDetPipeline:
         r0 = dict(res[0]) if self.batch == 1 else dict(frames=res)
         r0["fg_cls_score"], r0["decoded_bbox"] = outs[1], outs[2]
         return r0
+
+
+class InterleavedPipelines:
+    """`n` pipelines, each with its own launch stream (and its own post-processing side stream): successive batches
+    alternate between them, so two batches are in flight.  The persistent conv kernels give every CU a fixed list of
+    tiles; when the tile count is not a multiple of the CU count (W = 1328 and W <= 332 levels) the tail of a launch leaves
+    CUs idle -- the other batch's launches fill those tails and the ~120 launch gaps per batch (measured +8 %, n = 2;
+    n = 3 is slower again).  The caller keeps a batch's input tensors alive until its results are collected."""
+
+    def __init__(self, params, n=2, **kw):
+        self.pipes = [RangeDetPipeline(params, **kw) for _ in range(n)]
+        A = self.pipes[0].alloc
+        self.streams = [A.new_stream() for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
+        self._i = 0
+
+    def stream_context(self, j):
+        import contextlib
+        st = self.streams[j]
+        return self.pipes[j].alloc.torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
+    def enqueue(self, inputs):
+        """Enqueue one batch on the next pipeline; returns (pipeline index, graph outputs)."""
+        j = self._i % len(self.pipes)
+        self._i += 1
+        with self.stream_context(j):
+            return j, self.pipes[j].enqueue(inputs)
+
+    def collect(self, j):
+        """Synchronise and read back the detections of the batch last enqueued on pipeline j (list, one dict per frame)."""
+        return [p.collect() for p in self.pipes[j].post]

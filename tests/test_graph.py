@@ -223,6 +223,33 @@ def test_full_size_bf16_properties(be):
 
 
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_interleaved_pipelines_match_single(be):
+    """Two batches in flight on two launch streams (pipeline.InterleavedPipelines, what bench.py runs) give, batch by batch,
+    bit-identical detections to one pipeline run serially -- four batches, so each stream is reused while the other is busy."""
+    from rangedet_amd.pipeline import InterleavedPipelines, RangeDetPipeline
+    H, Wr, W, k = 16, 250, 256, 2000
+    P = synth.make_weights(seed=18, width=W, cls_bias=-1.0)
+    kw = dict(dtype=R.RD_BF16, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n=k, wnms_cap=2048, batch=2)
+    batches = [synth.make_batch([2 * i, 2 * i + 1], W=Wr, pad_W=W, H=H) for i in range(4)]
+    single = RangeDetPipeline(P, lib=be.lib, alloc=be.alloc, **kw)
+    want = [single.run(b_)["frames"] for b_ in batches]
+    multi = InterleavedPipelines(P, n=2, lib=be.lib, alloc=be.alloc, **kw)
+    got = [None] * 4
+    for i in (0, 1):
+        multi.enqueue(batches[i])
+    for i in (0, 1):                      # collect batch i (pipeline i), then reuse its pipeline for batch i + 2
+        got[i] = multi.collect(i)
+        j, _ = multi.enqueue(batches[i + 2])
+        assert j == i
+    for i in (2, 3):
+        got[i] = multi.collect(i - 2)
+    for w_, g_ in zip(want, got):
+        for fw, fg in zip(w_, g_):
+            assert fw["num_candidates"] == fg["num_candidates"] and fw["keep_inds"].tolist() == fg["keep_inds"].tolist()
+            assert np.array_equal(fw["wnms_rows"], fg["wnms_rows"])
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_kitti_full_size_bf16_properties(be):
     """BASELINE config 5 at its full size (64 x 2048 x 5, veh + ped heads, bf16): size-independent properties of the graph
     outputs -- per-class scores sorted and inside (0, 1), exactly k rows per class, finite boxes with positive extent,
