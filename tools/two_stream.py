@@ -1,4 +1,5 @@
-"""Two batches in flight on two streams vs one (dev experiment): python tools/two_stream.py [steps]"""
+"""1 / 2 / 3 batches in flight on separate launch streams (dev experiment behind pipeline.InterleavedPipelines):
+   python tools/two_stream.py [steps]     measured 13.5 / 12.5 / 12.9 ms per 8-frame step"""
 import os
 import sys
 import time
