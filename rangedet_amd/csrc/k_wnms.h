@@ -208,11 +208,28 @@ constexpr int WN_CT = 8;
 __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict__ prep, int cap,
                                                         const int* __restrict__ d_count, float thresh, float thresh_vote,
                                                         int is3d, unsigned long long* __restrict__ thr,
-                                                        unsigned long long* __restrict__ vote, int nwcap, WnmsBatch bs) {
+                                                        unsigned long long* __restrict__ vote, int nwcap, WnmsBatch bs,
+                                                        const int* __restrict__ rows, const int* __restrict__ nrows,
+                                                        const unsigned long long* __restrict__ supp_state) {
+  // rows == nullptr: row block blockIdx.y is rows 64*blockIdx.y .. (first round).  Otherwise (second round) the row
+  // block is 64 consecutive entries of the compacted, ascending list of rows that survived the first round.
   prep += blockIdx.z * bs.prep; thr += blockIdx.z * bs.words; vote += blockIdx.z * bs.words;
   const int rb = blockIdx.y, cb = blockIdx.x / WN_CT, sub = blockIdx.x % WN_CT;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
-  if (cb < rb || rb * 64 >= K || cb * 64 >= K) return;
+  int nr = K, qmin = rb * 64;
+  unsigned dead = 0u;   // second round: columns of this tile that the first round already suppressed.  Neither their thr
+                        // bit (ORed into a suppression word that already has it) nor their vote bit (masked by the
+                        // suppression snapshot in the merge) can influence anything, so those pairs are not evaluated.
+  if (rows) {
+    dead = (unsigned)(supp_state[blockIdx.z * (bs.ints / 2) + cb] >> (sub * WN_CT)) & 0xffu;
+    rows += blockIdx.z * bs.ints;
+    nr = nrows[blockIdx.z * bs.ints];                      // (per-frame workspaces are bs.ints 4-byte words apart)
+    if (rb * 64 >= nr) return;
+    qmin = rows[rb * 64];
+  }
+  // skip column tiles that lie entirely before the first row (the tile holding that row itself is still written: the
+  // scan and the merge read every row's words from its own, diagonal, word on)
+  if (cb * 64 + 63 < qmin || rb * 64 >= nr || cb * 64 >= K) return;
   __shared__ float colp[WN_CT * PREP_F];
   __shared__ float edges[EDGE_LDS_BYTES / 4];
   const int t = threadIdx.x;
@@ -226,8 +243,8 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
     colp[i] = q2 < K ? prep[(size_t)q2 * PREP_F + (i % PREP_F)] : 0.f;
   }
   __syncthreads();
-  const int q1 = rb * 64 + t;
-  if (q1 >= K) return;
+  if (rb * 64 + t >= nr) return;
+  const int q1 = rows ? rows[rb * 64 + t] : rb * 64 + t;
   unsigned mt = 0u, mv = 0u;
   if (c0 + WN_CT - 1 > q1) {
     float mine[PREP_F];
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
     for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
     for (int c = 0; c < WN_CT; ++c) {
       int q2 = c0 + c;
-      if (q2 < K && q2 > q1) {
+      if (q2 < K && q2 > q1 && !((dead >> c) & 1u)) {
         float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0, EL);
         if (ovr >= thresh) mt |= 1u << c;
         if (ovr > thresh_vote) mv |= 1u << c;
@@ -254,19 +271,23 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
                                                        unsigned long long* __restrict__ snap, int cap,
                                                        const int* __restrict__ d_count, int nwcap,
                                                        const int* __restrict__ order, int* __restrict__ keep_q,
-                                                       int* __restrict__ keep, int* __restrict__ d_nkeep, WnmsBatch bs) {
+                                                       int* __restrict__ keep, int* __restrict__ d_nkeep, WnmsBatch bs,
+                                                       int c_begin, int c_end, unsigned long long* __restrict__ supp_state) {
+  // 64-row chunks [c_begin, c_end) only.  c_begin > 0 resumes from the suppression state / keep count a previous launch
+  // left in supp_state / *d_nkeep; the state is stored back whenever supp_state is given.
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   thr += blockIdx.z * bs.words; snap += blockIdx.z * bs.words; order += blockIdx.z * bs.order;
   keep_q += blockIdx.z * bs.ints; keep += blockIdx.z * bs.keep; d_nkeep += blockIdx.z;
+  if (supp_state) supp_state += blockIdx.z * bs.ints / 2;   // per-frame workspaces are bs.ints 4-byte words apart
   unsigned long long* supp = (unsigned long long*)smem;      // [nwcap]
   unsigned long long* tile = supp + nwcap;                   // [64][nwcap]
   const int lane = threadIdx.x;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   const int nw = (K + 63) >> 6;
-  for (int w = lane; w < nw; w += 64) supp[w] = 0ull;
+  for (int w = lane; w < nw; w += 64) supp[w] = c_begin > 0 ? supp_state[w] : 0ull;
   __builtin_amdgcn_wave_barrier();
-  int M = 0;
-  for (int c = 0; c < nw; ++c) {
+  int M = c_begin > 0 ? *d_nkeep : 0;
+  for (int c = c_begin; c < min(nw, c_end); ++c) {
     const int rows = min(64, K - (c << 6));
     for (int w0 = c; w0 < nw; w0 += 64) {                     // batches of 16 independent row loads in flight
       const int w = w0 + lane;
@@ -303,6 +324,42 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
     }
   }
   if (lane == 0) *d_nkeep = M;
+  if (supp_state)
+    for (int w = lane; w < nw; w += 64) supp_state[w] = supp[w];
+}
+
+// Rows >= first_row that the first round left unsuppressed, ascending -> rows_out, their number -> *nrows_out.
+// One workgroup of 256 threads per frame, thread w owns suppression word w (K <= 16384 rows = 256 words).
+__global__ __launch_bounds__(256) void wnms_alive_kernel(const unsigned long long* __restrict__ supp_state, int cap,
+                                                         const int* __restrict__ d_count, int first_row,
+                                                         int* __restrict__ rows_out, int* __restrict__ nrows_out, WnmsBatch bs) {
+  supp_state += blockIdx.z * bs.ints / 2; rows_out += blockIdx.z * bs.ints; nrows_out += blockIdx.z * bs.ints;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
+  const int nw = (K + 63) >> 6, w = threadIdx.x;
+  unsigned long long alive = 0ull;
+  if (w < nw) {
+    alive = ~supp_state[w];
+    const int lo = first_row - (w << 6), hi = K - (w << 6);             // keep rows in [first_row, K)
+    if (lo >= 64) alive = 0ull; else if (lo > 0) alive &= ~0ull << lo;
+    if (hi < 64) alive &= hi <= 0 ? 0ull : (1ull << hi) - 1ull;
+  }
+  __shared__ int part[256];
+  const int cnt = __popcll(alive);
+  part[w] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = w >= off ? part[w - off] : 0;
+    __syncthreads();
+    part[w] += v;
+    __syncthreads();
+  }
+  int pos = part[w] - cnt;
+  while (alive) {
+    const int b = __ffsll(alive) - 1;
+    rows_out[pos++] = (w << 6) + b;
+    alive &= alive - 1ull;
+  }
+  if (w == 255) *nrows_out = part[255];
 }
 
 __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict__ dets, const int* __restrict__ order,
@@ -402,8 +459,8 @@ __global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {
 
 struct WnmsWs {
   float* prep;
-  unsigned long long *thr, *vote, *snap;
-  int *keep_q, *order;
+  unsigned long long *thr, *vote, *snap, *supp_state;
+  int *keep_q, *order, *alive, *nalive;
   void* sort_ws;
   int nwcap;
 };

@@ -17,8 +17,8 @@ namespace rd {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t wnms_ws_bytes(int cap) {
   const size_t nw = (size_t)(cap + 63) / 64;
-  return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 2 * align256((size_t)cap * 4) +
-         align256(sort_ws_bytes(cap)) + 256;
+  return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 3 * align256((size_t)cap * 4) +
+         align256(nw * 8) + 256 + align256(sort_ws_bytes(cap)) + 256;
 }
 inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   WnmsWs w;
@@ -31,6 +31,9 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   w.snap = (unsigned long long*)p; p += align256((size_t)cap * nw * 8);
   w.keep_q = (int*)p; p += align256((size_t)cap * 4);
   w.order = (int*)p; p += align256((size_t)cap * 4);
+  w.alive = (int*)p; p += align256((size_t)cap * 4);
+  w.supp_state = (unsigned long long*)p; p += align256(nw * 8);
+  w.nalive = (int*)p; p += 256;
   w.sort_ws = p;
   return w;
 }
@@ -363,13 +366,29 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int nb = (Kcap + 63) / 64;
   hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs);
-  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote,
-                     is3d, w.thr, w.vote, w.nwcap, bs);
   const size_t scan_lds = (size_t)65 * w.nwcap * 8;
   RD_REQUIRE(scan_lds <= 160 * 1024, RD_ESHAPE, "wnms_4c: Kcap too large for the scan tile");
   allow_big_lds(wnms_scan_kernel);
+  // Two rounds.  The greedy scan only ever reads the thr / vote rows of boxes it KEEPS, and the highest-scoring boxes
+  // suppress most of the rest: round 1 evaluates the pairs of the first R1 rows and scans them; round 2 evaluates pairs
+  // only for the later rows that are still unsuppressed (compacted list) and resumes the scan.  Results are identical
+  // to the one-round form -- the skipped rows are exactly the ones whose bits nobody reads.
+  const int R1 = 256, nb1 = R1 / 64;
+  static const bool one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;   // dev switch (tools/wnms_bench.py)
+  const bool two = Kcap >= 4 * R1 && !one_round;
+  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, two ? nb1 : nb, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
+                     thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)nullptr, (const int*)nullptr,
+                     (const unsigned long long*)nullptr);
   hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
-                     w.keep_q, keep, d_nkeep, bs);
+                     w.keep_q, keep, d_nkeep, bs, 0, two ? nb1 : nb, two ? w.supp_state : (unsigned long long*)nullptr);
+  if (two) {
+    hipLaunchKernelGGL(wnms_alive_kernel, dim3(1, 1, B), dim3(256), 0, st, w.supp_state, Kcap, d_count, R1, w.alive, w.nalive, bs);
+    hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb - nb1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
+                       thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)w.alive, (const int*)w.nalive,
+                       (const unsigned long long*)w.supp_state);
+    hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
+                       w.keep_q, keep, d_nkeep, bs, nb1, nb, w.supp_state);
+  }
   allow_big_lds(wnms_merge_kernel);
   hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap, 1, B), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, w.snap, Kcap,
                      d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs);

@@ -274,6 +274,25 @@ def test_wnms_vs_oracle(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("is3d", [0, 1])
+def test_wnms_two_rounds_vs_oracle(be, is3d):
+    """Capacity >= 1024 switches rd_wnms_4c to two rounds (pairs of the first 256 rows -> scan -> compacted list of the
+    rows still alive -> their pairs -> resumed scan).  K well above 256 so that both rounds, the compaction and the
+    resume matter; keep indices and merged rows bit-equal to the oracle, with exact score ties in the input."""
+    no, rep = (70, 8) if be.name == "emu" else (200, 8)
+    d = synth.cluster_dets(no, rep, seed=77, quant=33)
+    K = d.shape[0]
+    assert K > 2 * 256
+    o2 = np.argsort(-d[:, 11], kind="stable").astype(np.int32)
+    rows, keep = _wnms(be, d, 0.1, 0.5, is3d, o2, cap_extra=1024 + 64 - K if K < 1024 else 64)
+    flat, rk = O.wnms_4c(d, 0.1, 0.5, bool(is3d), 100, order=o2)
+    assert 16 < len(rk) < K and keep.tolist() == rk
+    assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
+    rows2, keep2 = _wnms(be, d, 0.1, 0.5, is3d, None, cap_extra=1024 + 64 - K if K < 1024 else 64)   # library-side ordering
+    assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_score_filter_and_12to8(be):
     rng = np.random.default_rng(4)
     n = 3000
