@@ -69,9 +69,10 @@ int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int
 /* Packed conv weights: [ntaps][nchunk][Cout][8 slots * (16/elem) channels], zero padded; one k-chunk =
  * 8 slots of 16 bytes.  rd_conv_packed_bytes gives the size.  w_oihw_host is (Cout,Cin,KH,KW) float32
  * (mx Convolution layout); deconv weight is (Cin,Cout,KH,KW) (mx Deconvolution layout) and is packed per
- * output phase (phase = ow % stride_w) -- rd_deconv_phase_taps tells how many taps a phase's PACKED image has: 9 when
- * the phase's taps fit the 3x3 window (it is then packed, and run, as a 3x3 tap list with zero weights for the absent
- * taps), else the phase's own tap count (<= 9; more is RD_ESHAPE). */
+ * output phase (phase = ow % stride_w) -- rd_deconv_phase_taps tells how many taps a phase's PACKED image has: the
+ * phase's own tap count (<= 9, in ascending (dh, dw) order; more is RD_ESHAPE), except that a phase whose taps lie
+ * inside the 3x3 window without being three rows x two adjacent columns is packed as all 9 window taps (zeros for the
+ * absent ones). */
 size_t rd_conv_packed_bytes(int ntaps, int cin, int cout, int dtype);
 int rd_pack_conv_weight_host(const float* w_oihw_host, int cout, int cin, int kh, int kw, int dtype,
                              void* packed_host);

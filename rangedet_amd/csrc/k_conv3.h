@@ -63,27 +63,37 @@ inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
           }
 }
 
-// DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (tap T of its unit):
-// the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions and the
-// steps of taps 0..C3_HT-1 C3_HP halo pieces each.  At tap 7 the wait must also cover the last halo piece:
-// the following step reads the next unit's halo.
-constexpr int C3_HT = 6, C3_HP = 2;   // halo pieces: C3_HP per step at taps 0 .. C3_HT-1 (C3_HT * C3_HP = 12)
-constexpr int c3_halo_pieces(int tap) { return tap < C3_HT ? C3_HP : 0; }
-constexpr int c3_younger(int R, int IPW, int T) {
+// Tap sets.  TS = 0: all nine taps (convs).  A transposed-conv phase only has taps in two of the three columns:
+// TS = 1 -> dw in {-1, 0}, TS = 2 -> dw in {0, +1}; its unit is 6 steps instead of 9 (no MFMAs on zero weights).
+constexpr int c3_nsteps(int TS) { return TS == 0 ? 9 : 6; }
+constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw+1) of step ordinal s
+  return TS == 0 ? s : 3 * (s / 2) + (s % 2) + (TS == 2 ? 1 : 0);
+}
+// Halo pieces (12 per wave and unit) per step ordinal: 2 each at ordinals 0..5 of a 9-step unit, 4 each at ordinals 0..2
+// of a 6-step unit; the last ones are issued two steps before the wait that must cover them (ordinal NS-2).
+constexpr int c3_halo_last(int NS) { return NS == 9 ? 5 : 2; }
+constexpr int c3_halo_pieces(int s, int NS) { return s <= c3_halo_last(NS) ? 12 / (c3_halo_last(NS) + 1) : 0; }
+constexpr int c3_halo_first(int s, int NS) { int n = 0; for (int t = 0; t < s; ++t) n += c3_halo_pieces(t, NS); return n; }
+// DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (ordinal s of its unit):
+// the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions plus its
+// halo pieces.  At ordinal NS-2 the wait must also cover the last halo piece: the following step reads the next halo.
+constexpr int c3_younger(int R, int IPW, int s, int NS) {
   int n = (R - 3) * IPW;
-  for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((T - d) % 9) + 9) % 9);
-  if (T == 7 && n > (7 - C3_HT) * IPW) n = (7 - C3_HT) * IPW;
+  for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((s - d) % NS) + NS) % NS, NS);
+  const int cap = (NS - 3 - c3_halo_last(NS)) * IPW;
+  if (s == NS - 2 && n > cap) n = cap;
   return n;
 }
 // s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
 #define C3_WAIT_IMM(vm, lgkm) (((vm) & 15) | (((vm) >> 4) << 14) | (7 << 4) | ((lgkm) << 8))
 
-template <int NCT, int DBG = 0>
+template <int NCT, int DBG = 0, int TS = 0>
 __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   using Cfg = C3Cfg<NCT>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int NR = 4 + NCT;                    // fragment reads per k-step
   constexpr int NM = 4 * NCT;                    // MFMAs per k-step
+  constexpr int NS = c3_nsteps(TS);              // steps (taps) per unit
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     dma_v(ok ? (const void*)(sp + hlane) : (const void*)a.zero16, buf * C3_HALO + q * 1024);
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
-  const int nslab_tile = a.nchunk * 9;
+  const int nslab_tile = a.nchunk * NS;
   auto slab_piece = [&](int j) {
     dma_s(a.w + (size_t)fslab * SLAB + (wave * IPW + j) * 1024, lane * 16, RING + fslot * SLAB + (wave * IPW + j) * 1024);
   };
@@ -223,20 +233,22 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   int rslot = 0;        // ring slot of the slab being consumed
   int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
 #pragma unroll
-  for (int k = 0; k < NR; ++k) C3_RD(0, k, aoff[0] + abuf, boff + rslot * SLAB, 0)   // fragments of (unit 0, tap 0, ks 0)
+  for (int k = 0; k < NR; ++k)   // fragments of (unit 0, first tap, ks 0)
+    C3_RD(0, k, aoff[c3_tap(TS, 0) % 3] + abuf + (c3_tap(TS, 0) / 3) * 8192, boff + rslot * SLAB, 0)
 
   // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
   //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
   //   block 1: MFMAs of ks 1, with the reads of (next step, ks 0) interleaved into its first half, then the step's
   //            barrier (slab g+2 landed everywhere, slab g free), then the DMA issue interleaved into the second half.
-#define C3_STEP(T)                                                                                                   \
+#define C3_STEP(S)                                                                                                   \
   {                                                                                                                  \
-    constexpr int dh_ = (T) / 3, dw_ = (T) % 3;                                                                      \
-    constexpr int ndh_ = ((T) + 1) % 9 / 3, ndw_ = ((T) + 1) % 3;                                                    \
+    constexpr int T_ = c3_tap(TS, (S)), TN_ = c3_tap(TS, ((S) + 1) % NS);                                            \
+    constexpr int dh_ = T_ / 3, dw_ = T_ % 3, ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                        \
+    constexpr int NH_ = c3_halo_pieces((S), NS), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
     const int acur_ = (aoff[dw_] + abuf + dh_ * 8192) ^ 32;                                                          \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
-    const int anext_ = aoff[ndw_] + ((T) == 8 ? C3_HALO - abuf : abuf) + ndh_ * 8192;                                \
+    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? C3_HALO - abuf : abuf) + ndh_ * 8192;                           \
     const int bnext_ = boff + rnext_ * SLAB;                                                                         \
     const int hbuf_ = abuf ? 0 : 1;                                                                                  \
     C3_FENCE();                                                                                                      \
@@ -249,15 +261,16 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       if (n < NR) C3_RD(0, n, anext_, bnext_, 0)                                                                     \
     }                                                                                                                \
     if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RD(0, n, anext_, bnext_, 0) }          \
-    C3_SYNC(c3_younger(R, IPW, (T)), NR)                                                                             \
-    if ((T) == 0) halo_begin();                                                                                      \
+    C3_SYNC(c3_younger(R, IPW, (S), NS), NR)                                                                         \
+    if ((S) == 0) halo_begin();                                                                                      \
     _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
       C3_MM(1, n)                                                                                                    \
-      if (!(DBG & 4)) {                                                                                              \
-        constexpr int HS_ = NM / 2 >= IPW + 2 * C3_HP ? 2 : 1;  /* MFMA slots per halo piece */                      \
-        const int p_ = n - NM / 2 - IPW;                                                                             \
-        if (n - NM / 2 < IPW) { slab_piece(n - NM / 2); C3_FENCE(); }                                                \
-        else if ((T) < C3_HT && p_ % HS_ == 0 && p_ / HS_ < C3_HP) { halo_piece(hbuf_, C3_HP * (T) + p_ / HS_); C3_FENCE(); } \
+      if (!(DBG & 4)) {   /* the step's DMA pieces, spread over the MFMA slots of this half block (slab pieces first) */ \
+        _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                              \
+          if (p * (NM / 2) / NP_ == n - NM / 2) {                                                                    \
+            if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS) + p - IPW);                    \
+            C3_FENCE();                                                                                              \
+          }                                                                                                          \
       }                                                                                                              \
     }                                                                                                                \
     slab_advance();                                                                                                  \
@@ -273,7 +286,8 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll 1
     for (int c = 0; c < a.nchunk; ++c) {
-      C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5) C3_STEP(6) C3_STEP(7) C3_STEP(8)
+      C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
+      if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
       abuf = C3_HALO - abuf;
     }
     if (k == 0) C3_TRACE()
@@ -436,7 +450,7 @@ inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int
 
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st) {
+                        int cout, int flags, int sw, hipStream_t st, int ts = 0) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
   a.sw = sw; a.Wo = (W - 1) / sw + 1;
@@ -457,8 +471,10 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
 #endif
-  if (cout == 128) hipLaunchKernelGGL((conv3x3_stream_kernel<4>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a);
-  else hipLaunchKernelGGL((conv3x3_stream_kernel<2>), dim3(grid), dim3(256), C3Cfg<2>::LDS, st, a);
+#define C3_LAUNCH(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
+  if (cout == 128) { if (ts == 0) C3_LAUNCH(4, 0); else if (ts == 1) C3_LAUNCH(4, 1); else C3_LAUNCH(4, 2); }
+  else { if (ts == 0) C3_LAUNCH(2, 0); else if (ts == 1) C3_LAUNCH(2, 1); else C3_LAUNCH(2, 2); }
+#undef C3_LAUNCH
   return check_launch("conv3x3_stream_kernel");
 }
 

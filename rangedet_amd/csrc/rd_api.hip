@@ -44,6 +44,10 @@ inline void allow_big_lds(K kernel) {
 inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4>);
   allow_big_lds(conv3x3_stream_kernel<2>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 1>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 2>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 1>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 2>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
@@ -117,27 +121,55 @@ int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, 
   return RD_OK;
 }
 // A phase whose taps all lie inside the 3x3 window (every transposed conv of the RangeDet graph) is packed and run as a
-// 3x3 tap list with zero weights for the absent taps: the persistent 3x3 kernel then serves it, writing the phase's pixels
-// of the output viewed as [H][Win][stride_w * Cstride].
+// tap list in (dh, dw) order; the persistent 3x3 kernel then serves it, writing the phase's pixels of the output viewed
+// as [H][Win][stride_w * Cstride].  Tap set 1 / 2: exactly the six taps with dh in {-1,0,1} and dw in {-1,0} / {0,+1}
+// (what k(3,8) s4 p2 and k(3,4) s2 p1 phases are) -> 6-step units; anything else inside the window is embedded in
+// all nine taps with zero weights.
 static bool deconv_embeds_3x3(const TapList& tl) {
   for (int t = 0; t < tl.n; ++t)
     if (tl.dh[t] < -1 || tl.dh[t] > 1 || tl.dw[t] < -1 || tl.dw[t] > 1) return false;
   return tl.n >= 1 && tl.n <= 9;
 }
+static int deconv_tap_set(const TapList& tl) {   // 1 / 2 as above, else 0
+  if (tl.n != 6 || !deconv_embeds_3x3(tl)) return 0;
+  for (int ts = 1; ts <= 2; ++ts) {
+    bool seen[6] = {false, false, false, false, false, false};
+    bool ok = true;
+    for (int t = 0; t < 6 && ok; ++t) {
+      const int c = tl.dw[t] - (ts == 1 ? -1 : 0);
+      if (c < 0 || c > 1) ok = false;
+      else seen[(tl.dh[t] + 1) * 2 + c] = true;
+    }
+    for (int i = 0; i < 6 && ok; ++i) ok = seen[i];
+    if (ok) return ts;
+  }
+  return 0;
+}
+// the phase's taps in ascending (dh, dw) order: the order the packed image and every kernel use
+static TapList deconv_taps_sorted(int kh, int kw, int s, int pad_w, int phase) {
+  TapList tl = deconv_taps(kh, kw, s, pad_w, phase);
+  if (tl.n > 9) return tl;
+  for (int i = 1; i < tl.n; ++i)
+    for (int j = i; j > 0 && (tl.dh[j] < tl.dh[j - 1] || (tl.dh[j] == tl.dh[j - 1] && tl.dw[j] < tl.dw[j - 1])); --j) {
+      std::swap(tl.dh[j], tl.dh[j - 1]); std::swap(tl.dw[j], tl.dw[j - 1]);
+      std::swap(tl.kh[j], tl.kh[j - 1]); std::swap(tl.kw[j], tl.kw[j - 1]);
+    }
+  return tl;
+}
 int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase) {
   if (stride_w < 1 || phase < 0 || phase >= stride_w) return RD_EINVAL;
   TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
   if (tl.n > 9) return RD_ESHAPE;
-  return deconv_embeds_3x3(tl) ? 9 : tl.n;
+  return (deconv_embeds_3x3(tl) && !deconv_tap_set(tl)) ? 9 : tl.n;
 }
 int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
                                int phase, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_deconv: null pointer");
   RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_deconv: dtype");
   RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
-  TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
+  TapList tl = deconv_taps_sorted(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
-  const bool emb = deconv_embeds_3x3(tl);
+  const bool emb = deconv_embeds_3x3(tl) && !deconv_tap_set(tl);
   auto get = [&](int co, int ci, int t) -> float {
     if (emb) {  // t indexes the 3x3 window (dh, dw) = (t/3 - 1, t%3 - 1): the phase's tap there, or zero
       int src = -1;
@@ -181,17 +213,18 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   const int Wout = (Win - 1) * stride_w - 2 * pad_w + kw;  // mx Deconvolution output size
   RD_REQUIRE(Wout > phase, RD_ESHAPE, "deconv2d: empty phase");
   const int Wq = (Wout - phase + stride_w - 1) / stride_w;
-  TapList tl = deconv_taps(kh, kw, stride_w, pad_w, phase);
+  TapList tl = deconv_taps_sorted(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "deconv2d: %d taps per phase unsupported", tl.n);
   allow_conv_lds();
   if (deconv_embeds_3x3(tl)) {
-    tl = conv_taps(3, 3);   // the weights were packed as a 3x3 window (rd_pack_deconv_weight_host)
+    const int ts = deconv_tap_set(tl);
+    if (!ts) tl = conv_taps(3, 3);   // packed as a full 3x3 window with zero weights (rd_pack_deconv_weight_host)
     if (dtype == RD_BF16 && Wout == stride_w * Win && (cout == 64 || cout == 128) && getenv("RD_CONV_V1") == nullptr) {
       // phase pixels of the output seen as [H][Win][stride_w * Cstride]: channel offset phase * Cstride
       const bf16_t* r = (const bf16_t*)residual;
       return launch_conv3(x, x_cstride, x_coff, w_packed_phase, scale, shift, r, r_cstride * stride_w,
                           r_coff + phase * r_cstride, y, y_cstride * stride_w, y_coff + phase * y_cstride, B, H, Win, cin,
-                          cout, flags, 1, (hipStream_t)stream);
+                          cout, flags, 1, (hipStream_t)stream, ts);
     }
   }
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,

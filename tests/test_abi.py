@@ -31,9 +31,9 @@ def test_product_library_loads_and_exports_every_symbol():
     assert L.raw("rd_conv_packed_bytes")(9, 128, 128, R.RD_BF16) == 2 * 9 * 128 * 128
     assert L.raw("rd_conv_packed_bytes")(9, 72, 128, R.RD_BF16) == 2 * 9 * 128 * 128   # 72 -> two 64-channel chunks
     assert L.raw("rd_conv_packed_bytes")(1, 8, 64, R.RD_F32) == 64 * 128
-    # every phase of the graph's transposed convs has 6 taps inside the 3x3 window -> packed (and run) as a 3x3 tap list
-    assert [L.raw("rd_deconv_phase_taps")(3, 8, 4, 2, p) for p in range(4)] == [9, 9, 9, 9]
-    assert [L.raw("rd_deconv_phase_taps")(3, 4, 2, 1, p) for p in range(2)] == [9, 9]
+    # every phase of the graph transposed convs: 6 taps (3 rows x 2 adjacent columns), run as a 6-step unit
+    assert [L.raw("rd_deconv_phase_taps")(3, 8, 4, 2, p) for p in range(4)] == [6, 6, 6, 6]
+    assert [L.raw("rd_deconv_phase_taps")(3, 4, 2, 1, p) for p in range(2)] == [6, 6]
     assert L.raw("rd_deconv_phase_taps")(3, 8, 4, 2, 4) == R.RD_EINVAL
     d = np.array([[0] * 11 + [s] for s in (0.7, 0.9, 0.7, 0.8)], np.float32)
     assert L.wnms_order_host(d).tolist()[:2] == [1, 3]
