@@ -18,6 +18,8 @@
  *   rd_dets12_to_8            bbox3d_12dim_to_8dim                                tools/test.py:43-53
  *   rd_rotated_iou_8pt        _contrib_RotatedIOU (8-point boxes)                 operator_cxx/contrib/rotated_iou-inl.h:509-547
  *   rd_batch_max_iou          Custom op 'batch_rotated_iou' ('bev')               operator_py/batch_rotated_iou.py:11-49
+ *   rd_nms3d                  _contrib_NMS3D (the wnms=False branch)              operator_cxx/contrib/nms_3d.cu:380-534,
+ *                             head/builder.py:530-534
  *   rd_input_transform        test-time input transform chain                     rangedet/core/input.py:14-42,89-229,522-624
  *
  * Conventions
@@ -172,6 +174,18 @@ int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, lo
 /* per proposal: max over gt of the cleaned IoU (NaN/Inf/>1/<0 -> 0).  proposals (n, p_stride>=8) */
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt,
                      void* stream);
+
+/* ---- greedy 3-D NMS: _contrib_NMS3D(boxes, iou_thres, max_keep, normal_iou=False) ----
+ * operator_cxx/contrib/nms_3d.cc:22-68 (shapes), nms_3d.cu:342-378 (overlap measures), :380-464 (mask + keep loop),
+ * :466-534 (forward).  boxes (B,N,10) float32 = 4 BEV corners (x,y) + z_low, z_high, ALREADY sorted by score descending
+ * (head/builder.py:519-534 feeds the decoded boxes of get_sorted_foreground).  Box i is kept when no kept box before it
+ * has overlap(kept, i) > iou_thres; overlap = intersection volume / union volume (polygon clip in BEV x height overlap),
+ * or the axis-aligned 2-D IoU of (x1,y1,x2,y2) = boxes[..., 0:4] when normal_iou != 0.  Stops after max_keep rows.
+ * keep_idx (B,max_keep) int32 padded with -1; bbox_after_nms (B,max_keep,10) padded with 0.
+ * Unlike the reference (N x N/64 words per frame) the mask is held for 1024 rows at a time. */
+size_t rd_nms3d_workspace_bytes(long N, int B);
+int rd_nms3d(const float* boxes, int B, long N, float iou_thres, int max_keep, int normal_iou, int* keep_idx,
+             float* bbox_after_nms, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- test-time input transform chain on the device (the step before the path) ----
  * rangedet/core/input.py:14-42,89-229,522-624 (LoadRecord, ProcessMissValue, SepAndClipData, GetUnnormalizedRange,

@@ -43,6 +43,8 @@ def lib():
                                   ctypes.c_int, fp, ip]
         L.orc_decode3d.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.orc_rotated_iou_8pt.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long]
+        L.orc_nms3d_overlap.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long, ctypes.c_int]
+        L.orc_nms3d.argtypes = [fp, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_int, ctypes.c_int, ip, fp]
         _LIB = L
     return _LIB
 
@@ -113,6 +115,27 @@ def rotated_iou_8pt(b1, b2):
     out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
     lib().orc_rotated_iou_8pt(pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.shape[0], b.shape[0])
     return out
+
+
+def nms3d_overlap(b1, b2, normal_iou=False):
+    """nms_3d.cu:342-378: the pairwise measure NMS3D thresholds, boxes (n,10)."""
+    a, pa = _f(b1)
+    b, pb = _f(b2)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().orc_nms3d_overlap(pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.shape[0], b.shape[0], int(normal_iou))
+    return out
+
+
+def nms3d(boxes, iou_thres, max_keep, normal_iou=False):
+    """_contrib_NMS3D (nms_3d.cu:380-534): boxes (B,N,10) sorted by score -> keep_idx (B,max_keep) int32 (-1 padded),
+    bbox_after_nms (B,max_keep,10) (0 padded)."""
+    bx, pb = _f(boxes)
+    B, N = bx.shape[0], bx.shape[1]
+    keep = np.empty((B, max_keep), dtype=np.int32)
+    out = np.empty((B, max_keep, 10), dtype=np.float32)
+    lib().orc_nms3d(pb, B, N, float(iou_thres), int(max_keep), int(normal_iou),
+                    keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return keep, out
 
 
 def batch_max_iou(proposal8, gt8):

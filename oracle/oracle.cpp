@@ -8,12 +8,14 @@
 //   * hash prefilter          operator_cxx/src_cxx/nms.h:252-307 (BBoxHash)
 //   * Decode3DBbox            operator_cxx/contrib/decode_3d_bbox-inl.h:64-277
 //   * 8-point rotated IoU     operator_cxx/contrib/rotated_iou-inl.h:49-128,130-172,388-493
+//   * greedy 3-D NMS          operator_cxx/contrib/nms_3d.cu:54-183,195-200,220-378 (overlap), :380-464 (mask + keep loop)
 //
 // Pinning status:
 //   wnms / single_overlap : PINNED against the reference source compiled as-is (oracle/_ref, built by
 //                           `make -C oracle ref`; tests/test_oracle_pin.py + tests/golden/*.npz).
-//   decode / rotated IoU  : PARITY UNPINNED.  The reference kernels live in headers that need MXNet's
-//                           internal headers (absent here) so they cannot be built; the reference has no
+//   decode / rotated IoU / NMS3D : PARITY UNPINNED.  The reference kernels live in headers / .cu files that
+//                           need MXNet's internal headers and CUDA (absent here; the CPU FCompute of NMS3D is
+//                           LOG(FATAL), nms_3d.cc:11-17) so they cannot be built; the reference has no
 //                           tests or golden vectors.  This file follows the cited lines literally.
 //
 // Build: g++ -O3 -ffp-contract=off -shared -fPIC (baseline x86-64, no -march: matches the reference's
@@ -421,5 +423,153 @@ void orc_decode3d(const float* delta, const float* pc, float* out, long n, int b
 void orc_rotated_iou_8pt(const float* b1, const float* b2, float* ious, long n1, long n2) {
   for (long i = 0; i < n1; ++i)
     for (long j = 0; j < n2; ++j) ious[i * n2 + j] = iou_8pt(b1 + i * 8, b2 + j * 8);
+}
+}
+
+// ----------------------------------------------------------------------------------------------
+// Greedy 3-D NMS  (_contrib_NMS3D, operator_cxx/contrib/nms_3d.cu).  PARITY UNPINNED: CUDA-only in the
+// reference (the CPU FCompute aborts), no tests or vectors; this follows the cited lines.
+// The reference builds the full N x N/64 bit mask (:380-431) and then keeps box i when its bit is clear,
+// OR-ing row i into the removal set (:433-464).  Row i only ever contributes bits j > i (own word:
+// start = threadIdx.x + 1; earlier words are not read by the keep loop), so that is the plain greedy loop
+// below, evaluated lazily: overlap(i, j) is only needed for kept i and not-yet-removed j.
+// ----------------------------------------------------------------------------------------------
+namespace nms3d {
+constexpr float kEps = 1e-8f;  // :29
+struct V { float x, y; };
+inline V sub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
+inline V add(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
+inline float det2(V a, V b) { return a.x * b.y - a.y * b.x; }                                               // :54-56
+inline float det3(V p1, V p2, V p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }  // :65-67
+inline bool boxes_touch(V p1, V p2, V q1, V q2) {                                                         // :69-75
+  return std::fmin(p1.x, p2.x) <= std::fmax(q1.x, q2.x) && std::fmin(q1.x, q2.x) <= std::fmax(p1.x, p2.x) &&
+         std::fmin(p1.y, p2.y) <= std::fmax(q1.y, q2.y) && std::fmin(q1.y, q2.y) <= std::fmax(p1.y, p2.y);
+}
+// :154-183
+inline bool crossing(V p1, V p0, V q1, V q0, V* out) {
+  if (!boxes_touch(p0, p1, q0, q1)) return false;
+  float s1 = det3(q0, p1, p0);
+  float s2 = det3(p1, q1, p0);
+  float s3 = det3(p0, q1, q0);
+  float s4 = det3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  float s5 = det3(q1, p1, p0);
+  if (std::fabs(s5 - s1) > kEps) {
+    out->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    out->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    out->x = (b0 * c1 - b1 * c0) / D;
+    out->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+// :95-152 (check_in_box3d_anotherway; MARGIN = -1e-2)
+inline bool contains(const float* box, V P) {
+  const float margin = -1e-2f;
+  V A{box[0], box[1]}, B{box[2], box[3]}, C{box[4], box[5]}, D{box[6], box[7]};
+  V AB = sub(B, A), BC = sub(C, B), CD = sub(D, C), DA = sub(A, D);
+  float turn = det2(AB, BC);
+  if (det2(sub(A, P), AB) * turn < margin) return false;
+  if (det2(sub(B, P), BC) * turn < margin) return false;
+  if (det2(sub(C, P), CD) * turn < margin) return false;
+  if (det2(sub(D, P), DA) * turn < margin) return false;
+  return true;
+}
+inline float quad_area(const float* b) {  // :195-200
+  float e1 = (b[0] - b[2]) * (b[0] - b[2]) + (b[1] - b[3]) * (b[1] - b[3]);
+  float e2 = (b[4] - b[2]) * (b[4] - b[2]) + (b[5] - b[3]) * (b[5] - b[3]);
+  return std::sqrt(e1 * e2);
+}
+inline float clip_area(const float* a, const float* b) {  // :220-340
+  V ca[5], cb[5];
+  for (int k = 0; k < 4; ++k) {
+    ca[k] = V{a[2 * k], a[2 * k + 1]};
+    cb[k] = V{b[2 * k], b[2 * k + 1]};
+  }
+  ca[4] = ca[0];
+  cb[4] = cb[0];
+  V pts[16];
+  V mid{0, 0};
+  int n = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (crossing(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[n])) {
+        mid = add(mid, pts[n]);
+        ++n;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (contains(a, cb[k])) {
+      mid = add(mid, cb[k]);
+      pts[n++] = cb[k];
+    }
+    if (contains(b, ca[k])) {
+      mid = add(mid, ca[k]);
+      pts[n++] = ca[k];
+    }
+  }
+  mid.x /= n;
+  mid.y /= n;
+  // bubble sort by polar angle about the centroid (:311-320, point_cmp :191-193)
+  for (int j = 0; j < n - 1; ++j)
+    for (int i = 0; i < n - j - 1; ++i)
+      if (atan2f(pts[i].y - mid.y, pts[i].x - mid.x) > atan2f(pts[i + 1].y - mid.y, pts[i + 1].x - mid.x))
+        std::swap(pts[i], pts[i + 1]);
+  float area = 0;
+  for (int k = 0; k < n - 1; ++k) area += det2(sub(pts[k], pts[0]), sub(pts[k + 1], pts[0]));
+  return (float)(std::fabs(area) / 2.0);
+}
+inline float volume_ratio(const float* a, const float* b) {  // iou_bev :342-368
+  float ha = a[9] - a[8], hb = b[9] - b[8];
+  float oh = std::fmin(a[9], b[9]) - std::fmax(a[8], b[8]);
+  if (oh < 0) oh = 0;
+  float area_a = quad_area(a), area_b = quad_area(b);
+  float va = area_a * ha, vb = area_b * hb;
+  float o2 = clip_area(a, b);
+  float vo = o2 * oh;
+  return vo / std::fmax(va + vb - vo, kEps);
+}
+inline float aligned_iou(const float* a, const float* b) {  // iou_normal :370-378
+  float left = std::fmax(a[0], b[0]), right = std::fmin(a[2], b[2]);
+  float top = std::fmax(a[1], b[1]), bottom = std::fmin(a[3], b[3]);
+  float w = std::fmax(right - left, 0.f), h = std::fmax(bottom - top, 0.f);
+  float inter = w * h;
+  float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / std::fmax(sa + sb - inter, kEps);
+}
+}  // namespace nms3d
+
+extern "C" {
+// pairwise measure, for tests of the geometry alone: out (n1,n2)
+void orc_nms3d_overlap(const float* b1, const float* b2, float* out, long n1, long n2, int normal_iou) {
+  for (long i = 0; i < n1; ++i)
+    for (long j = 0; j < n2; ++j)
+      out[i * n2 + j] = normal_iou ? nms3d::aligned_iou(b1 + i * 10, b2 + j * 10) : nms3d::volume_ratio(b1 + i * 10, b2 + j * 10);
+}
+// boxes (B,N,10) sorted by score; keep_idx (B,max_keep) filled with -1, out (B,max_keep,10) filled with 0 (:484-485)
+void orc_nms3d(const float* boxes, int B, long N, float thresh, int max_keep, int normal_iou, int* keep_idx, float* out) {
+  for (int b = 0; b < B; ++b) {
+    const float* bx = boxes + (size_t)b * N * 10;
+    int* kp = keep_idx + (size_t)b * max_keep;
+    float* ob = out + (size_t)b * max_keep * 10;
+    std::fill(kp, kp + max_keep, -1);
+    std::fill(ob, ob + (size_t)max_keep * 10, 0.f);
+    std::vector<char> gone(N, 0);
+    int nk = 0;
+    for (long i = 0; i < N; ++i) {
+      if (nk >= max_keep) break;
+      if (gone[i]) continue;
+      std::memcpy(ob + (size_t)nk * 10, bx + i * 10, 10 * sizeof(float));
+      kp[nk++] = (int)i;
+      for (long j = i + 1; j < N; ++j) {
+        if (gone[j]) continue;
+        float v = normal_iou ? nms3d::aligned_iou(bx + i * 10, bx + j * 10) : nms3d::volume_ratio(bx + i * 10, bx + j * 10);
+        if (v > thresh) gone[j] = 1;
+      }
+    }
+  }
 }
 }

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
 #include "k_conv1.h"
 #include "k_input.h"
+#include "k_nms3d.h"
 #include "k_meta.h"
 #include "k_misc.h"
 #include "k_riou.h"
@@ -464,6 +465,33 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
   RD_REQUIRE(n > 0 && n_gt > 0 && n_gt <= 256 && p_stride >= 8, RD_ESHAPE, "batch_max_iou: n_gt %d (<=256), p_stride %d (>=8)", n_gt, p_stride);
   hipLaunchKernelGGL(batch_max_iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, proposals, p_stride, gt8, out, n, n_gt);
   return check_launch("batch_max_iou");
+}
+
+// ---- greedy 3-D NMS (_contrib_NMS3D) ----------------------------------------------------------------------------------
+size_t rd_nms3d_workspace_bytes(long N, int B) {
+  if (N <= 0 || N > (1 << 18) || B <= 0) return 0;
+  return nms3d_frame_bytes((int)N) * (size_t)B;
+}
+int rd_nms3d(const float* boxes, int B, long N, float iou_thres, int max_keep, int normal_iou, int* keep_idx,
+             float* bbox_after_nms, void* ws, size_t ws_bytes, void* stream) {
+  RD_REQUIRE(boxes && keep_idx && bbox_after_nms && ws, RD_EINVAL, "nms3d: null pointer");
+  RD_REQUIRE(B > 0 && B <= 65535 && N > 0 && N <= (1 << 18) && max_keep > 0, RD_ESHAPE, "nms3d: B %d, N %ld (<= 262144), max_keep %d", B, N, max_keep);
+  RD_REQUIRE(ws_bytes >= rd_nms3d_workspace_bytes(N, B), RD_EWORKSPACE, "nms3d: workspace %zu < %zu bytes", ws_bytes, rd_nms3d_workspace_bytes(N, B));
+  RD_REQUIRE(((uintptr_t)ws & 7) == 0, RD_EINVAL, "nms3d: workspace must be 8-byte aligned");
+  Nms3dArgs a;
+  a.boxes = boxes; a.ws = (unsigned char*)ws; a.ws_frame = nms3d_frame_bytes((int)N);
+  a.keep = keep_idx; a.out = bbox_after_nms;
+  a.N = (int)N; a.ncw = (int)((N + 63) / 64); a.max_keep = max_keep; a.normal_iou = normal_iou ? 1 : 0; a.thresh = iou_thres;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(RD_PROF_WNMS, st);
+  const int gi = (std::max(std::max(a.ncw, max_keep), 2) + 255) / 256;
+  hipLaunchKernelGGL(nms3d_init_kernel, dim3(gi, B), dim3(256), 0, st, a);
+  for (int r0 = 0, blk = 64; r0 < a.N; r0 += blk, blk = std::min(2 * blk, NMS3D_RB)) {
+    const int rows = std::min(blk, a.N - r0);
+    hipLaunchKernelGGL(nms3d_pairs_kernel, dim3((a.N + NMS3D_SEG - 1) / NMS3D_SEG, rows, B), dim3(256), 0, st, a, r0);
+    hipLaunchKernelGGL(nms3d_scan_kernel, dim3(B), dim3(256), (size_t)a.ncw * 8, st, a, r0, blk);
+  }
+  return check_launch("nms3d");
 }
 
 // ---- input transform chain ----------------------------------------------------------------------------------------

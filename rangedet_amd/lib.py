@@ -60,6 +60,8 @@ SIGNATURES = {
     "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "rd_batch_max_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "rd_nms3d_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "rd_nms3d": (c_int, [c_void_p, c_int, c_long, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rd_input_transform": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "rd_prof_enable": (c_int, [c_int]),
     "rd_prof_reset": (c_int, []),

@@ -11,6 +11,7 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
                                                    -> rd_head_out into flat (B,N[,8]) buffers   (builder.py:242-261,99-154)
   sigmoid + Custom(get_sorted_foreground)          -> rd_sorted_foreground(apply_sigmoid=1)     (builder.py:459-461,512-521)
   contrib.Decode3DBbox                             -> rd_decode3d_bbox                          (builder.py:522-525)
+  contrib.NMS3D (wnms=False)                       -> rd_nms3d                                  (builder.py:530-534)
 Anything that does not match raises NotImplementedError at lowering time -- there is no slow generic path.
 """
 from dataclasses import dataclass, field
@@ -327,6 +328,9 @@ class Lowering:
             v = ("flat", self._sorted_fg(s)[s.index])
         elif s.op == "Decode3DBbox":
             v = ("flat", self._decode(s))
+        elif s.op == "NMS3D":
+            keep, final = self._nms3d(s)
+            v = ("flat_i32", keep) if s.index == 0 else ("flat", final)
         else:
             raise NotImplementedError("graph output %r (op %s) has no HIP lowering" % (s0.name, s.op))
         self.memo[key] = v
@@ -417,6 +421,23 @@ class Lowering:
         out = FlatRef(self.new_buf(self.B * k * 10 * 4, persistent=True), (k, 10))
         self.step("decode", delta=o_d, pc=o_p, out=out, k=k, box_type=o_d.shape[1], is_bin=int(s.attrs["is_bin"]))
         return out
+
+
+    def _nms3d(self, s):
+        key = ("nms3d", s.uid)
+        if key in self.memo:
+            return self.memo[key]
+        (bx,) = s.inputs
+        if bx.op != "Decode3DBbox":
+            raise NotImplementedError("NMS3D input must be the Decode3DBbox output (score-sorted boxes)")
+        boxes = self._decode(bx)
+        n, mk = boxes.shape[0], int(s.attrs["max_keep"])
+        keep = FlatRef(self.new_buf(self.B * mk * 4, persistent=True), (mk,))
+        final = FlatRef(self.new_buf(self.B * mk * 10 * 4, persistent=True), (mk, 10))
+        self.step("nms3d", boxes=boxes, N=n, thr=float(s.attrs["iou_thres"]), max_keep=mk,
+                  normal_iou=int(s.attrs["normal_iou"]), keep=keep, out=final)
+        self.memo[key] = (keep, final)
+        return self.memo[key]
 
 
 def lower(test_symbol, input_shapes, dtype=RD_BF16, batch=1):

@@ -182,9 +182,10 @@ class _Contrib:
 
     @staticmethod
     def NMS3D(boxes, iou_thres, max_keep, normal_iou=False, name=None):
-        raise NotImplementedError(
-            "contrib.NMS3D (the wnms=False branch, builder.py:530-534) is not built: every shipped config sets "
-            "RpnParam.wnms=True; see DESIGN.md 'out of scope'")
+        """_contrib_NMS3D (operator_cxx/contrib/nms_3d.cc:22-68): outputs (idx (B,max_keep) int32, bbox_after_nms
+        (B,max_keep,10)); the wnms=False branch of the head (builder.py:530-534)."""
+        return Symbol("NMS3D", [boxes], dict(iou_thres=float(iou_thres), max_keep=int(max_keep), normal_iou=bool(normal_iou)),
+                      name, nout=2)
 
 
 contrib = _Contrib()

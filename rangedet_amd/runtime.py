@@ -107,7 +107,7 @@ class Executor:
                     last_use[v.buf] = i
                     first_def.setdefault(v.buf, i)
         for kind, v in plan.outputs:
-            if kind == "flat":
+            if kind in ("flat", "flat_i32"):
                 last_use[v.buf] = len(plan.steps) + 1
         free = {}
         release = {}
@@ -166,6 +166,10 @@ class Executor:
             w = np.asarray(P[st["name"] + "_weight"], np.float32).reshape(-1, st["x"].C)[r0:r1]
             b["w"] = A.upload(w)
             b["bias"] = A.upload(np.asarray(P[st["name"] + "_bias"], np.float32)[r0:r1])
+        elif k == "nms3d":
+            nb = L.raw("rd_nms3d_workspace_bytes")(st["N"], self.B)
+            b["ws"] = A.alloc(nb)
+            b["ws_bytes"] = nb
         elif k == "sorted_fg":
             nb = L.raw("rd_sorted_foreground_workspace_bytes")(st["N"], st["k"]) * self.B
             b["ws"] = A.alloc(nb)
@@ -229,6 +233,9 @@ class Executor:
             elif k == "decode":
                 L.call("rd_decode3d_bbox", self.p(b["delta"]), self.p(b["pc"]), self.p(b["out"]), B, b["k"],
                        b["box_type"], b["is_bin"], st_)
+            elif k == "nms3d":
+                L.call("rd_nms3d", self.p(b["boxes"]), B, b["N"], b["thr"], b["max_keep"], b["normal_iou"], self.p(b["keep"]),
+                       self.p(b["out"]), A.ptr(b["ws"]), b["ws_bytes"], st_)
             else:
                 raise RuntimeError("unknown plan step %r" % k)
         if only is not None:
@@ -237,6 +244,8 @@ class Executor:
         for kind, v in self.plan.outputs:
             if kind == "flat":
                 outs.append(A.view_f32(self._phys[v.buf], (B,) + tuple(v.shape)))
+            elif kind == "flat_i32":
+                outs.append(A.view_i32(self._phys[v.buf], (B,) + tuple(v.shape)))
             elif kind == "input":
                 outs.append(inputs.get(v))
             else:

@@ -8,6 +8,7 @@ import pytest
 
 from conftest import BOTH, HIP_ONLY
 from emu_util import small_shapes
+from oracle import cpu_ops as O
 from oracle import graph_ref as G
 from rangedet_amd import lib as R
 from rangedet_amd import mx, synth
@@ -124,6 +125,48 @@ def test_e2e_small_f32(be):
     assert ok.sum() > k // 10
     assert np.abs(bx[0][ok] - ref["decoded_bbox"][0][ok]).max() < 1e-3
     assert outs[0] is None and outs[3].shape == (1,)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_e2e_nms3d_branch_f32(be):
+    """RpnParam.wnms = False: get_prediction_of_one_type ends in contrib.NMS3D (builder.py:530-534) and the test symbol
+    returns (score, bbox_after_nms, keep_inds) per class.  The lowered plan runs rd_nms3d on the decoded boxes; its outputs
+    must equal the oracle's NMS3D applied to those same boxes, bit for bit."""
+    emu = be.name == "emu"
+    H, Wr, W, k = (8, 30, 32, 150) if emu else (16, 250, 256, 2000)
+    cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
+    from rangedet_amd.symbol.backbone.dla_backbone import DLABackbone
+    from rangedet_amd.symbol.head.builder import RangeRCNN, RangeRpnHead
+    RP = cfg[2]
+    nb = dict({kk: 1 for kk in G.Cfg.num_block}, res1=2) if emu else G.Cfg.num_block
+    bp = type("BackboneParam", (), dict(fp16=True, normalizer=RP.normalizer, fpn_strides=(1, 2, 4), batch_image=1,
+                                        range_image_shape_hw=(H, W), add_data_sc=True, num_block=nb,
+                                        num_filter=G.Cfg.num_filter,
+                                        meta_kernel_units={'res1_unit2': dict(stride=1, meta_func_param='meta_baseline_bias',
+                                                                              data_channels=64, coord_channels=3,
+                                                                              channel_list=[32, 64], kernel_size=3)}))
+    if emu:
+        RP.head.cls_conv_layers = RP.head.reg_conv_layers = 1
+    RP.wnms = False
+    thr, mk = RP.all_proposal.nms_thr['veh'], RP.all_proposal.rpn_post_nms_top_n['veh']
+    dp = type("DetParam", (), dict(fpn_strides=(1, 2, 4), class_names=('veh',)))
+    sym = RangeRCNN(dp).get_test_symbol(DLABackbone(bp), RangeRpnHead(RP))
+    plan = lower(sym, small_shapes(H, W), R.RD_F32, 1)
+    st = [s for s in plan.steps if s["kind"] == "nms3d"]
+    assert len(st) == 1 and st[0]["N"] == k and st[0]["max_keep"] == mk and abs(st[0]["thr"] - thr) < 1e-7
+    P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
+    fr = synth.make_frame(0, W=Wr, pad_W=W, H=H)
+    ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
+    outs = ex.forward(fr)
+    be.alloc.sync()
+    final, keep = np.array(be.alloc.to_numpy(outs[2])), np.array(be.alloc.to_numpy(outs[3]))
+    assert final.shape == (1, mk, 10) and keep.shape == (1, mk) and keep.dtype == np.int32
+    boxes = ex.read_flat(st[0]["boxes"])
+    rk, ro = O.nms3d(boxes, thr, mk, False)
+    assert np.array_equal(keep, rk)
+    assert np.array_equal(final.view(np.uint32), ro.view(np.uint32))
+    nk = int((keep[0] >= 0).sum())
+    assert 0 < nk <= mk and np.all(np.diff(keep[0, :nk]) > 0)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

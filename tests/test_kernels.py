@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import BOTH
+from conftest import BOTH, HIP_ONLY
 from emu_util import bf16_round, empty_nhwc, from_nhwc, to_nhwc, bf16_bits_to_f32
 from oracle import cpu_ops as O
 from oracle import graph_ref as G
@@ -423,6 +423,92 @@ def test_rotated_iou_8pt(be):
     mx = be.empty(b1.shape[0] * 4)
     L.call("rd_batch_max_iou", be.ptr(be.up(b1)), 8, be.ptr(be.up(gt)), be.ptr(mx), b1.shape[0], gt.shape[0], be.stream)
     assert np.abs(be.down(mx, np.float32, (b1.shape[0],)) - O.batch_max_iou(b1, gt)).max() < 1e-5
+
+
+def nms3d_boxes(B, n_obj, rep, seed, jitter=0.05):
+    """(B,N,10) score-sorted boxes: 4 BEV corners + z_low, z_high (the layout Decode3DBbox hands to NMS3D)."""
+    out = []
+    for b in range(B):
+        d = synth.cluster_dets(n_obj, rep, seed=seed + b, jitter=jitter)
+        d = d[np.argsort(-d[:, 11], kind="stable")]
+        out.append(np.concatenate([d[:, :8], d[:, 9:10], d[:, 9:10] + d[:, 10:11]], axis=1))
+    return np.stack(out).astype(np.float32)
+
+
+def run_nms3d(be, boxes, thr, max_keep, normal):
+    L = be.lib
+    B, N = boxes.shape[:2]
+    wb = L.raw("rd_nms3d_workspace_bytes")(N, B)
+    assert wb > 0
+    ws = be.empty(wb)
+    keep, out = be.empty(B * max_keep * 4), be.empty(B * max_keep * 40)
+    L.call("rd_nms3d", be.ptr(be.up(boxes)), B, N, thr, max_keep, int(normal), be.ptr(keep), be.ptr(out), be.ptr(ws), wb, be.stream)
+    return be.down(keep, np.int32, (B, max_keep)), be.down(out, np.float32, (B, max_keep, 10))
+
+
+NMS3D_CASES = [
+    # B, n_obj, rep, thr, max_keep, normal_iou
+    (2, 12, 30, 0.1, 500, False),     # every survivor kept (fewer than max_keep), N = 360: one row block, ragged last word
+    (1, 40, 8, 0.5, 25, False),       # stops at max_keep
+    (1, 30, 45, 0.3, 100, False),     # N = 1350: two row blocks
+    (2, 20, 10, 0.3, 64, True),       # axis-aligned measure on columns 0..3
+    (1, 1, 1, 0.1, 4, False),         # a single box
+]
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", NMS3D_CASES)
+def test_nms3d_vs_oracle(be, case):
+    """rd_nms3d against the restatement of nms_3d.cu: keep indices and copied rows bit-equal, padding -1 / 0."""
+    B, n_obj, rep, thr, max_keep, normal = case
+    boxes = nms3d_boxes(B, n_obj, rep, seed=11)
+    if normal:   # make columns 0..3 proper (x1,y1,x2,y2) rectangles
+        xy = boxes[..., :8].reshape(B, -1, 4, 2)
+        boxes[..., 0:2] = xy.min(axis=2)
+        boxes[..., 2:4] = xy.max(axis=2)
+    keep, out = run_nms3d(be, boxes, thr, max_keep, normal)
+    rk, ro = O.nms3d(boxes, thr, max_keep, normal)
+    assert np.array_equal(keep, rk)
+    assert np.array_equal(out.view(np.uint32), ro.view(np.uint32))
+    assert (rk[:, 0] == 0).all()                                   # the best box is always kept
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_nms3d_overlap_degenerate(be):
+    """Degenerate inputs follow the reference's arithmetic too: identical boxes, zero-height overlap, zero-area boxes
+    (0/eps = 0: never suppressed), a box far away; through max_keep = N so that every decision is visible."""
+    base = nms3d_boxes(1, 3, 2, seed=5)[0]
+    extra = base[:2].copy()                                         # exact duplicates of the two best boxes
+    flat = base[2:3].copy(); flat[0, 9] = flat[0, 8]                # zero height
+    dot = np.zeros((1, 10), np.float32); dot[0, 9] = 1.0            # zero area at the origin
+    above = base[0:1].copy(); above[0, 8] += 50; above[0, 9] += 50  # same footprint, no height overlap
+    boxes = np.concatenate([base, extra, flat, dot, dot, above])[None]
+    N = boxes.shape[1]
+    keep, out = run_nms3d(be, boxes, 0.1, N, False)
+    rk, ro = O.nms3d(boxes, 0.1, N, False)
+    assert np.array_equal(keep, rk) and np.array_equal(out.view(np.uint32), ro.view(np.uint32))
+    L = be.lib
+    buf = be.empty(4096)
+    assert L.raw("rd_nms3d")(be.ptr(buf), 1, 0, 0.1, 4, 0, be.ptr(buf), be.ptr(buf), be.ptr(buf), 4096, be.stream) == R.RD_ESHAPE
+    assert L.raw("rd_nms3d")(be.ptr(buf), 1, 64, 0.1, 4, 0, be.ptr(buf), be.ptr(buf), be.ptr(buf), 16, be.stream) == R.RD_EWORKSPACE
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_nms3d_full_size_hip(be):
+    """N = 50 000 (rpn_pre_nms_top_n of the shipped configs): same keep list as the lazy greedy oracle, and the keep list
+    is a fixed point (no kept pair overlaps above the threshold; every dropped box among the first rows has a kept
+    suppressor)."""
+    boxes = nms3d_boxes(2, 125, 400, seed=3, jitter=0.15)          # 125 objects x 400 duplicates = 50 000 per frame
+    assert boxes.shape[1] == 50000
+    keep, out = run_nms3d(be, boxes, 0.1, 500, False)
+    rk, ro = O.nms3d(boxes, 0.1, 500, False)
+    assert np.array_equal(keep, rk) and np.array_equal(out.view(np.uint32), ro.view(np.uint32))
+    for b in range(2):
+        k = keep[b][keep[b] >= 0]
+        m = O.nms3d_overlap(boxes[b, k], boxes[b, k])
+        assert (np.triu(m, 1) <= 0.1).all()
+        first = np.setdiff1d(np.arange(2000), k)
+        assert (O.nms3d_overlap(boxes[b, k], boxes[b, first]) > 0.1).any(axis=0).all()
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
