@@ -17,7 +17,8 @@ RD_WNMS_MAX_K = 16384
 PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_PATH = os.path.join(_HERE, "librangedet_hip.so")
+# RANGEDET_HIP_LIB: another build of the same library (A/B timing of two builds on one box); never a CPU substitute
+DEFAULT_PATH = os.environ.get("RANGEDET_HIP_LIB") or os.path.join(_HERE, "librangedet_hip.so")
 
 c_int, c_long, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
@@ -98,7 +99,7 @@ class Lib:
         # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library is dlopen'ed first it pulls in /opt/rocm's
         # copy, torch then loads its own, and the process ends up with two runtimes -- the second one sees no device
         # ("no ROCm-capable device is detected").  Loading torch first makes both resolve to the same runtime.
-        if os.path.basename(path) == os.path.basename(DEFAULT_PATH):
+        if os.path.basename(path).startswith("librangedet_hip"):
             try:
                 import torch  # noqa: F401
             except ImportError:
