@@ -20,6 +20,8 @@
  *   rd_batch_max_iou          Custom op 'batch_rotated_iou' ('bev')               operator_py/batch_rotated_iou.py:11-49
  *   rd_nms3d                  _contrib_NMS3D (the wnms=False branch)              operator_cxx/contrib/nms_3d.cu:380-534,
  *                             head/builder.py:530-534
+ *   rd_assign3d_v2            processing_cxx.assign3D_v2                          operator_cxx/src_cxx/assigner.h:11-85
+ *   rd_get_point_num          processing_cxx.get_point_num                        operator_cxx/src_cxx/assigner.h:87-109
  *   rd_input_transform        test-time input transform chain                     rangedet/core/input.py:14-42,89-229,522-624
  *
  * Conventions
@@ -186,6 +188,21 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
 size_t rd_nms3d_workspace_bytes(long N, int B);
 int rd_nms3d(const float* boxes, int B, long N, float iou_thres, int max_keep, int normal_iou, int* keep_idx,
              float* bbox_after_nms, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- training-target assignment: processing_cxx.assign3D_v2 / get_point_num (pybinding.cpp:9-10) ----
+ * assigner.h:11-85.  For every point (pc (N,3), row-major) the index of the FIRST ground-truth box that contains it, or -1.
+ * bbox (M,24) = 8 corners x (x,y,z): A B C D bottom face, E.. top face; bbox_center (M,3); bbox_radius (M) is compared with
+ * the SQUARED centre distance, and so is max_dist (the reference does both, :47-51); mask (N) < 0.5 or is_in_nlz (N) > 0
+ * skips the point; the six limits are the caller's axis-aligned bounds of all boxes (input.py:303-308).  out (N) int32.
+ * M <= 1024 (boxes are held in LDS). */
+int rd_assign3d_v2(const float* pc, const float* bbox, const float* bbox_center, const float* bbox_radius, const float* mask,
+                   const float* is_in_nlz, long N, int M, float max_x, float min_x, float max_y, float min_y, float max_z,
+                   float min_z, float max_dist, int* out, void* stream);
+/* assigner.h:87-109.  bbox_inds (N) float32 box index per point (negative = none); out (N) float32 = number of points that
+ * share the point's box, -1 for points without a box.  Indices >= 500 (MAX_BOX_NUM, :92) are outside the reference's
+ * contract (it writes out of bounds); here such points get -1. */
+size_t rd_get_point_num_workspace_bytes(void);
+int rd_get_point_num(const float* bbox_inds, long N, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- test-time input transform chain on the device (the step before the path) ----
  * rangedet/core/input.py:14-42,89-229,522-624 (LoadRecord, ProcessMissValue, SepAndClipData, GetUnnormalizedRange,

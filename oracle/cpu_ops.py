@@ -43,6 +43,8 @@ def lib():
                                   ctypes.c_int, fp, ip]
         L.orc_decode3d.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.orc_rotated_iou_8pt.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long]
+        L.orc_assign3d_v2.argtypes = [fp] * 6 + [ctypes.c_long, ctypes.c_int] + [ctypes.c_float] * 7 + [ip]
+        L.orc_get_point_num.argtypes = [fp, ctypes.c_long, fp]
         L.orc_nms3d_overlap.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long, ctypes.c_int]
         L.orc_nms3d.argtypes = [fp, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_int, ctypes.c_int, ip, fp]
         _LIB = L
@@ -136,6 +138,24 @@ def nms3d(boxes, iou_thres, max_keep, normal_iou=False):
     lib().orc_nms3d(pb, B, N, float(iou_thres), int(max_keep), int(normal_iou),
                     keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return keep, out
+
+
+def assign3d_v2(pc, bbox, center, radius, mask, nlz, max_x, min_x, max_y, min_y, max_z, min_z, max_dist):
+    """assigner.h:11-85 -> (N,) int32."""
+    (p, pp), (b, pb), (c, pcn), (r, pr), (m, pm), (z, pz) = (_f(x) for x in (pc, bbox, center, radius, mask, nlz))
+    N, M = p.reshape(-1, 3).shape[0], b.reshape(-1, 24).shape[0]
+    out = np.empty(N, dtype=np.int32)
+    lib().orc_assign3d_v2(pp, pb, pcn, pr, pm, pz, N, M, max_x, min_x, max_y, min_y, max_z, min_z, max_dist,
+                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    return out
+
+
+def get_point_num(inds):
+    """assigner.h:87-109 -> (N,) float32."""
+    v, pv = _f(inds)
+    out = np.empty(v.size, dtype=np.float32)
+    lib().orc_get_point_num(pv, v.size, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
 
 
 def batch_max_iou(proposal8, gt8):

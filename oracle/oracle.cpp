@@ -8,6 +8,7 @@
 //   * hash prefilter          operator_cxx/src_cxx/nms.h:252-307 (BBoxHash)
 //   * Decode3DBbox            operator_cxx/contrib/decode_3d_bbox-inl.h:64-277
 //   * 8-point rotated IoU     operator_cxx/contrib/rotated_iou-inl.h:49-128,130-172,388-493
+//   * assign3D_v2 / get_point_num   operator_cxx/src_cxx/assigner.h:11-85,87-109
 //   * greedy 3-D NMS          operator_cxx/contrib/nms_3d.cu:54-183,195-200,220-378 (overlap), :380-464 (mask + keep loop)
 //
 // Pinning status:
@@ -571,5 +572,63 @@ void orc_nms3d(const float* boxes, int B, long N, float thresh, int max_keep, in
       }
     }
   }
+}
+}
+
+// ----------------------------------------------------------------------------------------------
+// assign3D_v2 / get_point_num  (operator_cxx/src_cxx/assigner.h).  PARITY UNPINNED: the header needs Eigen
+// (not in this image), the reference has no tests for it.  Plain-array restatement of the cited lines; the
+// centre distance is summed as x^2 + (y^2 + z^2), the order of Eigen's unrolled 3-element reduction (:47).
+// ----------------------------------------------------------------------------------------------
+extern "C" {
+void orc_assign3d_v2(const float* pc, const float* bbox, const float* center, const float* radius, const float* mask,
+                     const float* nlz, long N, int M, float max_x, float min_x, float max_y, float min_y, float max_z,
+                     float min_z, float max_dist, int* out) {
+  std::vector<float> dist(M);
+  for (long i = 0; i < N; ++i) {
+    out[i] = -1;
+    if (mask[i] < 0.5f || nlz[i] > 0) continue;  // :42
+    const float* P = pc + i * 3;
+    if (P[0] < min_x || P[0] > max_x) continue;
+    if (P[1] < min_y || P[1] > max_y) continue;
+    if (P[2] < min_z || P[2] > max_z) continue;
+    float lo = 0;
+    for (int j = 0; j < M; ++j) {
+      float dx = center[j * 3] - P[0], dy = center[j * 3 + 1] - P[1], dz = center[j * 3 + 2] - P[2];
+      dist[j] = dx * dx + (dy * dy + dz * dz);
+      if (j == 0 || dist[j] < lo) lo = dist[j];
+    }
+    if (lo > max_dist) continue;  // :49
+    for (int j = 0; j < M; ++j) {
+      const float* b = bbox + (size_t)j * 24;
+      const float *A = b, *B = b + 3, *C = b + 6, *D = b + 9, *E = b + 12;
+      if (dist[j] > radius[j]) continue;
+      if (P[2] <= A[2] || P[2] >= E[2]) continue;
+      if (P[0] < A[0] && P[0] < B[0] && P[0] < C[0] && P[0] < D[0]) continue;
+      if (P[1] < A[1] && P[1] < B[1] && P[1] < C[1] && P[1] < D[1]) continue;
+      if (P[0] > A[0] && P[0] > B[0] && P[0] > C[0] && P[0] > D[0]) continue;
+      if (P[1] > A[1] && P[1] > B[1] && P[1] > C[1] && P[1] > D[1]) continue;
+      float BPx = P[0] - B[0], BPy = P[1] - B[1];
+      float BAx = A[0] - B[0], BAy = A[1] - B[1];
+      if (BAx * BPx + BAy * BPy <= 0) continue;
+      float BCx = C[0] - B[0], BCy = C[1] - B[1];
+      if (BCx * BPx + BCy * BPy <= 0) continue;
+      float DPx = P[0] - D[0], DPy = P[1] - D[1];
+      float DAx = A[0] - D[0], DAy = A[1] - D[1];
+      if (DAx * DPx + DAy * DPy <= 0) continue;
+      float DCx = C[0] - D[0], DCy = C[1] - D[1];
+      if (DCx * DPx + DCy * DPy <= 0) continue;
+      out[i] = j;
+      break;
+    }
+  }
+}
+void orc_get_point_num(const float* inds, long N, float* out) {  // :87-109, MAX_BOX_NUM = 500
+  float count[500] = {0};
+  for (long i = 0; i < N; ++i) {
+    if (inds[i] < 0) continue;
+    count[(long)inds[i]] += 1;
+  }
+  for (long i = 0; i < N; ++i) out[i] = inds[i] < 0 ? -1.f : count[(long)inds[i]];
 }
 }

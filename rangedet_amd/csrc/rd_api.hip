@@ -1,6 +1,7 @@
 // librangedet_hip.so -- C ABI (include/rangedet_hip.h) over the hand-written gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared rd_api.hip -o librangedet_hip.so
 #include "k_conv1.h"
+#include "k_assign.h"
 #include "k_input.h"
 #include "k_nms3d.h"
 #include "k_meta.h"
@@ -492,6 +493,33 @@ int rd_nms3d(const float* boxes, int B, long N, float iou_thres, int max_keep, i
     hipLaunchKernelGGL(nms3d_scan_kernel, dim3(B), dim3(256), (size_t)a.ncw * 8, st, a, r0, blk);
   }
   return check_launch("nms3d");
+}
+
+// ---- target assignment (processing_cxx.assign3D_v2 / get_point_num) --------------------------------------------------
+int rd_assign3d_v2(const float* pc, const float* bbox, const float* bbox_center, const float* bbox_radius, const float* mask,
+                   const float* is_in_nlz, long N, int M, float max_x, float min_x, float max_y, float min_y, float max_z,
+                   float min_z, float max_dist, int* out, void* stream) {
+  RD_REQUIRE(pc && bbox && bbox_center && bbox_radius && mask && is_in_nlz && out, RD_EINVAL, "assign3d_v2: null pointer");
+  RD_REQUIRE(N > 0 && M > 0 && M <= ASSIGN_MAX_BOXES, RD_ESHAPE, "assign3d_v2: N %ld, M %d (1..%d)", N, M, ASSIGN_MAX_BOXES);
+  AssignArgs a;
+  a.pc = pc; a.bbox = bbox; a.center = bbox_center; a.radius = bbox_radius; a.mask = mask; a.nlz = is_in_nlz; a.out = out;
+  a.N = N; a.M = M;
+  a.max_x = max_x; a.min_x = min_x; a.max_y = max_y; a.min_y = min_y; a.max_z = max_z; a.min_z = min_z; a.max_dist = max_dist;
+  hipLaunchKernelGGL(assign3d_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)M * 14 * 4, (hipStream_t)stream, a);
+  return check_launch("assign3d_v2");
+}
+size_t rd_get_point_num_workspace_bytes(void) { return POINT_NUM_MAX_BOXES * sizeof(int); }
+int rd_get_point_num(const float* bbox_inds, long N, float* out, void* ws, size_t ws_bytes, void* stream) {
+  RD_REQUIRE(bbox_inds && out && ws, RD_EINVAL, "get_point_num: null pointer");
+  RD_REQUIRE(N > 0, RD_ESHAPE, "get_point_num: N %ld", N);
+  RD_REQUIRE(ws_bytes >= rd_get_point_num_workspace_bytes(), RD_EWORKSPACE, "get_point_num: workspace %zu < %zu bytes", ws_bytes,
+             rd_get_point_num_workspace_bytes());
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, rd_get_point_num_workspace_bytes(), st) != hipSuccess) return fail(RD_EHIP, "get_point_num: memset failed");
+  const unsigned g = (unsigned)std::min<long>((N + 255) / 256, 1024);
+  hipLaunchKernelGGL(point_num_count_kernel, dim3(g), dim3(256), 0, st, bbox_inds, N, (int*)ws);
+  hipLaunchKernelGGL(point_num_gather_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, bbox_inds, N, (const int*)ws, out);
+  return check_launch("get_point_num");
 }
 
 // ---- input transform chain ----------------------------------------------------------------------------------------

@@ -63,6 +63,9 @@ SIGNATURES = {
     "rd_batch_max_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rd_nms3d_workspace_bytes": (c_size_t, [c_long, c_int]),
     "rd_nms3d": (c_int, [c_void_p, c_int, c_long, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rd_assign3d_v2": (c_int, [c_void_p] * 6 + [c_long, c_int] + [c_float] * 7 + [c_void_p, c_void_p]),
+    "rd_get_point_num_workspace_bytes": (c_size_t, []),
+    "rd_get_point_num": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rd_input_transform": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "rd_prof_enable": (c_int, [c_int]),
     "rd_prof_reset": (c_int, []),

@@ -511,6 +511,83 @@ def test_nms3d_full_size_hip(be):
         assert (O.nms3d_overlap(boxes[b, k], boxes[b, first]) > 0.1).any(axis=0).all()
 
 
+def assign_case(N, M, seed):
+    """Points around M rotated ground-truth boxes (8 corners: A B C D bottom, E F G H top), the way
+    Bbox3dAssigner.get_faster_bbox3d_ind_assigner (rangedet/core/input.py:293-320) calls assign3D_v2."""
+    rng = np.random.default_rng(seed)
+    ctr = rng.uniform(-40, 40, (M, 2))
+    yaw = rng.uniform(-np.pi, np.pi, M)
+    l, w, h = rng.uniform(3.5, 9, M), rng.uniform(1.6, 2.6, M), rng.uniform(1.4, 3.0, M)
+    z0 = rng.uniform(-1, 0.5, M)
+    cor = np.stack([np.stack([l / 2, -w / 2], 1), np.stack([-l / 2, -w / 2], 1), np.stack([-l / 2, w / 2], 1),
+                    np.stack([l / 2, w / 2], 1)], 1)                                     # (M,4,2)
+    rot = np.stack([np.stack([np.cos(yaw), -np.sin(yaw)], 1), np.stack([np.sin(yaw), np.cos(yaw)], 1)], 1)
+    xy = np.einsum('mij,mkj->mki', rot, cor) + ctr[:, None]
+    bot = np.concatenate([xy, np.repeat(z0[:, None, None], 4, 1)], 2)
+    top = np.concatenate([xy, np.repeat((z0 + h)[:, None, None], 4, 1)], 2)
+    gt = np.concatenate([bot, top], 1).astype(np.float32)                               # (M,8,3)
+    near = ctr[rng.integers(0, M, N // 2)] + rng.normal(0, 2.5, (N // 2, 2))
+    pts = np.concatenate([np.concatenate([near, rng.uniform(-1.5, 4, (N // 2, 1))], 1),
+                          np.concatenate([rng.uniform(-75, 75, (N - N // 2, 2)), rng.uniform(-3, 6, (N - N // 2, 1))], 1)])
+    pts = pts[rng.permutation(N)].astype(np.float32)
+    pts[:M] = gt[:, 0]                                                                  # points exactly on corners / faces
+    pts[M:2 * M] = gt.mean(axis=1)
+    mask = (rng.uniform(size=N) > 0.1).astype(np.float32)
+    nlz = (rng.uniform(size=N) > 0.97).astype(np.float32)
+    lim = [float(gt[:, :, 0].max()), float(gt[:, :, 0].min()), float(gt[:, :, 1].max()), float(gt[:, :, 1].min()),
+           float(gt[:, :, 2].max()), float(gt[:, :, 2].min())]
+    return pts, gt.reshape(M, 24), gt.mean(axis=1), np.full(M, 100, np.float32), mask, nlz, lim
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("max_dist", [20.0, 2.0])
+def test_assign3d_and_point_num(be, max_dist):
+    """rd_assign3d_v2 / rd_get_point_num against the restatement of assigner.h: box index per point exact, counts exact."""
+    N = 8000 if be.name == "emu" else 64 * 2650
+    pts, gt, ctr, rad, mask, nlz, lim = assign_case(N, 60, seed=4)
+    L = be.lib
+    out = be.empty(N * 4)
+    L.call("rd_assign3d_v2", be.ptr(be.up(pts)), be.ptr(be.up(gt)), be.ptr(be.up(ctr)), be.ptr(be.up(rad)), be.ptr(be.up(mask)),
+           be.ptr(be.up(nlz)), N, 60, *lim, max_dist, be.ptr(out), be.stream)
+    got = be.down(out, np.int32, (N,))
+    ref = O.assign3d_v2(pts, gt, ctr, rad, mask, nlz, *lim, max_dist)
+    assert np.array_equal(got, ref)
+    assert (ref >= 0).sum() > N // 50 and (ref[(mask < 0.5) | (nlz > 0)] == -1).all()
+    nb = L.raw("rd_get_point_num_workspace_bytes")()
+    ws, cnt = be.empty(nb), be.empty(N * 4)
+    inds = got.astype(np.float32)
+    L.call("rd_get_point_num", be.ptr(be.up(inds)), N, be.ptr(cnt), be.ptr(ws), nb, be.stream)
+    gc = be.down(cnt, np.float32, (N,))
+    assert np.array_equal(gc, O.get_point_num(inds))
+    hist = np.bincount(got[got >= 0], minlength=60)
+    assert np.array_equal(gc[got >= 0], hist[got[got >= 0]].astype(np.float32)) and (gc[got < 0] == -1).all()
+    buf = be.empty(4096)
+    assert L.raw("rd_assign3d_v2")(*([be.ptr(buf)] * 6), 10, 0, *lim, 20.0, be.ptr(buf), be.stream) == R.RD_ESHAPE
+    assert L.raw("rd_assign3d_v2")(*([be.ptr(buf)] * 6), 10, 5000, *lim, 20.0, be.ptr(buf), be.stream) == R.RD_ESHAPE
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_processing_cxx_module_surface(be):
+    """The drop-in module, called the way the reference's callers do (tools/test.py:211-218, rangedet/core/input.py:311-319,
+    433-435): same positional arguments, same result shapes."""
+    from rangedet_amd import processing_cxx
+    d = synth.cluster_dets(12, 8, seed=2)
+    flat, keep = processing_cxx.wnms_4c(d, 0.1, 0.5, False, 100)
+    rflat, rkeep = O.wnms_4c(d, 0.1, 0.5, False, 100)
+    assert keep == rkeep and np.array_equal(np.array(flat, np.float32).view(np.uint32), np.array(rflat, np.float32).view(np.uint32))
+    assert processing_cxx.wnms_4c(np.zeros((0, 12), np.float32), 0.1, 0.5, False, 100) == ([], [])
+    pts, gt, ctr, rad, mask, nlz, lim = assign_case(4096, 20, seed=9)
+    inds = processing_cxx.assign3D_v2(pts.reshape(-1, 3), gt.reshape(-1, 24), ctr.reshape(-1, 3), rad.reshape(-1, 1),
+                                      mask.reshape(-1, 1), nlz.reshape(-1, 1), *lim, 20.0)
+    assert inds.shape == (4096, 1) and inds.dtype == np.int32
+    assert np.array_equal(inds.reshape(-1), O.assign3d_v2(pts, gt, ctr, rad, mask, nlz, *lim, 20.0))
+    num = processing_cxx.get_point_num(inds.reshape(-1).astype(np.float32))
+    assert num.shape == (4096, 1) and np.array_equal(num.reshape(-1), O.get_point_num(inds.astype(np.float32)))
+    w = 1 / num.reshape(-1)                                        # get_normalization_weight, input.py:436-437
+    w[w == -1] = 0
+    assert np.isfinite(w).all()
+
+
 @pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_error_conventions(be):
     """Status codes instead of aborts; messages through rd_last_error_string (SURVEY.md 8b 'Error conventions')."""
