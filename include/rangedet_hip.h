@@ -186,6 +186,10 @@ int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, flo
  * keep_idx (B,max_keep) int32 padded with -1; bbox_after_nms (B,max_keep,10) padded with 0.
  * Unlike the reference (N x N/64 words per frame) the mask is held for 1024 rows at a time. */
 size_t rd_nms3d_workspace_bytes(long N, int B);
+/* tools/test.py:193-196 (the `not pTest.nms.wnms` branch): out (B,max_keep) = score[b][keep_idx[b][i]], -inf where
+ * keep_idx is -1, so that rd_score_filter_dets_batched on (out, bbox_after_nms) yields the reference's final rows. */
+int rd_gather_keep_scores(const float* score, long score_bstride, int k, const int* keep_idx, int max_keep, float* out, int B,
+                          void* stream);
 int rd_nms3d(const float* boxes, int B, long N, float iou_thres, int max_keep, int normal_iou, int* keep_idx,
              float* bbox_after_nms, void* ws, size_t ws_bytes, void* stream);
 

@@ -23,7 +23,8 @@ KITTI_INPUT_CHANNELS = 5
 
 
 def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(64, 2656), fp16=True, batch_image=1,
-               pre_nms_top_n=None):
+               pre_nms_top_n=None, wnms=True):
+    _wnms = bool(wnms)
     if is_train:
         raise NotImplementedError("training is outside the hot path this package implements")
     V = _VARIANTS[variant]
@@ -82,7 +83,7 @@ def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(6
         num_classes = General.num_classes
         fpn_strides = FpnParam.fpn_strides
         num_reg_delta = 8
-        wnms = True
+        wnms = _wnms      # config:155 sets True; False = the contrib.NMS3D branch (builder.py:530-534)
 
         class head:
             cls_conv_layers = 4

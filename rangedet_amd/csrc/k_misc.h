@@ -333,4 +333,14 @@ __global__ __launch_bounds__(256) void dets12_to_8_kernel(const float* __restric
   o[7] = d[11];
 }
 
+// ---- scores of the boxes NMS3D kept (tools/test.py:193-196: cls_score[keep_inds] on the valid entries); padding entries
+// (keep = -1) get -inf so that the score filter that follows drops them ------------------------------------------------
+__global__ __launch_bounds__(256) void gather_keep_scores_kernel(const float* __restrict__ score, long score_bs, int k,
+                                                                 const int* __restrict__ keep, int mk, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mk) return;
+  const int q = keep[(size_t)blockIdx.y * mk + i];
+  out[(size_t)blockIdx.y * mk + i] = (q >= 0 && q < k) ? score[blockIdx.y * score_bs + q] : -__builtin_inff();
+}
+
 }  // namespace rd

@@ -455,6 +455,15 @@ int rd_dets12_to_8(const float* dets12, int Mcap, const int* d_count, float* out
   return rd_dets12_to_8_batched(dets12, 0, Mcap, d_count, out8, 0, 1, stream);
 }
 
+int rd_gather_keep_scores(const float* score, long score_bstride, int k, const int* keep_idx, int max_keep, float* out, int B,
+                          void* stream) {
+  RD_REQUIRE(score && keep_idx && out, RD_EINVAL, "gather_keep_scores: null pointer");
+  RD_REQUIRE(k > 0 && max_keep > 0 && B > 0, RD_ESHAPE, "gather_keep_scores: empty input");
+  hipLaunchKernelGGL(gather_keep_scores_kernel, dim3((max_keep + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, score,
+                     score_bstride, k, keep_idx, max_keep, out);
+  return check_launch("gather_keep_scores");
+}
+
 int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream) {
   RD_REQUIRE(boxes1 && boxes2 && ious, RD_EINVAL, "rotated_iou: null pointer");
   RD_REQUIRE(n1 > 0 && n2 > 0, RD_ESHAPE, "rotated_iou: empty input");

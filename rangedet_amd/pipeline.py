@@ -126,6 +126,44 @@ class BatchPostProcessor:
         return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
 
 
+class Nms3dPostProcessor:
+    """The harness steps after the graph when RpnParam.wnms is False (tools/test.py:193-224, `not pTest.nms.wnms`): the graph
+    already ran contrib.NMS3D, so what is left is: scores of the kept boxes, score filter + 10->11 dim, 12->8 dim.  Same
+    collect() result as BatchPostProcessor (wnms_rows = the filtered (K,12) rows; keep_inds = their NMS3D indices)."""
+
+    def __init__(self, B, k, max_keep, min_score, lib, alloc):
+        self.B, self.k, self.mk, self.min_score, self.L, self.A = B, k, max_keep, min_score, lib, alloc
+        A, L = alloc, lib
+        self.cap = max_keep
+        self.kscore = A.alloc(B * max_keep * 4)
+        self.dets = A.alloc(B * max_keep * 12 * 4)
+        self.count = A.alloc(max(16, 4 * B), zero=True)
+        self.ws_bytes = L.raw("rd_score_filter_workspace_bytes")(max_keep) * B
+        self.ws = A.alloc(self.ws_bytes)
+        self.out8 = A.alloc(B * max_keep * 8 * 4)
+        self._keep = None
+
+    def enqueue(self, score_ptr, score_bs, final_ptr, keep_ptr, keep_view, stream=None):
+        L, A, mk = self.L, self.A, self.mk
+        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
+        self._keep = keep_view
+        L.call("rd_gather_keep_scores", score_ptr, score_bs, self.k, keep_ptr, mk, A.ptr(self.kscore), self.B, st)
+        L.call("rd_score_filter_dets_batched", A.ptr(self.kscore), mk, final_ptr, mk * 10, mk, self.min_score, A.ptr(self.dets),
+               mk * 12, A.ptr(self.count), A.ptr(self.ws), self.ws_bytes, self.B, st)
+        L.call("rd_dets12_to_8_batched", A.ptr(self.dets), mk * 12, mk, A.ptr(self.count), A.ptr(self.out8), mk * 8, self.B, st)
+
+    def collect(self, b=0):
+        A = self.A
+        A.sync()
+        K = int(A.to_numpy(A.view_i32(self.count, (self.B,)))[b])
+        rows = A.to_numpy(A.view_f32(self.dets, (self.B, self.mk, 12)))[b, :K].copy()
+        d8 = A.to_numpy(A.view_f32(self.out8, (self.B, self.mk, 8)))[b, :K].copy()
+        keep = np.array(A.to_numpy(self._keep))[b]
+        sc = A.to_numpy(A.view_f32(self.kscore, (self.B, self.mk)))[b]
+        keep = keep[(keep >= 0) & (sc > self.min_score)]
+        return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
+
+
 class _FrameView:
     """pipe.post[b]: frame b of the batched post-processor behind the single-frame PostProcessor interface."""
 
@@ -147,9 +185,12 @@ class _FrameView:
 
 class RangeDetPipeline:
     def __init__(self, params, dtype=rdlib.RD_BF16, feat_size=(64, 2650), pad_field=(64, 2656), batch=1,
-                 pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None):
+                 pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None, wnms=True):
+        """wnms=False builds the graph with contrib.NMS3D inside (RpnParam.wnms = False, builder.py:530-534) and runs the
+        matching harness branch (tools/test.py:193-196) instead of the weighted NMS."""
         self.cfg = cfgmod.get_config(False, variant=variant, feat_size=feat_size, pad_field=pad_field,
-                                     batch_image=batch, pre_nms_top_n={variant: pre_nms_top_n})
+                                     batch_image=batch, pre_nms_top_n={variant: pre_nms_top_n}, wnms=wnms)
+        self.wnms = bool(wnms)
         General, RpnParam, ModelParam, TestParam = self.cfg[0], self.cfg[2], self.cfg[6], self.cfg[8]
         self.lib = lib or rdlib.get_lib()
         self.alloc = alloc or TorchAllocator()
@@ -160,8 +201,12 @@ class RangeDetPipeline:
         self.batch = batch
         self._post_stream = None
         self._filter_done = None
-        self.bpost = BatchPostProcessor(batch, self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
-                                        TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap)
+        if self.wnms:
+            self.bpost = BatchPostProcessor(batch, self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
+                                            TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap)
+        else:
+            self.bpost = Nms3dPostProcessor(batch, self.k, RpnParam.all_proposal.rpn_post_nms_top_n[cname],
+                                            TestParam.min_score[cname], self.lib, self.alloc)
         self.post = [_FrameView(self.bpost, b) for b in range(batch)]
 
     def forward(self, inputs):
@@ -184,6 +229,10 @@ class RangeDetPipeline:
         # one batched score filter (it is what reads the graph's score / box buffers: the next batch's forward only has
         # to wait for these three short kernels), then one batched weighted NMS for all frames
         ptr = lambda t: self.alloc.ptr(t) if hasattr(t, "data_ptr") else t.ctypes.data
+        if not self.wnms:   # outs = [rec_id, score (B,k), bbox_after_nms (B,mk,10), keep_inds (B,mk) int32, ...]
+            self.bpost.enqueue(ptr(sc), self.k, ptr(bx), ptr(outs[3]), outs[3], stream=self._post_stream)
+            self._filter_done = A.record_event(self._post_stream) if side else None
+            return outs
         sc_bs = (ptr(sc[1]) - ptr(sc[0])) // 4 if self.batch > 1 else 0
         bx_bs = (ptr(bx[1]) - ptr(bx[0])) // 4 if self.batch > 1 else 0
         self.bpost.enqueue_filter(ptr(sc[0]), sc_bs, ptr(bx[0]), bx_bs, stream=self._post_stream)

@@ -1,0 +1,91 @@
+"""rangedet_amd/export.py (the build's tools/create_prediction_bin_3d.py): the hand-written proto2 encoder against
+google.protobuf on a schema built at run time with the same field numbers, and the file-level traversal of
+create_prediction_bin_3d.py:80-104.  The field numbers themselves are unpinned (see the module docstring)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from rangedet_amd import export
+
+
+def _dynamic_schema():
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="rd_test_waymo.proto", package="rdtest", syntax="proto2")
+    label = fd.message_type.add(name="Label")
+    box = label.nested_type.add(name="Box")
+    for i, n in enumerate(["center_x", "center_y", "center_z", "width", "length", "height", "heading"], 1):
+        box.field.add(name=n, number=i, type=F.TYPE_DOUBLE, label=F.LABEL_OPTIONAL)
+    label.field.add(name="box", number=1, type=F.TYPE_MESSAGE, type_name=".rdtest.Label.Box", label=F.LABEL_OPTIONAL)
+    label.field.add(name="type", number=3, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
+    label.field.add(name="id", number=4, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    obj = fd.message_type.add(name="Object")
+    obj.field.add(name="object", number=1, type=F.TYPE_MESSAGE, type_name=".rdtest.Label", label=F.LABEL_OPTIONAL)
+    obj.field.add(name="score", number=2, type=F.TYPE_FLOAT, label=F.LABEL_OPTIONAL)
+    obj.field.add(name="context_name", number=4, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    obj.field.add(name="frame_timestamp_micros", number=5, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    objs = fd.message_type.add(name="Objects")
+    objs.field.add(name="objects", number=1, type=F.TYPE_MESSAGE, type_name=".rdtest.Object", label=F.LABEL_REPEATED)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    mk = (lambda n: get(pool.FindMessageTypeByName(n))) if get else \
+        (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName(n)))
+    return mk("rdtest.Object"), mk("rdtest.Objects")
+
+
+def _output_dict():
+    rng = np.random.default_rng(0)
+    d = {}
+    for rid in (3, 7, 8):
+        boxes = np.concatenate([rng.uniform(-60, 60, (5, 3)), rng.uniform(1, 6, (5, 3)), rng.uniform(-3.2, 3.2, (5, 1)),
+                                rng.uniform(0.5, 1, (5, 1))], axis=1).astype(np.float32)
+        d[rid] = {'det_xyzlwhyaws': {'TYPE_VEHICLE': boxes, 'TYPE_CYCLIST': boxes[:1, :7]},
+                  'meta_info': {'name': '1005081002024129653_5313_150_5333_150', 'timestamp_micros': 1510593600340000 + rid}}
+    d[9] = {}                                                   # a frame without detections is skipped (:90-91)
+    return d
+
+
+def test_encoder_matches_protobuf_runtime():
+    Object, Objects = _dynamic_schema()
+    od = _output_dict()
+    mine = export.serialize_objects(export.objects_from_output_dict(od))
+    ref = Objects()
+    for rid, out in od.items():
+        if len(out) == 0:
+            continue
+        for t, boxes in out['det_xyzlwhyaws'].items():
+            for b in boxes:
+                o = Object()
+                o.context_name = out['meta_info']['name']
+                o.frame_timestamp_micros = out['meta_info']['timestamp_micros']
+                bx = o.object.box
+                bx.center_x, bx.center_y, bx.center_z, bx.length, bx.width, bx.height, bx.heading = [float(v) for v in b[:7]]
+                if len(b) == 8:
+                    o.score = float(b[7])
+                o.object.id = ''
+                o.object.type = export.type_dict[t]
+                ref.objects.append(o)
+    assert mine == ref.SerializeToString()
+    back = Objects()
+    back.ParseFromString(mine)
+    assert len(back.objects) == 18 and back.objects[5].object.type == 4 and not back.objects[5].HasField("score")
+
+
+def test_bin_file_round_trip(tmp_path):
+    od = _output_dict()
+    pk = tmp_path / "checkpoint_output_dict_18e.pkl"
+    with open(pk, "wb") as f:
+        pickle.dump({3: np.zeros((1, 8, 3))}, f)
+        pickle.dump(od, f)
+    export.main(str(pk), "rangedet_veh_wo_aug_4_18e", str(tmp_path))
+    objs = export.parse_objects((tmp_path / "rangedet_veh_wo_aug_4_18e.bin").read_bytes())
+    assert len(objs) == 18
+    b = od[3]['det_xyzlwhyaws']['TYPE_VEHICLE'][0]
+    o = objs[0]
+    assert [o[k] for k in ("center_x", "center_y", "center_z", "length", "width", "height", "heading")] == [float(v) for v in b[:7]]
+    assert o["score"] == float(b[7]) and o["type"] == 1 and o["id"] == "" and o["frame_timestamp_micros"] == 1510593600340003
+    assert o["context_name"] == '1005081002024129653_5313_150_5333_150' and "score" not in objs[5]
+    assert export._varint(-1) == b"\xff" * 9 + b"\x01"

@@ -345,6 +345,36 @@ def test_pipeline_postprocess_matches_oracle(be):
 
 
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_pipeline_nms3d_branch_matches_harness(be):
+    """RangeDetPipeline(wnms=False): graph with contrib.NMS3D + the `not pTest.nms.wnms` harness branch on the device ==
+    tools/test.py:193-224 restated in numpy on the graph's own outputs (two frames in one batch)."""
+    from rangedet_amd.pipeline import RangeDetPipeline
+    H, Wr, W, k = 16, 250, 256, 2000
+    P = synth.make_weights(seed=18, width=W, cls_bias=-0.8)
+    frs = [synth.make_frame(i, W=Wr, pad_W=W, H=H) for i in (1, 2)]
+    fr = {n: np.concatenate([f[n] for f in frs]) for n in frs[0] if isinstance(frs[0][n], np.ndarray)}
+    pipe = RangeDetPipeline(P, dtype=R.RD_F32, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n=k, batch=2, wnms=False)
+    assert any(s["kind"] == "nms3d" for s in pipe.plan.steps)
+    res = pipe.run(fr)
+    outs = pipe.forward(fr)
+    be.alloc.sync()
+    sc, final, keep = (np.array(o.cpu().numpy()) for o in outs[1:4])
+    assert final.shape == (2, 200, 10) and keep.dtype == np.int32
+    for b in range(2):
+        kb = keep[b][keep[b] != -1]                                    # tools/test.py:194-196
+        b4, s_ = final[b][keep[b] != -1], sc[b][kb]
+        fg = s_ > 0.5
+        assert fg.sum() > 5
+        d11 = O.bbox3d_10dim_to_11dim(b4[fg])
+        rows = np.concatenate([d11, s_[fg][:, None]], axis=1)
+        got = res["frames"][b]
+        assert got["num_candidates"] == rows.shape[0]
+        assert np.abs(got["wnms_rows"] - rows).max() < 1e-5           # yaw column goes through device atan2f
+        assert np.abs(got["det_xyzlwhyaws"] - O.bbox3d_12dim_to_8dim(rows)).max() < 1e-4
+        assert got["keep_inds"].tolist() == kb[fg].tolist()
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_e2e_bf16_tolerance(be):
     """bf16 run (BASELINE config 2): documented tolerance vs the fp32 oracle -- logits/deltas within 5 % of their spread."""
     H, Wr, W, k = 16, 250, 256, 2000
