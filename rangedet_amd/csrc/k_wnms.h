@@ -289,16 +289,28 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
   int M = c_begin > 0 ? *d_nkeep : 0;
   for (int c = c_begin; c < min(nw, c_end); ++c) {
     const int rows = min(64, K - (c << 6));
-    for (int w0 = c; w0 < nw; w0 += 64) {                     // batches of 16 independent row loads in flight
+    // stage only the rows that are still unsuppressed when the chunk starts (the keep loop below never reads another
+    // row, and in the second round most chunks have none): batches of up to 16 independent row loads in flight
+    unsigned long long live = ~supp[c];
+    if (rows < 64) live &= (1ull << rows) - 1ull;
+    if (live == 0ull) continue;
+    for (int w0 = c; w0 < nw; w0 += 64) {
       const int w = w0 + lane;
-      for (int r0 = 0; r0 < rows; r0 += 16) {
+      unsigned long long rem = live;
+      while (rem) {
+        int rr[16];
         unsigned long long v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v[u] = (w < nw && r0 + u < rows) ? thr[(size_t)((c << 6) + r0 + u) * nwcap + w] : 0ull;
+        for (int u = 0; u < 16; ++u) {
+          rr[u] = rem ? __ffsll(rem) - 1 : -1;
+          rem &= rem - 1ull;                                   // (0 stays 0)
+        }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-          if (w < nw && r0 + u < rows) tile[(r0 + u) * nwcap + w] = v[u];
+          v[u] = (w < nw && rr[u] >= 0) ? thr[(size_t)((c << 6) + rr[u]) * nwcap + w] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (w < nw && rr[u] >= 0) tile[rr[u] * nwcap + w] = v[u];
       }
     }
     __builtin_amdgcn_wave_barrier();
