@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       const bool relu_i16 = relu_post || (relu_pre && !do_add);
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef short s16x2 __attribute__((ext_vector_type(2)));
-      // scale / shift of channel block j: read from LDS one (i, j) block ahead of its use
+      // scale / shift of a channel block.  cout 64: both blocks are read from LDS once per tile and stay in registers;
+      // cout 128 (no room for all four): read one (i, j) block ahead of its use
+      constexpr bool SC_HOIST = NCT == 2;
       f32x4 scq[2][4], shq[2][4];
       auto sc_load = [&](int j, f32x4 (&sc)[4], f32x4 (&sh)[4]) {
 #pragma unroll
@@ -352,14 +354,15 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         }
       };
       sc_load(0, scq[0], shq[0]);
+      if constexpr (SC_HOIST) sc_load(1, scq[1], shq[1]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (do_add && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
-          const int cur = (i * NCT + j) & 1;
-          sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
+          const int cur = SC_HOIST ? j : (i * NCT + j) & 1;
+          if constexpr (!SC_HOIST) sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
           const int cb = j * 32 + 16 * ehi;
           unsigned pk[8];
 #pragma unroll
