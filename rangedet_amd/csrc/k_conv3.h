@@ -35,8 +35,16 @@ struct Conv3Args {
   unsigned long long* trace;
 };
 
-constexpr int C3_TW = 126;                 // output columns per tile (halo = 128 columns exactly)
-constexpr int C3_HALO = 6 * 128 * 64;      // bytes of one halo image
+// Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
+// pixel fragment i of a wave = row 2w + (i >> 1), columns 32*(i & 1) ..  (+2048 bytes per fragment in the halo image, as
+// a halo row is 64 pixels x 64 B = two fragments).  Against 4 x 126 tiles: 10/8 instead of 6/4 halo rows per output row
+// (less HBM and LDS-DMA traffic per pixel) and a finer column grid (2656 = 42.8 tiles of 62: 99.6 % of the computed
+// columns are real, 95.8 % with 126; 664: 97 % instead of 88 %; 166: 89 % instead of 66 %).
+constexpr int C3_TW = 62;                  // output columns per tile (halo = 64 columns exactly)
+constexpr int C3_TH = 8;                   // output rows per tile
+constexpr int C3_HALO = 10 * 64 * 64;      // bytes of one halo image
+constexpr int C3_HPW = 10;                 // 1-KB halo pieces per wave and unit (40 in all)
+constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row
 template <int NCT> struct C3Cfg {
   static constexpr int R = NCT == 4 ? 7 : 10;  // ring depth (slabs)
   static constexpr int IPW = NCT / 2;          // slab DMA instructions per wave per step
@@ -69,10 +77,11 @@ constexpr int c3_nsteps(int TS) { return TS == 0 ? 9 : 6; }
 constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw+1) of step ordinal s
   return TS == 0 ? s : 3 * (s / 2) + (s % 2) + (TS == 2 ? 1 : 0);
 }
-// Halo pieces (12 per wave and unit) per step ordinal: 2 each at ordinals 0..5 of a 9-step unit, 4 each at ordinals 0..2
-// of a 6-step unit; the last ones are issued two steps before the wait that must cover them (ordinal NS-2).
-constexpr int c3_halo_last(int NS) { return NS == 9 ? 5 : 2; }
-constexpr int c3_halo_pieces(int s, int NS) { return s <= c3_halo_last(NS) ? 12 / (c3_halo_last(NS) + 1) : 0; }
+// Halo pieces (C3_HPW = 10 per wave and unit) per step ordinal: 2 each at ordinals 0..4 of a 9-step unit; 4, 4, 2 at
+// ordinals 0..2 of a 6-step unit; the last ones are issued at least two steps before the wait that must cover them
+// (ordinal NS-2).
+constexpr int c3_halo_last(int NS) { return NS == 9 ? 4 : 2; }
+constexpr int c3_halo_pieces(int s, int NS) { return NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)); }
 constexpr int c3_halo_first(int s, int NS) { int n = 0; for (int t = 0; t < s; ++t) n += c3_halo_pieces(t, NS); return n; }
 // DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (ordinal s of its unit):
 // the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions plus its
@@ -135,9 +144,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #endif
   };
   // halo image: linear 16-B slot P = 4*px + ps of the LDS image holds logical slot s = ps ^ ((px >> 2) & 3) of halo
-  // pixel px = 128*r + cc (conflict-free ds_read_b128 for any tap shift).  Wave w issues the 12
-  // 1-KB pieces q = 12*w .. 12*w+11: px = 16*q + (lane >> 2), so r = q >> 3 and cc = 16*(q & 7) + (lane >> 2).
-  // Source of a piece = uniform address of halo pixel (r, 16*(q&7)) + a per-lane constant; lanes outside the image
+  // pixel px = 64*r + cc (conflict-free ds_read_b128 for any tap shift).  Wave w issues the 10
+  // 1-KB pieces q = 10*w .. 10*w+9: px = 16*q + (lane >> 2), so r = q >> 2 and cc = 16*(q & 3) + (lane >> 2).
+  // Source of a piece = uniform address of halo pixel (r, 16*(q&3)) + a per-lane constant; lanes outside the image
   // (or past the last channel slot) read the zero page instead.
   const int hs = (lane & 3) ^ ((lane >> 4) & 3);          // logical slot this lane fetches (same for every piece)
   const int l4 = lane >> 2;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     const int t = wg + hk * G;
     const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
     const int hw0 = ct * C3_TW - 1;
-    hh0 = rb * 4 - 1;
+    hh0 = rb * C3_TH - 1;
     hlo = hw0 < 0 ? -hw0 : 0;
     hlim = a.W - hw0;
     hbase = (const unsigned char*)(a.x + (size_t)b * a.x_bs + a.x_co + hc * 32) +
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     else if (hk + 1 < ntl) { ++hk; hc = 0; }
   };
   auto halo_piece = [&](int buf, int j) {
-    const int q = wave * 12 + j, r = q >> 3, c16 = (q & 7) * 16;
+    const int q = wave * C3_HPW + j, r = q >> 2, c16 = (q & 3) * 16;
     const int cc = c16 + l4;
     const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
     const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
@@ -178,7 +187,8 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   };
 
   // ---- fragment addressing -------------------------------------------------------------------------------------
-  // pixel fragment i of tap (dh, dw): halo pixel (wave + 1 + dh, 1 + dw + 32*i + m); byte = px*64 + ((slot ^ (px>>2)) & 3)*16
+  // pixel fragment i of tap (dh, dw): halo pixel (2*wave + (i >> 1) + 1 + dh, 1 + dw + 32*(i & 1) + m), px = 64*row + col
+  // (so +32 px = +2048 B per fragment, +4096 B per tap row, +8192 B per wave); byte = px*64 + ((slot ^ (px>>2)) & 3)*16
   // with slot = 2*ks + hi.  (px >> 2) & 3 only depends on (1 + dw + m), +32 px = +2048 B, ks toggles bit 5.
   int aoff[3];
 #pragma unroll
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   // ---- prologue: first halo, a full ring ------------------------------------------------------------------------
   halo_begin();
 #pragma unroll
-  for (int j = 0; j < 12; ++j) halo_piece(0, j);
+  for (int j = 0; j < C3_HPW; ++j) halo_piece(0, j);
 #pragma unroll 1
   for (int s0 = 0; s0 < R; ++s0) {
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
 #pragma unroll
   for (int k = 0; k < NR; ++k)   // fragments of (unit 0, first tap, ks 0)
-    C3_RD(0, k, aoff[c3_tap(TS, 0) % 3] + abuf + (c3_tap(TS, 0) / 3) * 8192, boff + rslot * SLAB, 0)
+    C3_RD(0, k, aoff[c3_tap(TS, 0) % 3] + abuf + (c3_tap(TS, 0) / 3) * C3_ROWB, boff + rslot * SLAB, 0)
 
   // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
   //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
@@ -254,10 +264,10 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     constexpr int T_ = c3_tap(TS, (S)), TN_ = c3_tap(TS, ((S) + 1) % NS);                                            \
     constexpr int dh_ = T_ / 3, dw_ = T_ % 3, ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                        \
     constexpr int NH_ = c3_halo_pieces((S), NS), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
-    const int acur_ = (aoff[dw_] + abuf + dh_ * 8192) ^ 32;                                                          \
+    const int acur_ = (aoff[dw_] + abuf + dh_ * C3_ROWB) ^ 32;                                                         \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
-    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? C3_HALO - abuf : abuf) + ndh_ * 8192;                           \
+    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? C3_HALO - abuf : abuf) + ndh_ * C3_ROWB;                       \
     const int bnext_ = boff + rnext_ * SLAB;                                                                         \
     const int hbuf_ = abuf ? 0 : 1;                                                                                  \
     C3_FENCE();                                                                                                      \
@@ -307,15 +317,15 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
     const int t = wg + k * G;
     const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
-    const int oh = rb * 4 + wave;
+    const int oh0 = rb * C3_TH + 2 * wave;                   // fragment i: output row oh0 + (i >> 1), columns 32*(i & 1) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
     // and kept (spilled) across the whole MFMA phase
     int em = m, ehi = hi, el = lane;
     asm volatile("" : "+v"(em), "+v"(ehi), "+v"(el));
     constexpr int ROWB = COUT * 2, SPR = COUT / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
-    unsigned char* scr = smem + (C3_HALO - abuf) + wave * 12288;
-    bf16_t* __restrict__ yrow = a.y + (size_t)b * a.y_bs + (size_t)oh * a.Wo * a.y_cs + a.y_co;
-    const bf16_t* __restrict__ rrow = a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wo * a.r_cs + a.r_co;
+    unsigned char* scr = smem + (C3_HALO - abuf) + wave * (C3_HALO / 4);
+    bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
+    const bf16_t* __restrict__ rrow0 = a.res + (size_t)b * a.r_bs + (size_t)oh0 * a.Wo * a.r_cs + a.r_co;
     const int sh = a.sw - 1;   // stride 2: shift by 1, keep even columns
     // FL >= 0: the flag combination is a compile-time constant (no per-value selects); FL < 0: read a.flags
     auto epilogue = [&](auto FL) {
@@ -326,9 +336,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       // residuals: the loads of pixel fragment i+1 are issued before fragment i is processed (dead pixels read pixel 0)
       Slot16 rv[2][NCT][2];
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
-        const int tc = 32 * i + em, ow = ct * C3_TW + tc;
+        const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
         const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh);
-        const bf16_t* rp = rrow + (live ? (size_t)(ow >> sh) * a.r_cs : 0) + 16 * ehi;
+        const bf16_t* rp = rrow0 + (live ? (size_t)(i >> 1) * a.Wo * a.r_cs + (size_t)(ow >> sh) * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           dst[j][0] = *(const Slot16*)(rp + j * 32);
@@ -396,9 +406,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         for (int it = 0; it < 32 / RPI; ++it) {
           const int pr = it * RPI + el / SPR, sl = el % SPR;
           const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
-          const int tcs = 32 * i + pr, ows = ct * C3_TW + tcs;
-          if (tcs < C3_TW && ows < a.W && oh < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
-            *(Slot16*)(yrow + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
+          const int tcs = 32 * (i & 1) + pr, ows = ct * C3_TW + tcs;
+          if (tcs < C3_TW && ows < a.W && oh0 + (i >> 1) < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
+            *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
         }
         __builtin_amdgcn_wave_barrier();
         C3_FENCE();
@@ -474,7 +484,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   a.zero16 = conv_zero16();
   RD_REQUIRE(a.zero16, RD_EHIP, "conv: zero page allocation failed");
   a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;
-  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + 3) / 4; a.ntiles = a.ncol * a.nrow * B;
+  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + C3_TH - 1) / C3_TH; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus());
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);

@@ -25,7 +25,7 @@ for _ in range(5):
     L.call("rd_conv2d_bn_act", x.data_ptr(), cs, 0, w.data_ptr(), sc.data_ptr(), sh.data_ptr(), 0, cout, 0,
            y.data_ptr(), cout, 0, B, H, W, cin, cout, 3, 3, 1, 4, dt, st)
 torch.cuda.synchronize()
-ntiles = -(-W // 126) * (H // 4) * B
+ntiles = -(-W // 62) * -(-H // 8) * B
 nwg = min(ntiles, torch.cuda.get_device_properties(0).multi_processor_count)
 buf = np.zeros(nwg * 8, dtype=np.uint64)
 fn = L.cdll.rd_dev_conv_trace_read
