@@ -2,10 +2,10 @@
 // RangeDet FLOPs: backbone BasicBlocks dla_backbone.py:18-56 and the head towers head/builder.py:221-240).
 //
 // One workgroup (4 waves, one per SIMD, up to 512 registers each) per CU walks a list of output tiles of
-// 4 rows x 126 columns x all Cout.  Wave w owns output row w of the tile: 4 pixel fragments (32 px) x NCT channel
-// fragments (32 ch) = 4*NCT accumulators of 32x32 (cout 128: all 256 accumulation registers).
+// 8 rows x 62 columns x all Cout.  Wave w owns output rows 2w, 2w+1 of the tile: 4 pixel fragments (2 rows x 2 x 32 px)
+// x NCT channel fragments (32 ch) = 4*NCT accumulators of 32x32 (cout 128: all 256 accumulation registers).
 //
-//   unit  = (tile, 32-channel k-chunk): one halo image 6 rows x 128 columns x 64 B = 48 KB in LDS, DOUBLE buffered:
+//   unit  = (tile, 32-channel k-chunk): one halo image 10 rows x 64 columns x 64 B = 40 KB in LDS, DOUBLE buffered:
 //           the halo of unit u+1 (possibly the next tile) is fetched by LDS-DMA while unit u is computed;
 //   step  = (unit, tap): one weight slab Cout x 32 ch = NCT*2 KB, kept in MFMA-fragment order (a linear copy of the
 //           packed global image) in an R-deep LDS ring filled by LDS-DMA R steps ahead;
@@ -16,7 +16,7 @@
 //
 // All DMA traffic of a wave retires in order, so "my part of slab g+1 has landed" is a counted s_waitcnt vmcnt(N) with
 // N = DMA instructions issued after it -- a compile-time constant per tap because every step issues exactly IPW slab
-// instructions and every tap-0 step 12 halo instructions (dummy re-fetches keep that true at the end of the list).
+// instructions and every unit 10 halo instructions (dummy re-fetches keep that true at the end of the list).
 // LDS bytes per MFMA: (4 + NCT) KB / (4*NCT) = 0.5 KB (cout 128), 0.75 KB (cout 64) -- a quarter of ds_read_b128 peak.
 #pragma once
 #include "k_conv.h"
