@@ -93,6 +93,18 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
                      const float* shift, const void* residual, int r_cstride, int r_coff, void* y,
                      int y_cstride, int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw,
                      int stride_w, int flags, int dtype, void* stream);
+/* Last conv of a head tower (3x3, cout 128, BN + ReLU, bf16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
+ * rpn_{cls,reg}_conv_3 + BN + ReLU, then rpn_cls_logit / rpn_reg_delta with bias): the 128-channel result is consumed in
+ * the epilogue and never written.  out[b*out_batch_stride + (n_off + h*W + w)*nout + o], float32, like rd_head_out; nout <= 8.
+ * head_w_packed: rd_pack_head_weight_host(w (nout, 128) row-major float32) -> rd_head_packed_bytes() bytes (bf16 hi + lo
+ * pairs, so the fp32 weights keep their precision).  Same numbers as rd_conv2d_bn_act followed by rd_head_out up to fp32
+ * summation order. */
+size_t rd_head_packed_bytes(void);
+int rd_pack_head_weight_host(const float* w, int nout, int cin, void* out_host);
+int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
+                              const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
+                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, void* stream);
+
 /* Transposed conv, kernel (3,kw), stride (1,stride_w), pad (1,pad_w); one call per output phase. */
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase,
                        const float* scale, const float* shift, const void* residual, int r_cstride,

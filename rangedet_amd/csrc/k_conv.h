@@ -405,7 +405,7 @@ inline int launch_conv1(const void* x, int x_cs, int x_co, const void* w, const 
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st, int ts);
+                        int cout, int flags, int sw, hipStream_t st, int ts, const struct Conv3Args* head);
 
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,
@@ -440,7 +440,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   if (conv1_eligible(tl, in_stride, out_stride, cin, cout, dt, Win, Wq, Wout) && x_co + 16 * ((cin + 15) / 16) <= x_cs)
     return launch_conv1(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, Wout, cin, cout, flags, in_stride, st);
   if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
-    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st, 0);
+    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st, 0, nullptr);
   // Workgroup = 4 rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile),
   // 4 waves, 3-deep weight ring, two workgroups per CU when the halo allows.
   constexpr int RO = 4;

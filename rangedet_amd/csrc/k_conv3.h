@@ -33,6 +33,10 @@ struct Conv3Args {
   int H, W, B, nslots, nchunk, flags, ncol, nrow, ntiles;
   int sw, Wo;   // column stride (1 or 2) and output width: a stride-2 conv is the stride-1 conv with only the even columns stored
   unsigned long long* trace;
+  // HEAD variant: the 1x1 output conv that consumes this conv's result is applied in the epilogue and y is never written
+  const unsigned char* hw;   // packed head weights: [hi | lo][ks 0..7][64 lanes][8 bf16] = 16 KB (pack_head_frag)
+  const float* hb;           // [hn] bias
+  float* ho; long ho_bs, ho_off; int hn;   // out[b*ho_bs + (ho_off + h*W + w)*hn + o]
 };
 
 // Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
@@ -71,6 +75,21 @@ inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
           }
 }
 
+// packed 1x1 output-conv weights of the HEAD variant: [hi | lo][ks 0..7][64 lanes][8 bf16]; lane (mm, hi) of k-step ks holds
+// w[mm][16*ks + 8*hi + j] (rows mm >= nout and channels >= cin are zero), hi = bf16(w), lo = bf16(w - hi).
+inline void pack_head_frag(const float* w, int nout, int cin, void* out) {
+  bf16_t* o = (bf16_t*)out;
+  for (int part = 0; part < 2; ++part)
+    for (int ks = 0; ks < 8; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int mm = lane & 31, c = 16 * ks + 8 * (lane >> 5) + j;
+          const float v = (mm < nout && c < cin) ? w[(size_t)mm * cin + c] : 0.f;
+          const bf16_t h = f32_to_bf16(v);
+          *o++ = part == 0 ? h : f32_to_bf16(v - bf16_to_f32(h));
+        }
+}
+
 // Tap sets.  TS = 0: all nine taps (convs).  A transposed-conv phase only has taps in two of the three columns:
 // TS = 1 -> dw in {-1, 0}, TS = 2 -> dw in {0, +1}; its unit is 6 steps instead of 9 (no MFMAs on zero weights).
 constexpr int c3_nsteps(int TS) { return TS == 0 ? 9 : 6; }
@@ -96,8 +115,13 @@ constexpr int c3_younger(int R, int IPW, int s, int NS) {
 // s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
 #define C3_WAIT_IMM(vm, lgkm) (((vm) & 15) | (((vm) >> 4) << 14) | (7 << 4) | ((lgkm) << 8))
 
-template <int NCT, int DBG = 0, int TS = 0>
+// HEAD: the conv is the last layer of a head tower and its only consumer is the tower's 1x1 output conv (<= 8 outputs).
+// That conv is applied to each 32-pixel fragment while it sits, already rounded to bf16, in the epilogue's transpose
+// scratch (same LDS image and MFMA scheme as head_out_mfma_kernel, k_misc.h: weights as a bf16 hi + lo pair), and the
+// 128-channel result is never written to HBM.
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false>
 __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(!HEAD || (NCT == 4 && TS == 0), "fused output conv: cout 128, all nine taps");
   using Cfg = C3Cfg<NCT>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int NR = 4 + NCT;                    // fragment reads per k-step
@@ -108,6 +132,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   const int m = lane & 31, hi = lane >> 5;
   constexpr int RING = 2 * C3_HALO;
   float* Sc = (float*)(smem + RING + R * SLAB);
+  constexpr int HWOFF = RING + R * SLAB + 2 * COUT * (int)sizeof(float);   // HEAD: 16 KB of packed output-conv weights
   if (tid < COUT) {
     Sc[tid] = a.scale ? a.scale[tid] : 1.f;
     Sc[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
@@ -240,6 +265,10 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   halo_begin();
 #pragma unroll
   for (int j = 0; j < C3_HPW; ++j) halo_piece(0, j);
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_s(a.hw + (wave * 4 + j) * 1024, lane * 16, HWOFF + (wave * 4 + j) * 1024);
+  }
 #pragma unroll 1
   for (int s0 = 0; s0 < R; ++s0) {
 #pragma unroll
@@ -401,14 +430,36 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         }
         C3_FENCE();
         __builtin_amdgcn_wave_barrier();   // (the wave runs in lockstep on hardware; this orders the lanes under hipemu)
-        // read back pixel-major and store: lane -> (pixel it*RPI + el / SPR, slot el % SPR)
+        if constexpr (HEAD) {
+          // out[o][px] = sum_c w[o][c] * act[px][c]: A = weights (hi, lo), B = the fragment's pixels from the scratch image
+          f32x16 h0, h1;
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-          const int pr = it * RPI + el / SPR, sl = el % SPR;
-          const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
-          const int tcs = 32 * (i & 1) + pr, ows = ct * C3_TW + tcs;
-          if (tcs < C3_TW && ows < a.W && oh0 + (i >> 1) < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
-            *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
+          for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const s16x8 bq = *(const s16x8*)(scr + em * ROWB + (((2 * ks + ehi) ^ (em & 15)) << 4));
+            const s16x8 wh = *(const s16x8*)(smem + HWOFF + ks * 1024 + el * 16);
+            const s16x8 wl = *(const s16x8*)(smem + HWOFF + 8192 + ks * 1024 + el * 16);
+            h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bq, h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bq, h1, 0, 0, 0);
+          }
+          const int tcs = 32 * (i & 1) + em, ows = ct * C3_TW + tcs, ohs = oh0 + (i >> 1);
+          if (tcs < C3_TW && ows < a.W && ohs < a.H) {
+            float* o = a.ho + (size_t)b * a.ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * a.hn + 4 * ehi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * ehi + r < a.hn) o[r] = (h0[r] + h1[r]) + a.hb[4 * ehi + r];
+          }
+        } else {
+          // read back pixel-major and store: lane -> (pixel it*RPI + el / SPR, slot el % SPR)
+#pragma unroll
+          for (int it = 0; it < 32 / RPI; ++it) {
+            const int pr = it * RPI + el / SPR, sl = el % SPR;
+            const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
+            const int tcs = 32 * (i & 1) + pr, ows = ct * C3_TW + tcs;
+            if (tcs < C3_TW && ows < a.W && oh0 + (i >> 1) < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
+              *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
+          }
         }
         __builtin_amdgcn_wave_barrier();
         C3_FENCE();
@@ -473,9 +524,10 @@ inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int
 
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st, int ts = 0) {
+                        int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
+  if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
   a.sw = sw; a.Wo = (W - 1) / sw + 1;
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
   a.w = (const unsigned char*)w; a.scale = scale; a.shift = shift;
@@ -494,6 +546,10 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
 #endif
+  if (head) {
+    hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
+    return check_launch("conv3x3_stream_kernel<head>");
+  }
 #define C3_LAUNCH(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
   if (cout == 128) { if (ts == 0) C3_LAUNCH(4, 0); else if (ts == 1) C3_LAUNCH(4, 1); else C3_LAUNCH(4, 2); }
   else { if (ts == 0) C3_LAUNCH(2, 0); else if (ts == 1) C3_LAUNCH(2, 1); else C3_LAUNCH(2, 2); }

@@ -50,6 +50,7 @@ inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4, 0, 2>);
   allow_big_lds(conv3x3_stream_kernel<2, 0, 1>);
   allow_big_lds(conv3x3_stream_kernel<2, 0, 2>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
@@ -204,6 +205,31 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
   return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
                      y_coff, B, H, Win, Wout, Wout, cin, cout, stride_w, 1, 0, flags, dtype, (hipStream_t)stream);
 }
+// ---- last tower conv + the tower's 1x1 output conv in one launch (bf16) ---------------------------------------------
+size_t rd_head_packed_bytes(void) { return 16384; }
+int rd_pack_head_weight_host(const float* w, int nout, int cin, void* out_host) {
+  RD_REQUIRE(w && out_host, RD_EINVAL, "pack_head_weight: null pointer");
+  RD_REQUIRE(nout >= 1 && nout <= 8 && cin >= 1 && cin <= 128, RD_ESHAPE, "pack_head_weight: nout %d (1..8), cin %d (1..128)", nout, cin);
+  pack_head_frag(w, nout, cin, out_host);
+  return RD_OK;
+}
+int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
+                              const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
+                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, void* stream) {
+  RD_REQUIRE(x && w_packed && head_w_packed && head_bias && out, RD_EINVAL, "conv2d_head_out: null pointer");
+  RD_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && nout >= 1 && nout <= 8, RD_ESHAPE, "conv2d_head_out: shape / nout %d (1..8)", nout);
+  RD_REQUIRE(!(flags & RD_ADD), RD_EINVAL, "conv2d_head_out: no residual in a head tower");
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE,
+             "conv2d_head_out: x channel stride/offset");
+  RD_REQUIRE(getenv("RD_CONV_V1") == nullptr, RD_EINVAL, "conv2d_head_out: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
+  allow_conv_lds();
+  Conv3Args h;
+  memset(&h, 0, sizeof(h));
+  h.hw = (const unsigned char*)head_w_packed; h.hb = head_bias; h.ho = out; h.ho_bs = out_batch_stride; h.ho_off = n_off; h.hn = nout;
+  return launch_conv3(x, x_cstride, x_coff, w_packed, scale, shift, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
+                      (hipStream_t)stream, 0, &h);
+}
+
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase, const float* scale,
                        const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
                        int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
@@ -226,7 +252,7 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
       const bf16_t* r = (const bf16_t*)residual;
       return launch_conv3(x, x_cstride, x_coff, w_packed_phase, scale, shift, r, r_cstride * stride_w,
                           r_coff + phase * r_cstride, y, y_cstride * stride_w, y_coff + phase * y_cstride, B, H, Win, cin,
-                          cout, flags, 1, (hipStream_t)stream, ts);
+                          cout, flags, 1, (hipStream_t)stream, ts, nullptr);
     }
   }
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,

@@ -37,6 +37,10 @@ SIGNATURES = {
     "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p]),
+    "rd_head_packed_bytes": (c_size_t, []),
+    "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p]),
     "rd_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p]),
     "rd_meta_packed_bytes": (c_size_t, [c_int]),
@@ -142,6 +146,12 @@ class Lib:
         out = np.zeros(self.cdll.rd_conv_packed_bytes(nt, cin, cout, dtype), dtype=np.uint8)
         self.call("rd_pack_deconv_weight_host", w.ctypes.data, cin, cout, kh, kw, stride_w, pad_w, phase, dtype,
                   out.ctypes.data)
+        return out
+
+    def pack_head_weight(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_head_packed_bytes(), dtype=np.uint8)
+        self.call("rd_pack_head_weight_host", w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data)
         return out
 
     def pack_meta(self, w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype):

@@ -14,6 +14,7 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
   contrib.NMS3D (wnms=False)                       -> rd_nms3d                                  (builder.py:530-534)
 Anything that does not match raises NotImplementedError at lowering time -- there is no slow generic path.
 """
+import os
 from dataclasses import dataclass, field
 
 from .lib import RD_ADD, RD_BF16, RD_F32, RD_RELU_POST, RD_RELU_PRE
@@ -75,6 +76,38 @@ class Lowering:
         self._count_consumers(group)
         for out in group.inputs:
             self.plan.outputs.append(self.emit_value(out))
+        self._fuse_head_out()
+
+    # ---- fusion ------------------------------------------------------------------------------------------------
+    def _fuse_head_out(self):
+        """bf16: the last conv of a head tower whose ONLY consumer is one 1x1 output conv (rpn_cls_logit / rpn_reg_delta of a
+        single-class head) runs as rd_conv2d_bn_act_head_out: the output conv is applied in the 3x3 kernel's epilogue and the
+        128-channel tower output is never written to HBM nor read back.  (Two classes read the tensor twice: left alone.)"""
+        if self.dtype != RD_BF16 or os.environ.get("RD_NO_FUSE_HEAD"):
+            return
+        steps = self.plan.steps
+        uses = {}
+        for i, st in enumerate(steps):
+            for key, v in st.items():
+                if isinstance(v, TRef):
+                    uses.setdefault(v.buf, []).append((i, key))
+        drop = set()
+        for i, st in enumerate(steps):
+            if st["kind"] != "head_out" or st["nout"] > 8:
+                continue
+            x = st["x"]
+            refs = uses.get(x.buf, [])
+            prod = [j for j, key in refs if key == "out"]
+            if len(refs) != 2 or len(prod) != 1 or x.co != 0 or x.C != 128:
+                continue
+            c = steps[prod[0]]
+            if not (c["kind"] == "conv" and tuple(c["k"]) == (3, 3) and c["cout"] == 128 and c["stride_w"] == 1 and
+                    c["flags"] == RD_RELU_POST and c.get("res") is None and c["out"] == x):
+                continue
+            c["head"] = dict(name=st["name"], rows=st["rows"], nout=st["nout"], out=st["out"], n_off=st["n_off"], N=st["N"])
+            c["head_out"] = st["out"]        # top level: the executor's buffer liveness pass looks at step values
+            drop.add(i)
+        self.plan.steps = [st for i, st in enumerate(steps) if i not in drop]
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------
     def _count_consumers(self, root):

@@ -161,6 +161,12 @@ class Executor:
                              P[st["mlp1"] + "_weight"].reshape(64, 32), P[st["mlp1"] + "_bias"], s1, t1,
                              P[st["agg"] + "_weight"].reshape(64, 576), s2, t2, dt)
             b["packed"] = A.upload(pk)
+        if k == "conv" and st.get("head"):
+            h = st["head"]
+            r0, r1 = h["rows"]
+            hw = np.asarray(P[h["name"] + "_weight"], np.float32).reshape(-1, st["cout"])[r0:r1]
+            b["head_w"] = A.upload(L.pack_head_weight(hw))
+            b["head_bias"] = A.upload(np.asarray(P[h["name"] + "_bias"], np.float32)[r0:r1])
         elif k == "head_out":
             r0, r1 = st["rows"]
             w = np.asarray(P[st["name"] + "_weight"], np.float32).reshape(-1, st["x"].C)[r0:r1]
@@ -197,6 +203,11 @@ class Executor:
                 src = din(b["name"])
                 assert tuple(src.shape) == (B, o.C, o.H, o.W), (b["name"], tuple(src.shape), (B, o.C, o.H, o.W))
                 L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
+            elif k == "conv" and b.get("head"):
+                x, h = b["x"], b["head"]
+                L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]), B,
+                       x.H, x.W, b["cin"], b["flags"], A.ptr(b["head_w"]), A.ptr(b["head_bias"]), self.p(h["out"]),
+                       h["N"] * h["nout"], h["n_off"], h["nout"], st_)
             elif k == "conv":
                 x, o, r = b["x"], b["out"], b["res"]
                 L.call("rd_conv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]),

@@ -88,6 +88,45 @@ def test_conv2d_bn_act(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(2, 9, 70, 128, 8), (1, 4, 130, 128, 1), (1, 8, 62, 72, 7)])
+def test_conv_fused_with_head_out(be, case):
+    """rd_conv2d_bn_act_head_out == rd_conv2d_bn_act (bf16, ReLU) followed by rd_head_out on its output: the same bf16
+    activations feed the same hi + lo weight MFMAs, so only the fp32 summation order differs."""
+    B, H, W, cin, nout = case
+    rng = np.random.default_rng(5)
+    x = bf16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((128, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    sc, sh = rng.uniform(0.5, 1.5, 128).astype(np.float32), rng.standard_normal(128).astype(np.float32)
+    hw = (rng.standard_normal((nout, 128)) / np.sqrt(128)).astype(np.float32)
+    hb = rng.standard_normal(nout).astype(np.float32)
+    cs = -(-cin // 16) * 16
+    L = be.lib
+    xin = be.up(to_nhwc(x, BF16, cstride=cs))
+    wp, dsc, dsh = be.up(L.pack_conv_weight(w, BF16)), be.up(sc), be.up(sh)
+    dhw, dhb, dhp = be.up(hw), be.up(hb), be.up(L.pack_head_weight(hw))
+    N, off = H * W + 37, 21                                          # a level's slice of a longer flat tensor
+    y = be.empty(B * H * W * 128 * 2)
+    o1, o2 = be.empty(B * N * nout * 4), be.empty(B * N * nout * 4)
+    L.call("rd_conv2d_bn_act", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), None, 0, 0, be.ptr(y), 128, 0, B, H, W,
+           cin, 128, 3, 3, 1, R.RD_RELU_POST, BF16, be.stream)
+    L.call("rd_head_out", be.ptr(y), 128, 0, be.ptr(dhw), be.ptr(dhb), be.ptr(o1), N * nout, off, B, H, W, 128, nout, BF16, be.stream)
+    L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), B, H, W, cin, R.RD_RELU_POST,
+           be.ptr(dhp), be.ptr(dhb), be.ptr(o2), N * nout, off, nout, be.stream)
+    a = be.down(o1, np.float32, (B, N, nout))
+    b = be.down(o2, np.float32, (B, N, nout))
+    assert np.abs(a[:, off:off + H * W]).max() > 0.5
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
+    assert (b[:, :off] == 0).all() and (b[:, off + H * W:] == 0).all()   # nothing outside the level's slice is touched
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy() * sc[None, :, None, None] + sh[None, :, None, None]
+    act = bf16_round(np.maximum(ref, 0).astype(np.float32))
+    want = np.einsum('oc,bchw->bhwo', hw, act).reshape(B, H * W, nout) + hb
+    assert np.abs(b[:, off:off + H * W] - want).max() < 2 ** -7 * max(1.0, np.abs(want).max())
+    buf = be.ptr(be.empty(1 << 16))
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 9, be.stream) == R.RD_ESHAPE
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 6, buf, buf, buf, 100, 0, 8, be.stream) == R.RD_EINVAL
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 10, 128, 64, (3, 8), 4, 2), (BF16, 1, 2, 20, 128, 128, (3, 8), 4, 2),
                                   (F32, 2, 2, 13, 64, 64, (3, 4), 2, 1), (BF16, 1, 3, 24, 128, 64, (3, 4), 2, 1)])
 def test_deconv2d_bn_act(be, case):
