@@ -35,7 +35,12 @@ def test_config_and_full_graph_lowering():
     plan = lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
     kinds = Counter(s["kind"] for s in plan.steps)
     # 63 backbone conv/deconv - 4 deconv - 1 aggregation conv (inside the fused Meta unit) + 24 head tower convs
-    assert kinds["conv"] == 82 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 6
+    # bf16: the six 1x1 output convs ride in the epilogue of their tower's last conv (lower._fuse_head_out)
+    assert kinds["conv"] == 82 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
+    fused = [s for s in plan.steps if s.get("head")]
+    assert sorted(s["name"] for s in fused) == sorted("rpn_%s_conv_3_lvl_%d" % (t, l) for t in ("cls", "reg") for l in range(3))
+    assert sorted(s["head"]["nout"] for s in fused) == [1, 1, 1, 8, 8, 8]
+    assert Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_F32, 1).steps)["head_out"] == 6   # fp32: separate
     assert kinds["sorted_fg"] == 1 and kinds["decode"] == 1
     assert [o[0] for o in plan.outputs] == ["input", "flat", "flat", "zeros", "input", "input"]
     assert plan.outputs[1][1].shape == (50000,) and plan.outputs[2][1].shape == (50000, 10)
