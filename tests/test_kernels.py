@@ -72,6 +72,8 @@ CONV_CASES = [
     (BF16, 3, 4, 126, 8, 64, 3, 1, 4),     # one 32-channel unit per tile (every unit starts a new tile)
     (BF16, 2, 5, 260, 64, 64, 3, 2, 6),    # stride 2 = stride 1 with the even columns stored
     (BF16, 1, 4, 131, 128, 128, 3, 2, 4),  # stride 2, odd width
+    (BF16, 1, 27, 200, 64, 64, 3, 1, 6),   # 4 x 4 tiles: the middle ones are interior units (halo pieces with a uniform base)
+    (BF16, 1, 26, 190, 128, 128, 3, 1, 4),
     # streaming 1x1 kernel (k_conv1.h)
     (BF16, 2, 5, 77, 64, 128, 1, 2, 0),    # projection shortcut, stride 2, odd width
     (BF16, 1, 3, 40, 8, 64, 1, 1, 0),      # 8 input channels (one 16-channel k-step)
