@@ -380,6 +380,35 @@ def test_pipeline_nms3d_branch_matches_harness(be):
 
 
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_evaluate_loop_and_export(be, tmp_path):
+    """rangedet_amd.evaluate (tools/test.py's loop on the HIP path): raw records -> device transform -> pipeline -> the
+    output_dict pickle -> prediction bin; per frame the same detections as running that frame through the pipeline with
+    the host-side transform."""
+    from rangedet_amd import evaluate, export
+    from rangedet_amd.pipeline import RangeDetPipeline
+    H, W, Wp = 16, 250, 256
+    P = synth.make_weights(seed=18, width=Wp, cls_bias=-0.8)
+    roidb = [dict(synth.raw_record(i, H=H, W=W), rec_id=i) for i in range(3)]
+    ann, out = evaluate.run(roidb, P, batch=2, pre_nms_top_n=2000)
+    assert sorted(out) == [0, 1, 2] and set(ann) == set(out)
+    pipe = RangeDetPipeline(P, feat_size=(H, W), pad_field=(H, Wp), batch=1, pre_nms_top_n=2000)
+    for i in range(3):
+        ref = pipe.run(synth.make_frame(i, W=W, pad_W=Wp, H=H))["det_xyzlwhyaws"]
+        got = out[i]['det_xyzlwhyaws']['TYPE_VEHICLE']
+        assert got.shape == ref.shape and got.shape[0] > 0 and np.abs(got - ref).max() < 1e-3   # bf16 graph both ways
+        assert out[i]['meta_info'] == {'name': 'synthetic', 'timestamp_micros': i}
+    pk = tmp_path / "checkpoint_output_dict_18e.pkl"
+    with open(pk, "wb") as f:
+        import pickle
+        pickle.dump(ann, f)
+        pickle.dump(out, f)
+    export.main(str(pk), "cfg", str(tmp_path))
+    objs = export.parse_objects((tmp_path / "cfg.bin").read_bytes())
+    assert len(objs) == sum(v['det_xyzlwhyaws']['TYPE_VEHICLE'].shape[0] for v in out.values())
+    assert objs[0]["type"] == 1 and abs(objs[0]["score"] - float(out[0]['det_xyzlwhyaws']['TYPE_VEHICLE'][0, 7])) < 1e-7
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_e2e_bf16_tolerance(be):
     """bf16 run (BASELINE config 2): documented tolerance vs the fp32 oracle -- logits/deltas within 5 % of their spread."""
     H, Wr, W, k = 16, 250, 256, 2000
