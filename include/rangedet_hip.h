@@ -14,6 +14,7 @@
  *   rd_decode3d_bbox          _contrib_Decode3DBbox                               operator_cxx/contrib/decode_3d_bbox-inl.h:169-305
  *   rd_score_filter_dets      score filter + bbox3d_10dim_to_11dim                tools/test.py:56-81,200-209
  *   rd_wnms_4c                processing_cxx.wnms_4c                              operator_cxx/src_cxx/nms.h:452-577,781-794
+ *   rd_single_overlap         OverlapChecker::single_overlap                      operator_cxx/src_cxx/nms.h:195-249
  *   rd_wnms_order_host        the std::sort ordering of point4_wnms_4c            operator_cxx/src_cxx/nms.h:786-792
  *   rd_dets12_to_8            bbox3d_12dim_to_8dim                                tools/test.py:43-53
  *   rd_rotated_iou_8pt        _contrib_RotatedIOU (8-point boxes)                 operator_cxx/contrib/rotated_iou-inl.h:509-547
@@ -159,22 +160,36 @@ int rd_score_filter_dets_batched(const float* scores, long scores_bstride, const
                                  long n, float min_score, float* dets, long dets_bstride, int* d_count, void* ws,
                                  size_t ws_bytes, int B, void* stream);
 
-/* Weighted NMS.  dets (Kcap,12) device; the number of valid rows is *d_count when d_count != NULL, else Kcap.
- * order: device int32 (Kcap) processing order (sorted positions -> row index), or NULL = the library sorts on
- * the device (score descending, ties by row index ascending).  Outputs: out_dets (Kcap,12), keep (Kcap) row
- * indices into dets, *d_nkeep = M.  Kcap <= RD_WNMS_MAX_K. */
-#define RD_WNMS_MAX_K 16384
+/* Weighted NMS.  dets (Kcap,12) device; the number of valid rows is *d_count when d_count != NULL, else Kcap (rows past
+ * the count are ignored; a count above Kcap is clamped -- callers size Kcap from the data, up to RD_WNMS_MAX_K = more than
+ * the reference's pre_nms_top_n of 50000 rows).
+ * order: device int32 (Kcap) processing order (sorted positions -> row index).  NULL = the library orders on the device:
+ *   tie_order RD_TIE_REFERENCE  the order std::sort gives point4_wnms_4c (nms.h:786-792; unstable: tied scores come out in
+ *                               libstdc++ introsort order, replayed on the device; rows that arrive strictly sorted -- the
+ *                               pipeline's case without ties -- cost one pass);
+ *   tie_order RD_TIE_STABLE     score descending, ties by row index ascending (single frame only).
+ * hash_scale: cell size of the reference's BBoxHash prefilter (nms.h:252-307, 459, 470, 501-507; tools/test.py:216 passes
+ * 100): a pair of boxes is compared only when their cell ranges share a key, exactly like the reference.  <= 0: no
+ * prefilter.  Outputs: out_dets (Kcap,12), keep (Kcap) row indices into dets in processing order, *d_nkeep = M. */
+#define RD_WNMS_MAX_K 65536
+#define RD_TIE_STABLE 0
+#define RD_TIE_REFERENCE 1
 size_t rd_wnms_workspace_bytes(int Kcap);
-int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh,
-               float thresh_vote, int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws,
+int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, int tie_order, float thresh,
+               float thresh_vote, int is3d, int hash_scale, float* out_dets, int* keep, int* d_nkeep, void* ws,
                size_t ws_bytes, void* stream);
 /* B independent frames in one set of launches (the per-frame greedy scan is one latency-bound wavefront: B of them
  * run side by side instead of back to back).  Frame b uses dets + b*dets_bstride, order + b*order_bstride (stride 0 =
- * one order shared by all frames; order must not be NULL when B > 1), d_count[b], out_dets + b*out_bstride,
- * keep + b*keep_bstride, d_nkeep[b]; ws_bytes >= B * rd_wnms_workspace_bytes(Kcap).  Strides in elements. */
+ * one order shared by all frames; with order == NULL and B > 1 tie_order must be RD_TIE_REFERENCE), d_count[b],
+ * out_dets + b*out_bstride, keep + b*keep_bstride, d_nkeep[b]; ws_bytes >= B * rd_wnms_workspace_bytes(Kcap).
+ * Strides in elements. */
 int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int* d_count, const int* order,
-                       long order_bstride, float thresh, float thresh_vote, int is3d, float* out_dets, long out_bstride,
-                       int* keep, long keep_bstride, int* d_nkeep, void* ws, size_t ws_bytes, int B, void* stream);
+                       long order_bstride, int tie_order, float thresh, float thresh_vote, int is3d, int hash_scale,
+                       float* out_dets, long out_bstride, int* keep, long keep_bstride, int* d_nkeep, void* ws,
+                       size_t ws_bytes, int B, void* stream);
+/* OverlapChecker::single_overlap (nms.h:195-249) of n row pairs: out[i] = overlap(dets_a[i], dets_b[i]) -- BEV IoU of the two
+ * 4-corner boxes, or volume IoU with is3d (rows are (n,12) dets rows).  The measure the weighted NMS thresholds. */
+int rd_single_overlap(const float* dets_a, const float* dets_b, long n, int is3d, float* out, void* stream);
 /* HOST: the reference's own ordering (std::sort, score descending, unstable) for dets_host (K,12). */
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host);
 

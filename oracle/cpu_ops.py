@@ -38,6 +38,9 @@ def lib():
         L.orc_single_overlap.restype = ctypes.c_float
         L.orc_single_overlap.argtypes = [fp, fp, ctypes.c_int]
         L.orc_wnms_order.argtypes = [fp, ctypes.c_int, ip]
+        L.orc_antiqsort_keys.argtypes = [ctypes.c_int, fp]
+        L.orc_std_sort_depth_limit_hit.argtypes = [fp, ctypes.c_int]
+        L.orc_std_sort_depth_limit_hit.restype = ctypes.c_int
         L.orc_wnms_4c.restype = ctypes.c_int
         L.orc_wnms_4c.argtypes = [fp, ip, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                   ctypes.c_int, fp, ip]
@@ -80,6 +83,18 @@ def wnms_order(dets):
     order = np.empty(K, dtype=np.int32)
     lib().orc_wnms_order(p, K, order.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     return order
+
+
+def antiqsort_keys(n):
+    """n distinct scores on which the reference's std::sort (nms.h:791) degenerates into its heap-sort branch."""
+    k = np.empty(n, dtype=np.float32)
+    lib().orc_antiqsort_keys(n, k.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return k
+
+
+def std_sort_depth_limit_hit(keys):
+    k, p = _f(keys)
+    return bool(lib().orc_std_sort_depth_limit_hit(p, k.shape[0]))
 
 
 def wnms_4c(dets, thresh, thresh_vote, is3d=False, hash_scale=100, order=None):

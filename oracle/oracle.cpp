@@ -316,6 +316,45 @@ void orc_wnms_order(const float* dets, int K, int* order) {
   std::sort(order, order + K, [&](int i, int j) { return dets[i * 12 + 11] > dets[j * 12 + 11]; });
 }
 
+// Test inputs for the device replay of that std::sort: a "median-of-three killer" for THIS libstdc++ (M. D. McIlroy,
+// "A Killer Adversary for Quicksort", 1999: the comparator decides the keys while std::sort runs, so every partition is
+// maximally unbalanced and introsort reaches its depth limit -> heap sort).  keys[i] are distinct scores in (0.5, 1).
+namespace {
+struct Adversary {
+  std::vector<int> val;
+  int nsolid = 0, candidate = 0, gas;
+  explicit Adversary(int n) : val(n, n - 1), gas(n - 1) {}
+  bool less(int x, int y) {
+    if (val[x] == gas && val[y] == gas) { if (x == candidate) val[x] = nsolid++; else val[y] = nsolid++; }
+    if (val[x] == gas) candidate = x; else if (val[y] == gas) candidate = y;
+    return val[x] < val[y];
+  }
+};
+}  // namespace
+void orc_antiqsort_keys(int n, float* keys) {
+  Adversary adv(n);
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return adv.less(a, b); });
+  // ascending val under `less`  ==  descending score under the wnms comparator score[i] > score[j]
+  for (int i = 0; i < n; ++i) keys[i] = 0.5f + 0.45f * (float)(n - adv.val[i]) / (float)n;
+}
+// 1 when std::sort of iota(n) by keys descending leaves its quicksort loop through the depth limit (heap-sort branch):
+// its comparison count then differs from the same loop run with an unlimited depth (libstdc++ internals, test use only).
+int orc_std_sort_depth_limit_hit(const float* keys, int n) {
+  long c1 = 0, c2 = 0;
+  std::vector<int> a(n), b(n);
+  std::iota(a.begin(), a.end(), 0);
+  b = a;
+  std::sort(a.begin(), a.end(), [&](int i, int j) { ++c1; return keys[i] > keys[j]; });
+  auto cmp = __gnu_cxx::__ops::__iter_comp_iter([&](int i, int j) { ++c2; return keys[i] > keys[j]; });
+  if (n > 1) {
+    std::__introsort_loop(b.begin(), b.end(), (long)1 << 40, cmp);
+    std::__final_insertion_sort(b.begin(), b.end(), cmp);
+  }
+  return c1 != c2;
+}
+
 // nms.h:452-577.  dets (K,12); order (K).  out_dets capacity K*12, keep capacity K.  Returns M.
 int orc_wnms_4c(const float* dets, const int* order, int K, float thresh, float thresh_vote, int is3d,
                 int hash_scale, float* out_dets, int* keep) {

@@ -3,9 +3,12 @@
 //   1. prep   : per box (in processing order) clockwise-normalised corners, the 4 edge polar angles (the only
 //               atan2f of the algorithm -- hoisted out of the O(K^2) part), area, bottom, height.
 //   2. pairs  : for sorted positions q1 < q2 the half-plane-intersection IoU (nms.h:96-249) -> two K x K/64
-//               bit matrices  thr[q1] (ovr >= thresh)  and  vote[q1] (ovr > thresh_vote).  No spatial prefilter:
-//               the reference's 100 m hash passes every pair inside +-100 m, and an AABB reject is NOT
-//               result-neutral (disjoint boxes can produce a non-zero "IoU" in the reference's clipper).
+//               bit matrices  thr[q1] (ovr >= thresh)  and  vote[q1] (ovr > thresh_vote).  A pair is evaluated only
+//               when the two boxes share a cell of the reference's BBoxHash (nms.h:252-307, used at :470,501,506):
+//               the reference never computes the overlap of boxes without a common cell, and that is NOT
+//               result-neutral (its clipper returns a non-zero "IoU" for some disjoint boxes), so the predicate is
+//               reproduced exactly: per box the cell rectangle [floor(min/s), ceil(max/s)) with the reference's
+//               numeric_limits<float>::min() start value of the maxima and its i*100+j key aliasing.
 //   3. scan   : one wavefront walks the sorted positions; for an unsuppressed q it snapshots
 //               nb[q] = vote[q] & ~supp (written back in place) and ORs thr[q] into supp (64 words per step).
 //   4. merge  : one wavefront per kept row: median yaw by rank selection, then the 11 score-weighted sums in
@@ -17,7 +20,20 @@ namespace rd {
 
 struct WPt { float x, y; };
 struct WEdge { WPt a, b; float ang; };
-constexpr int PREP_F = 16;  // floats per prepped box: 8 corners, 4 angles, area, bottom, height, pad
+constexpr int PREP_F = 20;  // floats per prepped box: 8 corners, 4 angles, area, bottom, height, pad, 4 hash-cell bounds (int bits)
+
+// BBoxHash::getHash (nms.h:268-291): cells (i, j) with i in [c0, c2), j in [c1, c3), key i*100 + j (int).  Two boxes are
+// compared iff they share a key (createBBoxMap / getFilterResult, nms.h:256-267,292-303).  i1 - i2 takes every value of
+// [a0-b2+1, a2-1-b0] and j2 - j1 every value of [b1-a3+1, b3-1-a1] independently, and the keys collide iff
+// 100*(i1-i2) == j2-j1 -- so the test is an interval intersection (the d = 0 term is the plain rectangle overlap).
+__device__ __forceinline__ int w_floordiv100(int v) { return v >= 0 ? v / 100 : -((99 - v) / 100); }
+__device__ __forceinline__ bool w_share_cell(const int* a, const int* b) {
+  if (a[0] >= a[2] || a[1] >= a[3] || b[0] >= b[2] || b[1] >= b[3]) return false;   // a box without cells is in no list
+  const int dlo = a[0] - b[2] + 1, dhi = a[2] - 1 - b[0];
+  const int jlo = b[1] - a[3] + 1, jhi = b[3] - 1 - a[1];
+  const int dmin = -w_floordiv100(-jlo), dmax = w_floordiv100(jhi);       // ceil(jlo/100), floor(jhi/100)
+  return max(dlo, dmin) <= min(dhi, dmax);
+}
 
 #define RD_NOCONTRACT _Pragma("clang fp contract(off)")
 
@@ -165,10 +181,11 @@ struct WnmsBatch {
 };
 __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict__ dets, const int* __restrict__ order,
                                                         int cap, const int* __restrict__ d_count, float* __restrict__ prep,
-                                                        WnmsBatch bs) {
+                                                        WnmsBatch bs, float hscale, int* __restrict__ novf) {
   RD_NOCONTRACT
   dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; prep += blockIdx.z * bs.prep;
   int q = blockIdx.x * 256 + threadIdx.x;
+  if (q == 0) novf[blockIdx.z * bs.ints] = 0;   // overflow list of the merge step starts empty
   int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   if (q >= K) return;
   const float* b = dets + (size_t)order[q] * 12;
@@ -184,6 +201,22 @@ __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict_
     p[3] = t0;
   }
   float* o = prep + (size_t)q * PREP_F;
+  {  // nms.h:268-286: minima start at max(), maxima at numeric_limits<float>::min() (the smallest POSITIVE normal, not
+     // lowest()); y is divided by the x scale for the lower bound and x by the y scale for the upper one (equal here)
+    float mn0 = 3.402823466e+38f, mn1 = 3.402823466e+38f, mx0 = 1.175494351e-38f, mx1 = 1.175494351e-38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mn0 = fminf(mn0, b[2 * k]); mn1 = fminf(mn1, b[2 * k + 1]);
+      mx0 = fmaxf(mx0, b[2 * k]); mx1 = fmaxf(mx1, b[2 * k + 1]);
+    }
+    int c[4] = {0, 0, 1, 1};                               // hscale <= 0: no prefilter, every pair shares cell (0, 0)
+    if (hscale > 0.f) {
+      c[0] = (short)(int)floorf(mn0 / hscale); c[1] = (short)(int)floorf(mn1 / hscale);
+      c[2] = (short)(int)ceilf(mx0 / hscale);  c[3] = (short)(int)ceilf(mx1 / hscale);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[16 + k] = __int_as_float(c[k]);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     o[2 * k] = p[k].x;
@@ -201,35 +234,33 @@ __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict_
   o[15] = 0.f;
 }
 
-// grid (8*nb, nb), 64 threads: rows 64*blockIdx.y.. x the 8 columns 64*cb + 8*sub.. (cb = blockIdx.x / 8, upper
-// triangle only).  One wave evaluates 64 x 8 pairs and writes ONE BYTE of each row's 64-bit mask word (little endian:
-// byte `sub` holds bits 8*sub..8*sub+7), so K = 1.5k boxes already give ~2.4k waves for the 256 CUs.
+// Pair tiles: 64 rows x 8 columns per wave -- row block rb (64 consecutive processing positions, or 64 consecutive entries
+// of the compacted alive list), column word cb, byte `sub` of that word; one wave evaluates 64 x 8 pairs and writes ONE
+// BYTE of each row's 64-bit mask word (little endian: byte `sub` holds bits 8*sub..8*sub+7).  The grid is a fixed number
+// of single-wave workgroups per frame that stride over the tile list (sized from the DEVICE-side counts, so the launch
+// does not depend on how many boxes passed the score filter and a large capacity costs nothing when K is small).
 constexpr int WN_CT = 8;
 __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict__ prep, int cap,
                                                         const int* __restrict__ d_count, float thresh, float thresh_vote,
                                                         int is3d, unsigned long long* __restrict__ thr,
                                                         unsigned long long* __restrict__ vote, int nwcap, WnmsBatch bs,
                                                         const int* __restrict__ rows, const int* __restrict__ nrows,
-                                                        const unsigned long long* __restrict__ supp_state) {
-  // rows == nullptr: row block blockIdx.y is rows 64*blockIdx.y .. (first round).  Otherwise (second round) the row
-  // block is 64 consecutive entries of the compacted, ascending list of rows that survived the first round.
+                                                        const unsigned long long* __restrict__ supp_state, int rb_begin,
+                                                        int rb_end) {
+  // rows == nullptr: row blocks [rb_begin, rb_end) of the processing order (first round).  Otherwise (second round) the row
+  // blocks are 64 consecutive entries of the compacted, ascending list of rows that survived the first round.
   prep += blockIdx.z * bs.prep; thr += blockIdx.z * bs.words; vote += blockIdx.z * bs.words;
-  const int rb = blockIdx.y, cb = blockIdx.x / WN_CT, sub = blockIdx.x % WN_CT;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
-  int nr = K, qmin = rb * 64;
-  unsigned dead = 0u;   // second round: columns of this tile that the first round already suppressed.  Neither their thr
-                        // bit (ORed into a suppression word that already has it) nor their vote bit (masked by the
-                        // suppression snapshot in the merge) can influence anything, so those pairs are not evaluated.
+  const int ncb = (K + 63) >> 6;
+  int nr = K, rb0 = rb_begin, nrb = min(rb_end, ncb) - rb_begin;
   if (rows) {
-    dead = (unsigned)(supp_state[blockIdx.z * (bs.ints / 2) + cb] >> (sub * WN_CT)) & 0xffu;
     rows += blockIdx.z * bs.ints;
     nr = nrows[blockIdx.z * bs.ints];                      // (per-frame workspaces are bs.ints 4-byte words apart)
-    if (rb * 64 >= nr) return;
-    qmin = rows[rb * 64];
+    rb0 = 0;
+    nrb = (nr + 63) >> 6;
+    supp_state += blockIdx.z * (bs.ints / 2);
   }
-  // skip column tiles that lie entirely before the first row (the tile holding that row itself is still written: the
-  // scan and the merge read every row's words from its own, diagonal, word on)
-  if (cb * 64 + 63 < qmin || rb * 64 >= nr || cb * 64 >= K) return;
+  if (nrb <= 0) return;
   __shared__ float colp[WN_CT * PREP_F];
   __shared__ float edges[EDGE_LDS_BYTES / 4];
   const int t = threadIdx.x;
@@ -237,42 +268,67 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
   EL.ax = edges; EL.ay = edges + 512; EL.bx = edges + 1024; EL.by = edges + 1536; EL.an = edges + 2048;
   EL.dq = (int*)(edges + 2560);
   EL.t = t;
-  const int c0 = cb * 64 + sub * WN_CT;
-  for (int i = t; i < WN_CT * PREP_F; i += 64) {
-    int q2 = c0 + i / PREP_F;
-    colp[i] = q2 < K ? prep[(size_t)q2 * PREP_F + (i % PREP_F)] : 0.f;
-  }
-  __syncthreads();
-  if (rb * 64 + t >= nr) return;
-  const int q1 = rows ? rows[rb * 64 + t] : rb * 64 + t;
-  unsigned mt = 0u, mv = 0u;
-  if (c0 + WN_CT - 1 > q1) {
-    float mine[PREP_F];
+  const long ntile = (long)nrb * ncb * WN_CT;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int rb = rb0 + (int)(tile / (ncb * WN_CT)), cb = (int)((tile / WN_CT) % ncb), sub = (int)(tile % WN_CT);
+    const int qmin = rows ? rows[rb * 64] : rb * 64;
+    // skip column tiles that lie entirely before the first row (the tile holding that row itself is still written: the
+    // scan and the merge read every row's words from its own, diagonal, word on)
+    if (cb * 64 + 63 < qmin) continue;
+    // second round: columns of this tile that the first round already suppressed.  Neither their thr bit (ORed into a
+    // suppression word that already has it) nor their vote bit (masked by the suppression snapshot in the merge) can
+    // influence anything, so those pairs are not evaluated.
+    const unsigned dead = rows ? (unsigned)(supp_state[cb] >> (sub * WN_CT)) & 0xffu : 0u;
+    const int c0 = cb * 64 + sub * WN_CT;
+    __syncthreads();                                       // previous tile's colp readers are done
+    for (int i = t; i < WN_CT * PREP_F; i += 64) {
+      int q2 = c0 + i / PREP_F;
+      colp[i] = q2 < K ? prep[(size_t)q2 * PREP_F + (i % PREP_F)] : 0.f;
+    }
+    __syncthreads();
+    if (rb * 64 + t >= nr) continue;
+    const int q1 = rows ? rows[rb * 64 + t] : rb * 64 + t;
+    unsigned mt = 0u, mv = 0u;
+    if (c0 + WN_CT - 1 > q1) {
+      float mine[PREP_F];
 #pragma unroll
-    for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
-    for (int c = 0; c < WN_CT; ++c) {
-      int q2 = c0 + c;
-      if (q2 < K && q2 > q1 && !((dead >> c) & 1u)) {
-        float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0, EL);
-        if (ovr >= thresh) mt |= 1u << c;
-        if (ovr > thresh_vote) mv |= 1u << c;
+      for (int k = 0; k < PREP_F; ++k) mine[k] = prep[(size_t)q1 * PREP_F + k];
+      int mc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mc[k] = __float_as_int(mine[16 + k]);
+      for (int c = 0; c < WN_CT; ++c) {
+        int q2 = c0 + c;
+        if (q2 < K && q2 > q1 && !((dead >> c) & 1u)) {
+          int oc[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) oc[k] = __float_as_int(colp[c * PREP_F + 16 + k]);
+          if (!w_share_cell(mc, oc)) continue;             // the reference never evaluates this pair
+          float ovr = w_overlap(mine, &colp[c * PREP_F], is3d != 0, EL);
+          if (ovr >= thresh) mt |= 1u << c;
+          if (ovr > thresh_vote) mv |= 1u << c;
+        }
       }
     }
+    ((unsigned char*)thr)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mt;
+    ((unsigned char*)vote)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mv;
   }
-  ((unsigned char*)thr)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mt;
-  ((unsigned char*)vote)[((size_t)q1 * nwcap + cb) * 8 + sub] = (unsigned char)mv;
 }
 
-// Greedy scan, one wavefront.  Per 64 sorted rows the needed part of the thr bit-matrix (64 rows x remaining words) is
-// pulled into LDS with all loads in flight at once (one memory latency per 64 rows instead of a dependent load chain per
-// kept row); the rows are then resolved sequentially out of LDS.  For every kept row the suppression state BEFORE it is
-// snapshotted to `snap` (the merge kernel forms the neighbourhood vote[q] & ~snap), so the vote matrix is never read here.
+// Greedy scan, one wavefront.  Per 64 sorted rows the needed part of the thr bit-matrix is pulled into LDS with all loads
+// in flight at once (one memory latency per 64 rows instead of a dependent load chain per kept row); the rows are then
+// resolved sequentially out of LDS.  For every kept row the suppression state BEFORE it is snapshotted to `snap` (the merge
+// kernel forms the neighbourhood vote[q] & ~snap), so the vote matrix is never read here.
+// The LDS tile holds `tile_w` mask words per row.  K <= 64*tile_w: one column chunk, as described.  Larger K (up to
+// RD_WNMS_MAX_K): column chunks of tile_w words -- which rows of a chunk are kept only depends on the chunk's DIAGONAL word
+// (column 0 of the first column chunk), so the first column chunk runs the sequential keep loop and records the kept rows,
+// and every further column chunk stages just those rows and replays the same snapshot / OR sequence on its own words.
 __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long* __restrict__ thr,
                                                        unsigned long long* __restrict__ snap, int cap,
                                                        const int* __restrict__ d_count, int nwcap,
                                                        const int* __restrict__ order, int* __restrict__ keep_q,
                                                        int* __restrict__ keep, int* __restrict__ d_nkeep, WnmsBatch bs,
-                                                       int c_begin, int c_end, unsigned long long* __restrict__ supp_state) {
+                                                       int c_begin, int c_end, unsigned long long* __restrict__ supp_state,
+                                                       int tile_w) {
   // 64-row chunks [c_begin, c_end) only.  c_begin > 0 resumes from the suppression state / keep count a previous launch
   // left in supp_state / *d_nkeep; the state is stored back whenever supp_state is given.
   HIP_DYNAMIC_SHARED(unsigned char, smem);
@@ -280,7 +336,7 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
   keep_q += blockIdx.z * bs.ints; keep += blockIdx.z * bs.keep; d_nkeep += blockIdx.z;
   if (supp_state) supp_state += blockIdx.z * bs.ints / 2;   // per-frame workspaces are bs.ints 4-byte words apart
   unsigned long long* supp = (unsigned long long*)smem;      // [nwcap]
-  unsigned long long* tile = supp + nwcap;                   // [64][nwcap]
+  unsigned long long* tile = supp + nwcap;                   // [64][tile_w]
   const int lane = threadIdx.x;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
   const int nw = (K + 63) >> 6;
@@ -294,45 +350,65 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
     unsigned long long live = ~supp[c];
     if (rows < 64) live &= (1ull << rows) - 1ull;
     if (live == 0ull) continue;
-    for (int w0 = c; w0 < nw; w0 += 64) {
-      const int w = w0 + lane;
-      unsigned long long rem = live;
-      while (rem) {
-        int rr[16];
-        unsigned long long v[16];
+    unsigned long long kept = 0ull;                          // rows of this chunk that the keep loop kept
+    const int M0 = M;
+    for (int wb = c; wb < nw; wb += tile_w) {                // column chunk [wb, we)
+      const int we = min(nw, wb + tile_w);
+      const unsigned long long need = wb == c ? live : kept;
+      for (int w0 = wb; w0 < we; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned long long rem = need;
+        while (rem) {
+          int rr[16];
+          unsigned long long v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          rr[u] = rem ? __ffsll(rem) - 1 : -1;
-          rem &= rem - 1ull;                                   // (0 stays 0)
+          for (int u = 0; u < 16; ++u) {
+            rr[u] = rem ? __ffsll(rem) - 1 : -1;
+            rem &= rem - 1ull;                               // (0 stays 0)
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            v[u] = (w < we && rr[u] >= 0) ? thr[(size_t)((c << 6) + rr[u]) * nwcap + w] : 0ull;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (w < we && rr[u] >= 0) tile[rr[u] * tile_w + (w - wb)] = v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v[u] = (w < nw && rr[u] >= 0) ? thr[(size_t)((c << 6) + rr[u]) * nwcap + w] : 0ull;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (w < nw && rr[u] >= 0) tile[rr[u] * nwcap + w] = v[u];
       }
-    }
-    __builtin_amdgcn_wave_barrier();
-    int r = 0;
-    while (r < rows) {
-      unsigned long long avail = ~supp[c] & (~0ull << r);
-      if (rows < 64) avail &= (1ull << rows) - 1ull;
-      if (avail == 0ull) break;
-      r = __ffsll(avail) - 1;
-      const int q = (c << 6) + r;
-      for (int w = c + lane; w < nw; w += 64) {
-        const unsigned long long sw = supp[w];
-        snap[(size_t)M * nwcap + w] = sw;
-        supp[w] = sw | tile[r * nwcap + w];
-      }
-      if (lane == 0) {
-        keep_q[M] = q;
-        keep[M] = order[q];
-      }
-      ++M;
-      ++r;
       __builtin_amdgcn_wave_barrier();
+      if (wb == c) {
+        int r = 0;
+        while (r < rows) {
+          unsigned long long avail = ~supp[c] & (~0ull << r);
+          if (rows < 64) avail &= (1ull << rows) - 1ull;
+          if (avail == 0ull) break;
+          r = __ffsll(avail) - 1;
+          const int q = (c << 6) + r;
+          for (int w = wb + lane; w < we; w += 64) {
+            const unsigned long long sw = supp[w];
+            snap[(size_t)M * nwcap + w] = sw;
+            supp[w] = sw | tile[r * tile_w + (w - wb)];
+          }
+          if (lane == 0) {
+            keep_q[M] = q;
+            keep[M] = order[q];
+          }
+          kept |= 1ull << r;
+          ++M;
+          ++r;
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+        int i = 0;
+        for (unsigned long long rem = kept; rem; rem &= rem - 1ull, ++i) {
+          const int r = __ffsll(rem) - 1;
+          for (int w = wb + lane; w < we; w += 64) {          // each lane only ever touches its own words: no barrier
+            const unsigned long long sw = supp[w];
+            snap[(size_t)(M0 + i) * nwcap + w] = sw;
+            supp[w] = sw | tile[r * tile_w + (w - wb)];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   if (lane == 0) *d_nkeep = M;
@@ -341,57 +417,51 @@ __global__ __launch_bounds__(64) void wnms_scan_kernel(const unsigned long long*
 }
 
 // Rows >= first_row that the first round left unsuppressed, ascending -> rows_out, their number -> *nrows_out.
-// One workgroup of 256 threads per frame, thread w owns suppression word w (K <= 16384 rows = 256 words).
+// One workgroup of 256 threads per frame; suppression words are taken 256 at a time with a running output offset.
 __global__ __launch_bounds__(256) void wnms_alive_kernel(const unsigned long long* __restrict__ supp_state, int cap,
                                                          const int* __restrict__ d_count, int first_row,
                                                          int* __restrict__ rows_out, int* __restrict__ nrows_out, WnmsBatch bs) {
   supp_state += blockIdx.z * bs.ints / 2; rows_out += blockIdx.z * bs.ints; nrows_out += blockIdx.z * bs.ints;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
-  const int nw = (K + 63) >> 6, w = threadIdx.x;
-  unsigned long long alive = 0ull;
-  if (w < nw) {
-    alive = ~supp_state[w];
-    const int lo = first_row - (w << 6), hi = K - (w << 6);             // keep rows in [first_row, K)
-    if (lo >= 64) alive = 0ull; else if (lo > 0) alive &= ~0ull << lo;
-    if (hi < 64) alive &= hi <= 0 ? 0ull : (1ull << hi) - 1ull;
-  }
+  const int nw = (K + 63) >> 6, tid = threadIdx.x;
   __shared__ int part[256];
-  const int cnt = __popcll(alive);
-  part[w] = cnt;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int v = w >= off ? part[w - off] : 0;
+  int base = 0;
+  for (int w0 = 0; w0 < nw; w0 += 256) {
+    const int w = w0 + tid;
+    unsigned long long alive = 0ull;
+    if (w < nw) {
+      alive = ~supp_state[w];
+      const int lo = first_row - (w << 6), hi = K - (w << 6);             // keep rows in [first_row, K)
+      if (lo >= 64) alive = 0ull; else if (lo > 0) alive &= ~0ull << lo;
+      if (hi < 64) alive &= hi <= 0 ? 0ull : (1ull << hi) - 1ull;
+    }
+    const int cnt = __popcll(alive);
+    part[tid] = cnt;
     __syncthreads();
-    part[w] += v;
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    int pos = base + part[tid] - cnt;
+    while (alive) {
+      const int b = __ffsll(alive) - 1;
+      rows_out[pos++] = (w << 6) + b;
+      alive &= alive - 1ull;
+    }
+    base += part[255];
     __syncthreads();
   }
-  int pos = part[w] - cnt;
-  while (alive) {
-    const int b = __ffsll(alive) - 1;
-    rows_out[pos++] = (w << 6) + b;
-    alive &= alive - 1ull;
-  }
-  if (w == 255) *nrows_out = part[255];
+  if (tid == 0) *nrows_out = base;
 }
 
-__global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict__ dets, const int* __restrict__ order,
-                                                        const unsigned long long* __restrict__ vote,
-                                                        const unsigned long long* __restrict__ snap, int cap,
-                                                        const int* __restrict__ d_count, int nwcap,
-                                                        const int* __restrict__ keep_q, const int* __restrict__ d_nkeep,
-                                                        float* __restrict__ out, WnmsBatch bs) {
+// One kept row: neighbourhood list, median yaw, weighted sums.  nbl / yws hold n + 1 entries (LDS in the common case, a
+// per-frame global scratch for the rare row whose neighbourhood does not fit -- see wnms_merge_big_kernel).
+__device__ void wnms_merge_row(const float* __restrict__ dets, const int* __restrict__ order,
+                               const unsigned long long* __restrict__ vrow, const unsigned long long* __restrict__ srow,
+                               int nw, int q, int* nbl, float* yws, int lane, float* __restrict__ orow, bool global_scratch) {
   RD_NOCONTRACT
-  dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; vote += blockIdx.z * bs.words; snap += blockIdx.z * bs.words;
-  keep_q += blockIdx.z * bs.ints; out += blockIdx.z * bs.out;
-  const int mrow = blockIdx.x;
-  if (mrow >= d_nkeep[blockIdx.z]) return;
-  HIP_DYNAMIC_SHARED(unsigned char, smem);  // (cap + 2) ints + (cap + 2) floats
-  int* nbl = (int*)smem;
-  float* yws = (float*)(smem + (size_t)(cap + 2) * 4);
-  const int lane = threadIdx.x;
-  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
-  const int nw = (K + 63) >> 6;
-  const int q = keep_q[mrow];
   const int irow = order[q];
   const float yaw_i = dets[(size_t)irow * 12 + 8];
   // neighbourhood list in ascending sorted position, self first (nms.h:496-517)
@@ -401,7 +471,7 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
     yws[0] = yaw_i;
   }
   for (int w = q >> 6; w < nw; ++w) {
-    unsigned long long word = vote[(size_t)q * nwcap + w] & ~snap[(size_t)mrow * nwcap + w];
+    unsigned long long word = vrow[w] & ~srow[w];
     if ((word >> lane) & 1ull) {
       int pos = n + __popcll(word & ((1ull << lane) - 1ull));
       int q2 = (w << 6) + lane;
@@ -410,6 +480,7 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
     }
     n += __popcll(word);
   }
+  if (global_scratch) __threadfence();
   __syncthreads();
   // median yaw (nms.h:527-540)
   float med = yaw_i;
@@ -419,6 +490,7 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
       if (lane == 0) yws[n] = yaw_i;
       sz = n + 1;
     }
+    if (global_scratch) __threadfence();
     __syncthreads();
     const int target = sz >> 1;
     float found = 0.f;
@@ -460,8 +532,288 @@ __global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict_
       sum3 += p;
     }
   }
-  if (lane < 11) out[(size_t)mrow * 12 + lane] = sum1 / sum3;
-  if (lane == 11) out[(size_t)mrow * 12 + 11] = dets[(size_t)irow * 12 + 11];
+  if (lane < 11) orow[lane] = sum1 / sum3;
+  if (lane == 11) orow[11] = dets[(size_t)irow * 12 + 11];
+}
+
+// One wavefront per kept row.  lds_cap = entries of the LDS neighbourhood list; a row whose neighbourhood (+ the median's
+// extra slot) does not fit is appended to the frame's overflow list and handled by wnms_merge_big_kernel.
+__global__ __launch_bounds__(64) void wnms_merge_kernel(const float* __restrict__ dets, const int* __restrict__ order,
+                                                        const unsigned long long* __restrict__ vote,
+                                                        const unsigned long long* __restrict__ snap, int cap,
+                                                        const int* __restrict__ d_count, int nwcap,
+                                                        const int* __restrict__ keep_q, const int* __restrict__ d_nkeep,
+                                                        float* __restrict__ out, WnmsBatch bs, int lds_cap,
+                                                        int* __restrict__ ovf, int* __restrict__ novf) {
+  dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; vote += blockIdx.z * bs.words; snap += blockIdx.z * bs.words;
+  keep_q += blockIdx.z * bs.ints; out += blockIdx.z * bs.out; ovf += blockIdx.z * bs.ints; novf += blockIdx.z * bs.ints;
+  HIP_DYNAMIC_SHARED(unsigned char, smem);  // lds_cap ints + lds_cap floats
+  const int lane = threadIdx.x;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
+  const int nw = (K + 63) >> 6;
+  const int nkeep = d_nkeep[blockIdx.z];
+  for (int mrow = blockIdx.x; mrow < nkeep; mrow += gridDim.x) {
+    const int q = keep_q[mrow];
+    const unsigned long long* vrow = vote + (size_t)q * nwcap;
+    const unsigned long long* srow = snap + (size_t)mrow * nwcap;
+    if (K + 2 > lds_cap) {   // the list might not fit: count first
+      int n = 1;
+      for (int w = (q >> 6) + lane; w < nw; w += 64) n += __popcll(vrow[w] & ~srow[w]);
+      for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+      n -= 63;                                               // every lane started from 1
+      if (n + 1 > lds_cap) {
+        if (lane == 0) ovf[atomicAdd(novf, 1)] = mrow;
+        continue;
+      }
+    }
+    __syncthreads();                                         // previous row's list readers are done
+    wnms_merge_row(dets, order, vrow, srow, nw, q, (int*)smem, (float*)(smem + (size_t)lds_cap * 4), lane,
+                   out + (size_t)mrow * 12, false);
+  }
+}
+// The overflow rows of a frame, one after the other, with the list in the frame's global scratch (cap + 2 entries).
+__global__ __launch_bounds__(64) void wnms_merge_big_kernel(const float* __restrict__ dets, const int* __restrict__ order,
+                                                            const unsigned long long* __restrict__ vote,
+                                                            const unsigned long long* __restrict__ snap, int cap,
+                                                            const int* __restrict__ d_count, int nwcap,
+                                                            const int* __restrict__ keep_q, float* __restrict__ out,
+                                                            WnmsBatch bs, const int* __restrict__ ovf,
+                                                            const int* __restrict__ novf, int* __restrict__ scratch) {
+  dets += blockIdx.z * bs.dets; order += blockIdx.z * bs.order; vote += blockIdx.z * bs.words; snap += blockIdx.z * bs.words;
+  keep_q += blockIdx.z * bs.ints; out += blockIdx.z * bs.out; ovf += blockIdx.z * bs.ints; novf += blockIdx.z * bs.ints;
+  scratch += blockIdx.z * bs.ints;
+  const int n_ovf = *novf;
+  if (n_ovf == 0) return;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
+  const int nw = (K + 63) >> 6;
+  for (int i = 0; i < n_ovf; ++i) {
+    const int mrow = ovf[i], q = keep_q[mrow];
+    __syncthreads();
+    wnms_merge_row(dets, order, vote + (size_t)q * nwcap, snap + (size_t)mrow * nwcap, nw, q, scratch,
+                   (float*)(scratch + cap + 2), threadIdx.x, out + (size_t)mrow * 12, true);
+    __threadfence();
+  }
+}
+
+// ---- processing order of the reference: std::sort with an unstable comparator on ties (nms.h:786-792) ----------------------
+// point4_wnms_4c sorts iota(K) with `score[i] > score[j]` through libstdc++'s std::sort, whose result for tied scores is
+// whatever introsort leaves.  This kernel replays that algorithm (GCC libstdc++ bits/stl_algo.h: __introsort_loop with
+// median-of-three to first + unguarded Hoare partition, threshold 16, depth limit 2*floor(log2 n) -> heap sort, then the
+// final insertion sort) decision by decision, one wavefront per frame: the partition scans advance 64 elements per step
+// (ballot), the sub-ranges are independent of the order in which they are processed (explicit stack), and the final
+// insertion sort never moves an element across the boundary of a finished range (left >= pivot >= right), so the
+// finished ranges are insertion-sorted independently, one lane per range.  Strictly decreasing input (the common case in
+// the pipeline: rows arrive sorted, ties are rare) is recognised up front: every correct sort returns the identity.
+struct TieSort {
+  float* sc; int* ix; unsigned* segbit; int n, lane; bool fence;
+  __device__ __forceinline__ void sync() const {
+    if (fence) __threadfence();
+    __builtin_amdgcn_wave_barrier();
+  }
+  // (the leading barrier orders "every lane has read its operands" before lane 0 writes: free on hardware, where the
+  // wave runs in lockstep; required under hipemu, where lanes are fibers)
+  __device__ __forceinline__ void swap(int a, int b) const {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && a != b) {
+      const float t = sc[a]; sc[a] = sc[b]; sc[b] = t;
+      const int u = ix[a]; ix[a] = ix[b]; ix[b] = u;
+    }
+    sync();
+  }
+  __device__ __forceinline__ void mark(int first) const {
+    if (lane == 0) segbit[first >> 5] |= 1u << (first & 31);
+  }
+  __device__ int partition_pivot(int first, int last) const {          // __unguarded_partition_pivot
+    const int mid = first + (last - first) / 2;
+    const int a = first + 1, b = mid, c = last - 1;                    // __move_median_to_first(first, a, b, c)
+    const float sa = sc[a], sb = sc[b], s3 = sc[c];
+    if (sa > sb) {
+      if (sb > s3) swap(first, b); else if (sa > s3) swap(first, c); else swap(first, a);
+    } else if (sa > s3) swap(first, a);
+    else if (sb > s3) swap(first, c);
+    else swap(first, b);
+    const float pv = sc[first];
+    int f = first + 1, l = last;                                       // __unguarded_partition(first + 1, last, first)
+    for (;;) {
+      for (;;) {                                                       // while (comp(f, pivot)) ++f;
+        const int p = f + lane;
+        const bool go = p < n && sc[p] > pv;
+        const unsigned long long stop = __ballot(!go);
+        if (stop) { f += __ffsll(stop) - 1; break; }
+        f += 64;
+      }
+      --l;
+      for (;;) {                                                       // while (comp(pivot, l)) --l;
+        const int p = l - lane;
+        const bool go = p >= 0 && pv > sc[p];
+        const unsigned long long stop = __ballot(!go);
+        if (stop) { l -= __ffsll(stop) - 1; break; }
+        l -= 64;
+      }
+      if (!(f < l)) return f;
+      swap(f, l);
+      ++f;
+    }
+  }
+  // heap sort of [first, last): __partial_sort(first, last, last) = __make_heap + __sort_heap (all lanes in lockstep, lane 0 writes)
+  __device__ void put(int p, float s, int i) const {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { sc[p] = s; ix[p] = i; }
+    sync();
+  }
+  __device__ void adjust_heap(int first, int hole, int len, float vs, int vi) const {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (sc[first + child] > sc[first + child - 1]) --child;
+      put(first + hole, sc[first + child], ix[first + child]);
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      put(first + hole, sc[first + child - 1], ix[first + child - 1]);
+      hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                                       // __push_heap
+    while (hole > top && sc[first + parent] > vs) {
+      put(first + hole, sc[first + parent], ix[first + parent]);
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    put(first + hole, vs, vi);
+  }
+  __device__ void heap_sort(int first, int last) const {
+    const int len = last - first;
+    if (len >= 2)
+      for (int parent = (len - 2) / 2;; --parent) {                    // __make_heap
+        adjust_heap(first, parent, len, sc[first + parent], ix[first + parent]);
+        if (parent == 0) break;
+      }
+    for (int l = last; l - first > 1;) {                               // __sort_heap / __pop_heap
+      --l;
+      const float vs = sc[l]; const int vi = ix[l];
+      put(l, sc[first], ix[first]);
+      adjust_heap(first, 0, l - first, vs, vi);
+    }
+  }
+  __device__ void run(int* stack) const {
+    if (n < 2) return;
+    int sp = 0, first = 0, last = n, depth = 2 * (31 - __clz(n));
+    for (;;) {
+      while (last - first > 16) {                                      // __introsort_loop
+        if (depth == 0) { heap_sort(first, last); break; }
+        --depth;
+        const int cut = partition_pivot(first, last);
+        stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; ++sp;
+        last = cut;
+      }
+      if (first < n) mark(first);
+      if (sp == 0) break;
+      --sp;
+      first = stack[3 * sp]; last = stack[3 * sp + 1]; depth = stack[3 * sp + 2];
+    }
+    sync();
+    // __final_insertion_sort, range by range: lane owns the ranges that start in its bitmap words
+    const int nwords = (n + 31) >> 5;
+    for (int w = lane; w < nwords; w += 64) {
+      unsigned bits = segbit[w];
+      while (bits) {
+        const int s = (w << 5) + __ffs(bits) - 1;
+        bits &= bits - 1u;
+        int e = n;                                                      // next range start
+        {
+          unsigned rest = bits;
+          int ww = w;
+          while (!rest && ++ww < nwords) rest = segbit[ww];
+          if (rest) e = (ww << 5) + __ffs(rest) - 1;
+        }
+        for (int i = s + 1; i < e; ++i) {
+          const float v = sc[i]; const int vi = ix[i];
+          int j = i;
+          while (j > s && v > sc[j - 1]) { sc[j] = sc[j - 1]; ix[j] = ix[j - 1]; --j; }
+          sc[j] = v; ix[j] = vi;
+        }
+      }
+    }
+    sync();
+  }
+};
+constexpr int TIE_LDS_K = 16384;   // keys + indices + range bitmap in LDS up to this K (130 KB); beyond it: global scratch
+__global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restrict__ dets, int cap,
+                                                            const int* __restrict__ d_count, int* __restrict__ order,
+                                                            WnmsBatch bs, long order_stride, int* __restrict__ scratch) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  dets += blockIdx.z * bs.dets; order += blockIdx.z * order_stride; scratch += blockIdx.z * bs.ints;
+  const int lane = threadIdx.x;
+  const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
+  // identity for the unused tail; strictly decreasing scores -> identity everywhere
+  int unsorted = 0;
+  for (int i = lane; i < cap; i += 64) {
+    order[i] = i;
+    if (i + 1 < K && !(dets[(size_t)i * 12 + 11] > dets[(size_t)(i + 1) * 12 + 11])) unsorted = 1;
+  }
+  if (!__ballot(unsorted)) return;
+  __shared__ int stack[3 * 40];
+  TieSort T;
+  T.n = K; T.lane = lane;
+  const int nbit = (K + 31) >> 5;
+  if (cap <= TIE_LDS_K) {
+    T.sc = (float*)smem; T.ix = (int*)(smem + (size_t)cap * 4); T.segbit = (unsigned*)(smem + (size_t)cap * 8); T.fence = false;
+  } else {
+    T.sc = (float*)scratch; T.ix = scratch + cap; T.segbit = (unsigned*)(scratch + 2 * (size_t)cap); T.fence = true;
+  }
+  for (int i = lane; i < K; i += 64) { T.sc[i] = dets[(size_t)i * 12 + 11]; T.ix[i] = i; }
+  for (int i = lane; i < nbit; i += 64) T.segbit[i] = 0u;
+  T.sync();
+  T.run(stack);
+  for (int i = lane; i < K; i += 64) order[i] = T.ix[i];
+}
+
+// OverlapChecker::single_overlap (nms.h:195-249) for n independent row pairs: out[i] = overlap(a[i], b[i]) with a as the
+// first (kept) box.  Rows are (.., 12) dets rows (8 corners, yaw, bottom, height, score); the per-box preparation is the
+// same code as wnms_prep_kernel's (normalised winding, edge angles, area).
+__device__ __forceinline__ void w_prep_box(const float* b, float* o) {
+  RD_NOCONTRACT
+  WPt p[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = {b[2 * k], b[2 * k + 1]};
+  bool cw = ((p[1].x - p[0].x) * (p[2].y - p[0].y) - (p[2].x - p[0].x) * (p[1].y - p[0].y)) > 0;
+  if (cw) {
+    WPt t0 = p[0], t1 = p[1];
+    p[0] = p[3]; p[1] = p[2]; p[2] = t1; p[3] = t0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = p[k].x;
+    o[2 * k + 1] = p[k].y;
+    int k1 = (k + 1) & 3;
+    o[8 + k] = atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);
+  }
+  float area = 0.f;
+  area += w_cross3(p[0], p[1], p[2]);
+  area += w_cross3(p[0], p[2], p[3]);
+  if (area < 0) area = -area;
+  o[12] = area / 2;
+  o[13] = b[9];
+  o[14] = b[10];
+  o[15] = 0.f;
+}
+__global__ __launch_bounds__(64) void single_overlap_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                            int is3d, float* __restrict__ out) {
+  __shared__ float edges[EDGE_LDS_BYTES / 4];
+  __shared__ float pb[64 * 16];
+  const int t = threadIdx.x;
+  EdgeLds EL;
+  EL.ax = edges; EL.ay = edges + 512; EL.bx = edges + 1024; EL.by = edges + 1536; EL.an = edges + 2048;
+  EL.dq = (int*)(edges + 2560);
+  EL.t = t;
+  const long i = (long)blockIdx.x * 64 + t;
+  if (i >= n) return;
+  float pa[16];
+  w_prep_box(a + i * 12, pa);
+  w_prep_box(b + i * 12, pb + t * 16);
+  out[i] = w_overlap(pa, pb + t * 16, is3d != 0, EL);
 }
 
 __global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {
@@ -472,7 +824,7 @@ __global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {
 struct WnmsWs {
   float* prep;
   unsigned long long *thr, *vote, *snap, *supp_state;
-  int *keep_q, *order, *alive, *nalive;
+  int *keep_q, *order, *alive, *nalive, *ovf, *novf, *scratch;
   void* sort_ws;
   int nwcap;
 };

@@ -19,8 +19,8 @@ namespace rd {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t wnms_ws_bytes(int cap) {
   const size_t nw = (size_t)(cap + 63) / 64;
-  return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 3 * align256((size_t)cap * 4) +
-         align256(nw * 8) + 256 + align256(sort_ws_bytes(cap)) + 256;
+  return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 4 * align256((size_t)cap * 4) +
+         align256(((size_t)cap + 2) * 8 + ((size_t)cap / 32 + 2) * 4) + align256(nw * 8) + 256 + align256(sort_ws_bytes(cap)) + 256;
 }
 inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   WnmsWs w;
@@ -34,8 +34,11 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   w.keep_q = (int*)p; p += align256((size_t)cap * 4);
   w.order = (int*)p; p += align256((size_t)cap * 4);
   w.alive = (int*)p; p += align256((size_t)cap * 4);
+  w.ovf = (int*)p; p += align256((size_t)cap * 4);
+  // merge overflow list / tie-order keys (cap + 2 ints + cap + 2 floats, or cap floats + cap ints + a cap-bit map)
+  w.scratch = (int*)p; p += align256(((size_t)cap + 2) * 8 + ((size_t)cap / 32 + 2) * 4);
   w.supp_state = (unsigned long long*)p; p += align256(nw * 8);
-  w.nalive = (int*)p; p += 256;
+  w.nalive = (int*)p; w.novf = (int*)p + 1; p += 256;
   w.sort_ws = p;
   return w;
 }
@@ -397,19 +400,34 @@ int rd_score_filter_dets(const float* scores, const float* boxes10, long n, floa
 
 size_t rd_wnms_workspace_bytes(int Kcap) { return Kcap > 0 ? wnms_ws_bytes(Kcap) : 0; }
 int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int* d_count, const int* order,
-                       long order_bstride, float thresh, float thresh_vote, int is3d, float* out_dets, long out_bstride,
-                       int* keep, long keep_bstride, int* d_nkeep, void* ws, size_t ws_bytes, int B, void* stream) {
+                       long order_bstride, int tie_order, float thresh, float thresh_vote, int is3d, int hash_scale,
+                       float* out_dets, long out_bstride, int* keep, long keep_bstride, int* d_nkeep, void* ws,
+                       size_t ws_bytes, int B, void* stream) {
   RD_REQUIRE(dets && out_dets && keep && d_nkeep && ws, RD_EINVAL, "wnms_4c: null pointer");
   RD_REQUIRE(Kcap > 0 && Kcap <= RD_WNMS_MAX_K, RD_ESHAPE, "wnms_4c: Kcap %d not in [1, %d]", Kcap, RD_WNMS_MAX_K);
   RD_REQUIRE(B > 0, RD_ESHAPE, "wnms_4c: batch %d", B);
+  RD_REQUIRE(tie_order == RD_TIE_STABLE || tie_order == RD_TIE_REFERENCE, RD_EINVAL, "wnms_4c: tie_order %d", tie_order);
   const size_t per = rd_wnms_workspace_bytes(Kcap);
   RD_REQUIRE(ws_bytes >= per * (size_t)B, RD_EWORKSPACE, "wnms_4c: workspace %zu < %zu", ws_bytes, per * (size_t)B);
-  RD_REQUIRE(order || B == 1, RD_EINVAL, "wnms_4c: the batched call needs an explicit processing order");
+  RD_REQUIRE(order || B == 1 || tie_order == RD_TIE_REFERENCE, RD_EINVAL,
+             "wnms_4c: the batched call needs an explicit processing order or RD_TIE_REFERENCE");
   hipStream_t st = (hipStream_t)stream;
   WnmsWs w = wnms_ws_carve(ws, Kcap);
   ProfScope ps(RD_PROF_WNMS, st);
+  // consecutive frames use consecutive `per`-byte workspaces (per is a multiple of 256), so every carved array of
+  // frame b sits b * per bytes after frame 0's
+  WnmsBatch bs;
+  bs.dets = dets_bstride; bs.order = order_bstride; bs.prep = (long)(per / 4); bs.words = (long)(per / 8);
+  bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int* ord = order;
-  if (!ord) {  // device ordering: score descending, ties by row index ascending
+  if (!ord && tie_order == RD_TIE_REFERENCE) {   // the reference's own order: std::sort replayed on the device
+    const size_t lds = Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + ((size_t)Kcap / 32 + 2) * 4 : 0;
+    allow_big_lds(wnms_tie_order_kernel);
+    hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(64), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
+                       w.scratch);
+    ord = w.order;
+    bs.order = (long)(per / 4);
+  } else if (!ord) {  // device ordering: score descending, ties by row index ascending
     void* swa = (void*)(((uintptr_t)w.sort_ws + 255) & ~(uintptr_t)255);
     SortWs s = sort_ws_carve(swa, Kcap);
     hipLaunchKernelGGL(sort_keygen_dets_kernel, dim3((Kcap + 255) / 256), dim3(256), 0, st, dets, Kcap, d_count, s.keysA, s.idxA);
@@ -418,17 +436,16 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
     if (hipMemcpyAsync(w.order, s.idxA, (size_t)Kcap * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return rd::fail(RD_EHIP, "wnms_4c: order copy");
     ord = w.order;
-    order_bstride = 0;
+    bs.order = 0;
   }
-  // consecutive frames use consecutive `per`-byte workspaces (per is a multiple of 256), so every carved array of
-  // frame b sits b * per bytes after frame 0's
-  WnmsBatch bs;
-  bs.dets = dets_bstride; bs.order = order_bstride; bs.prep = (long)(per / 4); bs.words = (long)(per / 8);
-  bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int nb = (Kcap + 63) / 64;
-  hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs);
-  const size_t scan_lds = (size_t)65 * w.nwcap * 8;
-  RD_REQUIRE(scan_lds <= 160 * 1024, RD_ESHAPE, "wnms_4c: Kcap too large for the scan tile");
+  hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs,
+                     (float)hash_scale, w.novf);
+  // RD_WNMS_TILE_W / RD_WNMS_MERGE_LDS: test switches that force the column-chunked scan and the merge overflow path at small K
+  const char* e_tw = getenv("RD_WNMS_TILE_W");
+  const char* e_ml = getenv("RD_WNMS_MERGE_LDS");
+  const int tile_w = std::min(w.nwcap, e_tw ? std::max(1, atoi(e_tw)) : 256);
+  const size_t scan_lds = ((size_t)w.nwcap + (size_t)64 * tile_w) * 8;
   allow_big_lds(wnms_scan_kernel);
   // Two rounds.  The greedy scan only ever reads the thr / vote rows of boxes it KEEPS, and the highest-scoring boxes
   // suppress most of the rest: round 1 evaluates the pairs of the first R1 rows and scans them; round 2 evaluates pairs
@@ -437,28 +454,42 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const int R1 = 256, nb1 = R1 / 64;
   static const bool one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;   // dev switch (tools/wnms_bench.py)
   const bool two = Kcap >= 4 * R1 && !one_round;
-  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, two ? nb1 : nb, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
+  // pair tiles are strided over a fixed number of single-wave workgroups: enough to fill the CUs a few waves deep
+  const int pgrid = std::max(64, 4096 / B);
+  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
                      thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)nullptr, (const int*)nullptr,
-                     (const unsigned long long*)nullptr);
+                     (const unsigned long long*)nullptr, 0, two ? nb1 : nb);
   hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
-                     w.keep_q, keep, d_nkeep, bs, 0, two ? nb1 : nb, two ? w.supp_state : (unsigned long long*)nullptr);
+                     w.keep_q, keep, d_nkeep, bs, 0, two ? nb1 : nb, two ? w.supp_state : (unsigned long long*)nullptr, tile_w);
   if (two) {
     hipLaunchKernelGGL(wnms_alive_kernel, dim3(1, 1, B), dim3(256), 0, st, w.supp_state, Kcap, d_count, R1, w.alive, w.nalive, bs);
-    hipLaunchKernelGGL(wnms_pairs_kernel, dim3(nb * WN_CT, nb - nb1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
+    hipLaunchKernelGGL(wnms_pairs_kernel, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
                        thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)w.alive, (const int*)w.nalive,
-                       (const unsigned long long*)w.supp_state);
+                       (const unsigned long long*)w.supp_state, 0, 0);
     hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
-                       w.keep_q, keep, d_nkeep, bs, nb1, nb, w.supp_state);
+                       w.keep_q, keep, d_nkeep, bs, nb1, nb, w.supp_state, tile_w);
   }
   allow_big_lds(wnms_merge_kernel);
-  hipLaunchKernelGGL(wnms_merge_kernel, dim3(Kcap, 1, B), dim3(64), (size_t)(Kcap + 2) * 8, st, dets, ord, w.vote, w.snap, Kcap,
-                     d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs);
+  const int lds_cap = std::min(Kcap + 2, e_ml ? std::max(4, atoi(e_ml)) : 16384);
+  hipLaunchKernelGGL(wnms_merge_kernel, dim3(std::min(Kcap, 4096), 1, B), dim3(64), (size_t)lds_cap * 8, st, dets, ord, w.vote,
+                     w.snap, Kcap, d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs, lds_cap, w.ovf, w.novf);
+  if (Kcap + 2 > lds_cap)
+    hipLaunchKernelGGL(wnms_merge_big_kernel, dim3(1, 1, B), dim3(64), 0, st, dets, ord, w.vote, w.snap, Kcap, d_count, w.nwcap,
+                       w.keep_q, out_dets, bs, (const int*)w.ovf, (const int*)w.novf, w.scratch);
   return check_launch("wnms_4c");
 }
-int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, float thresh, float thresh_vote,
-               int is3d, float* out_dets, int* keep, int* d_nkeep, void* ws, size_t ws_bytes, void* stream) {
-  return rd_wnms_4c_batched(dets, 0, Kcap, d_count, order, 0, thresh, thresh_vote, is3d, out_dets, 0, keep, 0, d_nkeep, ws,
-                            ws_bytes, 1, stream);
+int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, int tie_order, float thresh,
+               float thresh_vote, int is3d, int hash_scale, float* out_dets, int* keep, int* d_nkeep, void* ws,
+               size_t ws_bytes, void* stream) {
+  return rd_wnms_4c_batched(dets, 0, Kcap, d_count, order, 0, tie_order, thresh, thresh_vote, is3d, hash_scale, out_dets, 0,
+                            keep, 0, d_nkeep, ws, ws_bytes, 1, stream);
+}
+int rd_single_overlap(const float* dets_a, const float* dets_b, long n, int is3d, float* out, void* stream) {
+  RD_REQUIRE(n >= 0 && (n == 0 || (dets_a && dets_b && out)), RD_EINVAL, "single_overlap: bad arguments");
+  if (n == 0) return RD_OK;
+  hipLaunchKernelGGL(single_overlap_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dets_a, dets_b, n,
+                     is3d, out);
+  return check_launch("single_overlap");
 }
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
   RD_REQUIRE(K >= 0 && (K == 0 || (dets_host && order_host)), RD_EINVAL, "wnms_order_host: bad arguments");

@@ -13,7 +13,8 @@ import numpy as np
 RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
 RD_F32, RD_BF16 = 0, 1
 RD_RELU_PRE, RD_ADD, RD_RELU_POST = 1, 2, 4
-RD_WNMS_MAX_K = 16384
+RD_WNMS_MAX_K = 65536
+RD_TIE_STABLE, RD_TIE_REFERENCE = 0, 1
 PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -56,11 +57,12 @@ SIGNATURES = {
     "rd_score_filter_dets_batched": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_float, c_void_p, c_long, c_void_p,
                                              c_void_p, c_size_t, c_int, c_void_p]),
     "rd_wnms_workspace_bytes": (c_size_t, [c_int]),
-    "rd_wnms_4c_batched": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p,
-                                   c_long, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "rd_wnms_4c_batched": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_int, c_int,
+                                   c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "rd_dets12_to_8_batched": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
-    "rd_wnms_4c": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
-                           c_void_p, c_size_t, c_void_p]),
+    "rd_wnms_4c": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rd_single_overlap": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "rd_wnms_order_host": (c_int, [c_void_p, c_int, c_void_p]),
     "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),

@@ -21,8 +21,9 @@ def input_shapes(H, W, strides=(1, 2, 4)):
 class PostProcessor:
     """tools/test.py:200-224 on the device for one frame: (k,) scores + (k,10) boxes -> (M,12) rows, keep, (M,8)."""
 
-    def __init__(self, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096):
-        self.k, self.cap = k, min(cap, rdlib.RD_WNMS_MAX_K)
+    def __init__(self, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096, hash_scale=100, tie_order="reference"):
+        self.k, self.cap = k, min(cap, k, rdlib.RD_WNMS_MAX_K)
+        self.hash_scale, self.tie_order = int(hash_scale), tie_order
         self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
         self.L, self.A = lib, alloc
         A, L = alloc, lib
@@ -36,8 +37,9 @@ class PostProcessor:
         self.keep = A.alloc(self.cap * 4)
         self.nkeep = A.alloc(16, zero=True)
         self.out8 = A.alloc(self.cap * 8 * 4)
-        # the rows reaching WNMS are already in (score desc, index asc) order: get_sorted_foreground sorts and the score
-        # filter is a stable compaction, so the processing order is the identity and the device re-sort is skipped
+        # tie_order "stable": the rows reaching WNMS are already in (score desc, index asc) order -- get_sorted_foreground
+        # sorts and the score filter is a stable compaction -- so the processing order is the identity.  "reference"
+        # (default): the library replays the reference's std::sort (nms.h:786-792) so tied scores are processed in its order
         self.identity = A.upload(np.arange(self.cap, dtype=np.int32))
 
     def enqueue_filter(self, score_ptr, box_ptr, stream=None):
@@ -50,8 +52,11 @@ class PostProcessor:
     def enqueue_nms(self, order_ptr=None, stream=None):
         L, A = self.L, self.A
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
-        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr or A.ptr(self.identity), self.thr_lo, self.thr_hi,
-               self.is3d, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, st)
+        if order_ptr is None and self.tie_order == "stable":
+            order_ptr = A.ptr(self.identity)
+        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr, rdlib.RD_TIE_REFERENCE, self.thr_lo,
+               self.thr_hi, self.is3d, self.hash_scale, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w),
+               self.ws_w_bytes, st)
         L.call("rd_dets12_to_8", A.ptr(self.out), self.cap, A.ptr(self.nkeep), A.ptr(self.out8), st)
 
     def enqueue(self, score_ptr, box_ptr, order_ptr=None, stream=None):
@@ -81,8 +86,9 @@ class BatchPostProcessor:
     single latency-bound wavefront per frame, so B of them run side by side instead of back to back.  Per-frame buffers
     are slices of contiguous allocations; frame b's results are read back with collect(b)."""
 
-    def __init__(self, B, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096):
-        self.B, self.k, self.cap = B, k, min(cap, rdlib.RD_WNMS_MAX_K)
+    def __init__(self, B, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096, hash_scale=100, tie_order="reference"):
+        self.B, self.k, self.cap = B, k, min(cap, k, rdlib.RD_WNMS_MAX_K)
+        self.hash_scale, self.tie_order = int(hash_scale), tie_order
         self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
         self.L, self.A = lib, alloc
         A, L = alloc, lib
@@ -107,9 +113,10 @@ class BatchPostProcessor:
     def enqueue_nms(self, stream=None):
         L, A = self.L, self.A
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
-        L.call("rd_wnms_4c_batched", A.ptr(self.dets), self.k * 12, self.cap, A.ptr(self.count), A.ptr(self.identity), 0,
-               self.thr_lo, self.thr_hi, self.is3d, A.ptr(self.out), self.cap * 12, A.ptr(self.keep), self.cap,
-               A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, self.B, st)
+        order = A.ptr(self.identity) if self.tie_order == "stable" else None
+        L.call("rd_wnms_4c_batched", A.ptr(self.dets), self.k * 12, self.cap, A.ptr(self.count), order, 0,
+               rdlib.RD_TIE_REFERENCE, self.thr_lo, self.thr_hi, self.is3d, self.hash_scale, A.ptr(self.out), self.cap * 12,
+               A.ptr(self.keep), self.cap, A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, self.B, st)
         L.call("rd_dets12_to_8_batched", A.ptr(self.out), self.cap * 12, self.cap, A.ptr(self.nkeep), A.ptr(self.out8),
                self.cap * 8, self.B, st)
 

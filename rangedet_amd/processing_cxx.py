@@ -2,10 +2,10 @@
 (operator_cxx/src_cxx/pybinding.cpp:6-11): ``wnms_4c(dets, thresh, thresh_vote, _3D, hash_scale) -> (list, list)``
 with positional arguments only, ``assign3D_v2``, ``get_point_num``; executed by the HIP kernels of librangedet_hip.so.
 
-Ordering: the reference sorts with std::sort (unstable, nms.h:786-792); ``rd_wnms_order_host`` runs that same call on
-the host so tied scores come out exactly as in the reference, everything else happens on the GPU.  ``hash_scale`` only
-parameterises the reference's spatial prefilter, which never rejects a pair that could matter; it is accepted
-and ignored.  ``assign3D_v2`` / ``get_point_num`` (training-target generation, assigner.h) run on the GPU as well.
+Ordering: the reference sorts with std::sort (unstable, nms.h:786-792); the library replays that sort on the device
+(RD_TIE_REFERENCE) so tied scores are processed exactly as in the reference.  ``hash_scale`` is the cell size of the
+reference's BBoxHash prefilter (nms.h:252-307): boxes without a common cell are never compared, here as there.
+``assign3D_v2`` / ``get_point_num`` (training-target generation, assigner.h) run on the GPU as well.
 """
 import numpy as np
 
@@ -30,12 +30,11 @@ def wnms_4c(dets, thresh, thresh_vote, _3D, hash_scale):
     if K > rdlib.RD_WNMS_MAX_K:
         raise rdlib.RangeDetError(rdlib.RD_ESHAPE, "wnms_4c: %d boxes exceed RD_WNMS_MAX_K" % K)
     L, A = _ctx()
-    order = L.wnms_order_host(d)
-    dd, od = A.upload(d), A.upload(order)
+    dd = A.upload(d)
     nb = L.raw("rd_wnms_workspace_bytes")(K)
     ws, out, keep, nk = A.alloc(nb), A.alloc(K * 48), A.alloc(K * 4), A.alloc(16, zero=True)
-    L.call("rd_wnms_4c", A.ptr(dd), K, None, A.ptr(od), float(thresh), float(thresh_vote), int(bool(_3D)), A.ptr(out),
-           A.ptr(keep), A.ptr(nk), A.ptr(ws), nb, A.stream)
+    L.call("rd_wnms_4c", A.ptr(dd), K, None, None, rdlib.RD_TIE_REFERENCE, float(thresh), float(thresh_vote), int(bool(_3D)),
+           int(hash_scale), A.ptr(out), A.ptr(keep), A.ptr(nk), A.ptr(ws), nb, A.stream)
     A.sync()
     M = int(A.to_numpy(A.view_i32(nk, (1,)))[0])
     rows = A.to_numpy(A.view_f32(out, (K, 12)))[:M]

@@ -247,6 +247,7 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return hipemu::exchange(v, 0); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }

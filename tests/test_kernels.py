@@ -1,5 +1,8 @@
 """Parity of every C-ABI entry point against the oracle / a plain PyTorch-CPU fp32 reference on seeded inputs.
 Each case runs on 'emu' (hipemu CPU build of the same HIP sources; CPU tier) and on 'hip' (real MI355X; -m gpu)."""
+import glob
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -276,7 +279,7 @@ def test_decode3d_bbox(be):
         L.call("rd_decode3d_bbox", be.ptr(out), be.ptr(out), be.ptr(out), B, N, 9, 0, be.stream)
 
 
-def _wnms(be, d, thr, vote, is3d, order=None, cap_extra=5):
+def _wnms(be, d, thr, vote, is3d, order=None, cap_extra=5, tie=R.RD_TIE_STABLE, hash_scale=100):
     L = be.lib
     K = d.shape[0]
     cap = K + cap_extra
@@ -289,7 +292,7 @@ def _wnms(be, d, thr, vote, is3d, order=None, cap_extra=5):
     nb = L.raw("rd_wnms_workspace_bytes")(cap)
     ws, outd, keep, nk = be.empty(nb), be.empty(cap * 48), be.empty(cap * 4), be.empty(16)
     L.call("rd_wnms_4c", be.ptr(be.up(dbuf)), cap, be.ptr(be.up(np.array([K], np.int32))), be.ptr(be.up(ob)) if ob is not None else None,
-           thr, vote, int(is3d), be.ptr(outd), be.ptr(keep), be.ptr(nk), be.ptr(ws), nb, be.stream)
+           tie, thr, vote, int(is3d), hash_scale, be.ptr(outd), be.ptr(keep), be.ptr(nk), be.ptr(ws), nb, be.stream)
     M = int(be.down(nk, np.int32, (1,))[0])
     return be.down(outd, np.float32, (cap, 12))[:M], be.down(keep, np.int32, (cap,))[:M]
 
@@ -312,6 +315,9 @@ def test_wnms_vs_oracle(be, case):
     flat2, rk2 = O.wnms_4c(d, 0.1, 0.5, bool(is3d), 100, order=o2)
     assert keep2.tolist() == rk2
     assert np.array_equal(rows2.view(np.uint32), np.array(flat2, np.float32).reshape(-1, 12).view(np.uint32))
+    # the reference's order computed on the device (std::sort replay): same result as with the host-side std::sort
+    rows3, keep3 = _wnms(be, d, 0.1, 0.5, is3d, None, tie=R.RD_TIE_REFERENCE)
+    assert keep3.tolist() == rk and np.array_equal(rows3.view(np.uint32), rows.view(np.uint32))
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -331,6 +337,126 @@ def test_wnms_two_rounds_vs_oracle(be, is3d):
     assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
     rows2, keep2 = _wnms(be, d, 0.1, 0.5, is3d, None, cap_extra=1024 + 64 - K if K < 1024 else 64)   # library-side ordering
     assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("f", sorted(glob.glob(os.path.join(GOLD, "wnms_*.npz"))), ids=os.path.basename)
+def test_wnms_golden_through_hip(be, f):
+    """Every committed golden vector (made by the REFERENCE's compiled nms.h, tests/golden/make_golden.py) through
+    rd_wnms_4c with the library's own ordering (std::sort replay) and the fixture's hash_scale: keep indices and merged rows
+    bit-equal.  Includes exact score ties (k512_ties), boxes beyond +-100 m (k256_far), hash_scale 10 (k256_hash10), 3-D IoU."""
+    g = np.load(f)
+    d = g["dets"]
+    if d.shape[0] == 0:
+        assert g["keep"].shape[0] == 0      # nms.h:463-466; the C ABI rejects Kcap == 0, callers skip the call
+        return
+    if be.name == "emu" and d.shape[0] > 600:
+        pytest.skip("CPU emulation of K = 2048 takes minutes; runs on the GPU tier")
+    rows, keep = _wnms(be, d, float(g["thresh"]), float(g["thresh_vote"]), bool(g["is3d"]), None, tie=R.RD_TIE_REFERENCE,
+                       hash_scale=int(g["hash_scale"]))
+    assert keep.tolist() == g["keep"].tolist()
+    assert np.array_equal(rows.view(np.uint32), g["rows"].view(np.uint32))
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_pair_overlap_golden_through_hip(be):
+    """pair_overlaps.npz (the reference's OverlapChecker::single_overlap on 1.1k box pairs) through rd_single_overlap: the
+    device polygon clipper restates the reference's float operations in order, so the IoUs are bit-equal (BEV and 3-D)."""
+    g = np.load(os.path.join(GOLD, "pair_overlaps.npz"))
+    a, b = g["a"], g["b"]
+    n = a.shape[0]
+    out = be.empty(n * 4)
+    for is3d, key in ((0, "iou"), (1, "iou3d")):
+        be.lib.call("rd_single_overlap", be.ptr(be.up(a)), be.ptr(be.up(b)), n, is3d, be.ptr(out), be.stream)
+        got = be.down(out, np.float32, (n,))
+        bad = got.view(np.uint32) != g[key].view(np.uint32)
+        # device atan2f differs from glibc by an ulp on a few edges; it only enters through |angle difference| < 1e-5
+        # comparisons, so a different IoU would need an edge pair within an ulp of that threshold -- none in the fixture
+        assert not bad.any(), (int(bad.sum()), np.abs(got - g[key]).max())
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_wnms_hash_prefilter_matters(be):
+    """Boxes spread over +-170 m so that many pairs lie in different 100 m cells (the four quadrants around the ego vehicle
+    never share a cell): result with hash_scale 100 and 10 equals the oracle (== reference) for that scale, and the
+    prefilter-free evaluation (hash_scale 0) is what the oracle gives with one huge cell."""
+    d = synth.cluster_dets(24, 10, seed=21, spread=170.0)
+    for hs in (100, 10, 37):
+        rows, keep = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, hash_scale=hs)
+        flat, rk = O.wnms_4c(d, 0.1, 0.5, False, hs)
+        assert keep.tolist() == rk, hs
+        assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
+    rows, keep = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, hash_scale=0)
+    flat, rk = O.wnms_4c(d, 0.1, 0.5, False, 30000)
+    assert keep.tolist() == rk
+
+
+def _tie_order(be, scores, cap_extra=3):
+    L = be.lib
+    K = len(scores)
+    cap = K + cap_extra
+    d = np.zeros((cap, 12), np.float32)
+    d[:K, 11] = scores
+    d[:K, :8] = np.array([0, 0, 1, 0, 1, 1, 0, 1], np.float32) + 5 * np.arange(K, dtype=np.float32)[:, None]   # disjoint boxes
+    d[:K, 10] = 1
+    nb = L.raw("rd_wnms_workspace_bytes")(cap)
+    ws, outd, keep, nk = be.empty(nb), be.empty(cap * 48), be.empty(cap * 4), be.empty(16)
+    L.call("rd_wnms_4c", be.ptr(be.up(d)), cap, be.ptr(be.up(np.array([K], np.int32))), None, R.RD_TIE_REFERENCE, 0.1, 0.5, 0, 0,
+           be.ptr(outd), be.ptr(keep), be.ptr(nk), be.ptr(ws), nb, be.stream)
+    assert int(be.down(nk, np.int32, (1,))[0]) == K      # nothing overlaps: every box is kept, in processing order
+    return be.down(keep, np.int32, (cap,))[:K], d[:K]
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_tie_order_replays_std_sort(be):
+    """The device replay of libstdc++'s std::sort (nms.h:786-792) against the real std::sort of the oracle build, on inputs
+    that exercise every branch: already sorted with ties (the pipeline's case), random with many ties, all equal, n <= 16
+    (insertion sort only), and a median-of-three killer sequence that drives introsort into its heap-sort fallback."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (1, 2, 3, 15, 16, 17, 33, 100, 700, 1500):
+        q = rng.integers(0, max(2, n // 3), n).astype(np.float32) / 64 + 0.5
+        cases.append(q)                                       # random order, many ties
+        cases.append(-np.sort(-q))                            # sorted, ties
+        cases.append(np.full(n, 0.75, np.float32))            # all equal
+        cases.append(-np.sort(-rng.uniform(0.5, 1, n).astype(np.float32)))   # strictly sorted: identity fast path
+    cases.append(O.antiqsort_keys(600))                       # adversarial input: depth limit reached -> heap sort
+    cases.append(O.antiqsort_keys(2000))
+    for sc in cases:
+        got, d = _tie_order(be, sc)
+        want = O.wnms_order(d)
+        assert np.array_equal(got, want), (len(sc), int((got != want).sum()))
+    assert O.std_sort_depth_limit_hit(O.antiqsort_keys(600))   # the killer really reaches the heap-sort branch
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_wnms_chunked_scan_and_merge_overflow(be, monkeypatch):
+    """K beyond 64*256 rows takes the column-chunked scan and neighbourhoods beyond the LDS list the global-scratch merge.
+    Both paths are forced at small K through the library's test switches and must give the same bits as the normal paths."""
+    d = synth.cluster_dets(40, 9, seed=31, quant=33)
+    base = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, cap_extra=1024)
+    flat, rk = O.wnms_4c(d, 0.1, 0.5, False, 100)
+    assert base[1].tolist() == rk
+    monkeypatch.setenv("RD_WNMS_TILE_W", "2")
+    monkeypatch.setenv("RD_WNMS_MERGE_LDS", "6")
+    alt = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, cap_extra=1024)
+    assert alt[1].tolist() == rk and np.array_equal(alt[0].view(np.uint32), base[0].view(np.uint32))
+    assert np.array_equal(base[0].view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_wnms_large_k(be):
+    """K = 20 000 rows above the score threshold (the reference accepts up to pre_nms_top_n = 50 000, nms.h:452-577): capacity
+    above 16 384 rows = column-chunked scan, global-memory tie order, grid-strided pair tiles.  Bit-equal to the oracle."""
+    d = synth.cluster_dets(2500, 8, seed=41, quant=1024)
+    assert d.shape[0] == 20000
+    rows, keep = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE)
+    flat, rk = O.wnms_4c(d, 0.1, 0.5, False, 100)
+    assert len(rk) > 1000 and keep.tolist() == rk
+    assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -424,8 +550,8 @@ def test_postprocess_batched(be):
     ident = be.up(np.arange(cap, dtype=np.int32))
     L.call("rd_score_filter_dets_batched", be.ptr(be.up(sc)), n, be.ptr(be.up(bx)), n * 10, n, 0.5, be.ptr(dets), n * 12,
            be.ptr(cnt), be.ptr(wsf), fb, B, be.stream)
-    L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), be.ptr(ident), 0, 0.1, 0.5, 0, be.ptr(out), cap * 12,
-           be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+    L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), be.ptr(ident), 0, R.RD_TIE_STABLE, 0.1, 0.5, 0, 100,
+           be.ptr(out), cap * 12, be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
     L.call("rd_dets12_to_8_batched", be.ptr(out), cap * 12, cap, be.ptr(nk), be.ptr(o8), cap * 8, B, be.stream)
     K = be.down(cnt, np.int32, (4,))[:B]
     M = be.down(nk, np.int32, (4,))[:B]
@@ -444,9 +570,19 @@ def test_postprocess_batched(be):
         assert kp[b, :M[b]].tolist() == rk
         assert np.array_equal(rows[b, :M[b]].view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
         assert np.abs(d8[b, :M[b]] - O.bbox3d_12dim_to_8dim(rows[b, :M[b]])).max() < 1e-4
-    with pytest.raises(Exception):   # B > 1 needs an explicit order
-        L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), None, 0, 0.1, 0.5, 0, be.ptr(out), cap * 12,
-               be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+    with pytest.raises(Exception):   # B > 1: explicit order or the reference's tie order
+        L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), None, 0, R.RD_TIE_STABLE, 0.1, 0.5, 0, 100,
+               be.ptr(out), cap * 12, be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+    # batched, order computed by the library the reference's way (frame 1 has exact score ties): equal to the oracle's default
+    L.call("rd_wnms_4c_batched", be.ptr(dets), n * 12, cap, be.ptr(cnt), None, 0, R.RD_TIE_REFERENCE, 0.1, 0.5, 0, 100,
+           be.ptr(out), cap * 12, be.ptr(keep), cap, be.ptr(nk), be.ptr(wsw), wb, B, be.stream)
+    M = be.down(nk, np.int32, (4,))[:B]
+    rows = be.down(out, np.float32, (B, cap, 12))
+    kp = be.down(keep, np.int32, (B, cap))
+    for b in range(2):
+        flat, rk = O.wnms_4c(alld[b, :K[b]], 0.1, 0.5, False, 100)
+        assert kp[b, :M[b]].tolist() == rk
+        assert np.array_equal(rows[b, :M[b]].view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -639,9 +775,9 @@ def test_error_conventions(be):
     assert rc == R.RD_ESHAPE and b"cout" in L.raw("rd_last_error_string")()
     rc = L.raw("rd_conv2d_bn_act")(p, 16, 0, p, p, p, None, 0, 0, p, 64, 0, 1, 2, 8, 16, 64, 5, 5, 1, 0, F32, be.stream)
     assert rc == R.RD_ESHAPE
-    rc = L.raw("rd_wnms_4c")(p, 100000, None, None, 0.1, 0.5, 0, p, p, p, p, 4096, be.stream)
+    rc = L.raw("rd_wnms_4c")(p, 100000, None, None, 0, 0.1, 0.5, 0, 100, p, p, p, p, 4096, be.stream)
     assert rc == R.RD_ESHAPE
-    rc = L.raw("rd_wnms_4c")(p, 64, None, None, 0.1, 0.5, 0, p, p, p, p, 16, be.stream)
+    rc = L.raw("rd_wnms_4c")(p, 64, None, None, 0, 0.1, 0.5, 0, 100, p, p, p, p, 16, be.stream)
     assert rc == R.RD_EWORKSPACE
     rc = L.raw("rd_decode3d_bbox")(None, p, p, 1, 10, 8, 0, be.stream)
     assert rc == R.RD_EINVAL
