@@ -170,8 +170,9 @@ def main():
     multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=4096, batch=Bf)
     pipe = multi.pipes[0]   # (per-kernel profiling replay and the roofline figures use one pipeline on the default stream)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
-    frames_np = [synth.make_batch([(rank + world * (i * Bf + j)) for j in range(Bf)]) for i in range(args.frames)]
-    frames = [{k: torch.from_numpy(v).to(dev) for k, v in f.items()} for f in frames_np]
+    # (synthetic raw records through the device transform chain, rd_input_transform)
+    frames = [synth.make_batch([(rank + world * (i * Bf + j)) for j in range(Bf)], lib=pipe.lib, alloc=pipe.alloc)
+              for i in range(args.frames)]
     L = pipe.lib
     REC = MAX_DET * 12 + 1
     gather_in = [torch.zeros(Bf * REC, device=dev) for _ in multi.pipes]
@@ -289,7 +290,8 @@ def main():
             "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) / Bf for k, v in prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params, {k: v[:1] for k, v in frames_np[0].items()})
+            from oracle import input_ref   # (the checker's numpy transform: only this leg may touch oracle/)
+            out["cpu_baseline"] = cpu_baseline(params, input_ref.make_frame(rank))
         line = json.dumps(out)
     if gather:
         dist.barrier()

@@ -70,6 +70,12 @@ int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int
 int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int src_cstride, int src_coff,
                     int src_dtype, void* stream);
 
+/* `rows` rows of `bytes` bytes: row r from src + r*src_row_bytes to dst + r*dst_row_bytes + dst_offset_bytes (device to
+ * device, on `stream`).  The per-level point / mask variables are concatenated with it (builder.py:454-458: concat of
+ * pc_vehicle_frame_s{1,2,4} / range_image_mask_s{1,2,4} along the point axis), one call per level for the whole batch. */
+int rd_copy_rows(const void* src, long src_row_bytes, void* dst, long dst_row_bytes, long dst_offset_bytes, long bytes,
+                 int rows, void* stream);
+
 /* ---- weight packing (HOST, no GPU needed) ---------------------------------------------------------- */
 /* Packed conv weights: [ntaps][nchunk][Cout][8 slots * (16/elem) channels], zero padded; one k-chunk =
  * 8 slots of 16 bytes.  rd_conv_packed_bytes gives the size.  w_oihw_host is (Cout,Cin,KH,KW) float32

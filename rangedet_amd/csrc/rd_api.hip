@@ -96,6 +96,17 @@ int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int
     return rd::fail(RD_EINVAL, "nchw_to_nhwc: dtype %d", dst_dtype);
   return check_launch("nchw_to_nhwc");
 }
+int rd_copy_rows(const void* src, long src_row_bytes, void* dst, long dst_row_bytes, long dst_offset_bytes, long bytes,
+                 int rows, void* stream) {
+  RD_REQUIRE(src && dst, RD_EINVAL, "copy_rows: null pointer");
+  RD_REQUIRE(rows > 0 && bytes > 0 && src_row_bytes >= bytes && dst_row_bytes >= dst_offset_bytes + bytes && dst_offset_bytes >= 0,
+             RD_ESHAPE, "copy_rows: bad geometry");
+  ProfScope ps(RD_PROF_LAYOUT, (hipStream_t)stream);
+  if (hipMemcpy2DAsync((char*)dst + dst_offset_bytes, (size_t)dst_row_bytes, src, (size_t)src_row_bytes, (size_t)bytes,
+                       (size_t)rows, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+    return rd::fail(RD_EHIP, "copy_rows: hipMemcpy2DAsync failed");
+  return RD_OK;
+}
 int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int src_cstride, int src_coff,
                     int src_dtype, void* stream) {
   RD_REQUIRE(src && dst, RD_EINVAL, "nhwc_to_nchw: null pointer");

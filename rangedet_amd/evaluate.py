@@ -6,8 +6,9 @@ transform -> forward + post-processing -> `output_dict` / `annotation_dict` -> t
         [--out experiments/<cfg>/checkpoint_output_dict_18e.pkl] [--bin-dir <dir> --config-name <cfg>] [--batch 8]
     python -m rangedet_amd.evaluate --synthetic 16 --random-weights --out /tmp/out.pkl         (self-contained dry run)
 
-A roidb record is the dict datasets/create_range_image_roidb.py writes: `pc_url` (npz with range_image_return1 /
-pc_vehicle_frame / ... arrays, rangedet/core/input.py:14-42), `gt_bbox_imu`, `gt_class`.  Frames are batched; each frame's
+A roidb record is the dict datasets/create_range_image_roidb.py writes: `pc_url` (npz with the arrays `range_image`,
+`pc_vehicle_frame`, `inclination`, `azimuth`, ...: create_range_image_roidb.py:119-124,164; read by LoadRecord,
+rangedet/core/input.py:23-38), `gt_bbox_imu`, `gt_class`.  Frames are batched; each frame's
 result is what tools/test.py:200-232 computes for it: `det_xyzlwhyaws[TYPE_VEHICLE]` (M,8) + `meta_info`.
 """
 import argparse
@@ -23,9 +24,9 @@ def load_record(rec):
     """LoadRecord (rangedet/core/input.py:14-42) for one roidb entry: the raw arrays the device transform needs."""
     if 'range_image' in rec:                                   # already loaded (synthetic records)
         return rec
-    with np.load(rec['pc_url']) as z:
-        return dict(range_image=z['range_image_return1'], pc_vehicle_frame=z['pc_vehicle_frame'],
-                    inclination=np.asarray(rec.get('inclination', z['inclination'] if 'inclination' in z else None)))
+    with np.load(rec['pc_url']) as z:                          # same keys and float32 casts as LoadRecord.apply (:29-36)
+        return dict(range_image=z['range_image'].astype(np.float32), pc_vehicle_frame=z['pc_vehicle_frame'].astype(np.float32),
+                    inclination=z['inclination'].astype(np.float32))
 
 
 def meta_info(rec, rid):

@@ -29,6 +29,7 @@ SIGNATURES = {
     "rd_last_error_string": (ctypes.c_char_p, []),
     "rd_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_copy_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p]),
     "rd_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rd_pack_conv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_deconv_phase_taps": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -13,8 +13,8 @@ numpy arrays instead of ``mx.nd.NDArray``.
         uint32  magic                  0xF993fac9 = V2, 0xF993faca = V3 (numpy shape semantics), 0xF993fac8 = V1;
                                        anything else = legacy format: the word is ndim, dims are uint32
         int32   storage type           V2/V3 only; 0 = dense (the only kind a checkpoint of this model holds)
-        uint32  ndim ; int64 dim[ndim] V1/V2/V3 shape (legacy: uint32 dims)
-        (an array with no elements ends here)
+        int32   ndim ; int64 dim[ndim] V1/V2/V3 shape (legacy: uint32 dims)
+        (a "none" array ends here: ndim 0 for V1/V2/legacy, ndim -1 for V3 whose ndim 0 is a scalar)
         int32 dev_type ; int32 dev_id  context it was saved from
         int32   type flag              0 f32, 1 f64, 2 f16, 3 u8, 4 i32, 5 i8, 6 i64
         raw little-endian data         prod(shape) * itemsize bytes
@@ -65,7 +65,11 @@ def _read_ndarray(r):
         stype = r.take("<i")
         if stype != 0:
             raise ParamsFormatError("sparse storage type %d is not supported (dense checkpoints only)" % stype)
-        ndim = r.take("<I")
+        ndim = r.take("<i")                                # int32: V3 (numpy shape semantics) stores -1 for "unknown"
+        if ndim < 0:
+            if magic == V3_MAGIC and ndim == -1:
+                return None                                # "none" array under numpy semantics: nothing else is stored
+            raise ParamsFormatError("negative ndim %d" % ndim)
         shape = tuple(r.take("<%dq" % ndim)) if ndim > 1 else ((r.take("<q"),) if ndim == 1 else ())
     elif magic == V1_MAGIC:
         ndim = r.take("<I")

@@ -87,7 +87,9 @@ def bn_affine(P, name, eps):
 
 
 class Executor:
-    def __init__(self, plan, params, lib=None, alloc=None, reuse_buffers=True):
+    def __init__(self, plan, params, lib=None, alloc=None, reuse_buffers=True, keep_sorted_idx=False):
+        """keep_sorted_idx: also keep get_sorted_foreground's (B,k) flat indices (parity tests read them with sorted_idx())."""
+        self.keep_sorted_idx = keep_sorted_idx
         self.plan = plan
         self.lib = lib or rdlib.get_lib()
         self.alloc = alloc or TorchAllocator()
@@ -180,6 +182,7 @@ class Executor:
             nb = L.raw("rd_sorted_foreground_workspace_bytes")(st["N"], st["k"]) * self.B
             b["ws"] = A.alloc(nb)
             b["ws_bytes"] = nb
+            b["idx"] = A.alloc(self.B * st["k"] * 4) if self.keep_sorted_idx else None
         return b
 
     # ---- execution ------------------------------------------------------------------------------------------------------
@@ -231,16 +234,18 @@ class Executor:
                        b["N"] * b["nout"], b["n_off"], B, x.H, x.W, x.C, b["nout"], dt, st_)
             elif k == "concat_in":
                 o = b["out"]
-                dst = A.view_f32(self._phys[o.buf], (B,) + tuple(o.shape))
+                row = b["N"] * b["last"] * 4                      # bytes of one frame's concatenated row
                 off = 0
                 for name, n in b["names"]:
                     src = din(name)
-                    A.assign(dst[:, off:off + n], src)
+                    assert tuple(src.shape)[:2] == (B, n), (name, tuple(src.shape))
+                    L.call("rd_copy_rows", A.ptr(src), n * b["last"] * 4, self.p(o), row, off * b["last"] * 4,
+                           n * b["last"] * 4, B, st_)
                     off += n
             elif k == "sorted_fg":
                 L.call("rd_sorted_foreground", self.p(b["score"]), self.p(b["delta"]), self.p(b["pc"]), self.p(b["mask"]),
                        B, b["N"], b["k"], b["D"], b["apply_sigmoid"], self.p(b["out_score"]), self.p(b["out_delta"]),
-                       self.p(b["out_pc"]), None, A.ptr(b["ws"]), b["ws_bytes"], st_)
+                       self.p(b["out_pc"]), A.ptr(b["idx"]) if b["idx"] is not None else None, A.ptr(b["ws"]), b["ws_bytes"], st_)
             elif k == "decode":
                 L.call("rd_decode3d_bbox", self.p(b["delta"]), self.p(b["pc"]), self.p(b["out"]), B, b["k"],
                        b["box_type"], b["is_bin"], st_)
@@ -267,6 +272,12 @@ class Executor:
         """numpy copy of a flat float32 plan tensor (B, *shape), e.g. the pre-sort logits/deltas (tests only)."""
         self.alloc.sync()
         return np.array(self.alloc.to_numpy(self.alloc.view_f32(self._phys[ref.buf], (self.B,) + tuple(ref.shape))))
+
+    def sorted_idx(self, which=0):
+        """(B,k) int32 flat indices chosen by the which-th get_sorted_foreground step (needs keep_sorted_idx=True)."""
+        b = [x for x in self._bound if x["kind"] == "sorted_fg"][which]
+        self.alloc.sync()
+        return np.array(self.alloc.to_numpy(self.alloc.view_i32(b["idx"], (self.B, b["k"]))))
 
     def debug_tensor(self, ref):
         """NCHW float32 numpy copy of an activation (tests only)."""

@@ -1,12 +1,10 @@
 """Synthetic inputs and weights for the RangeDet hot path (no dataset or checkpoint is available offline).
 
-``make_frame`` follows the *input contract* of the reference's test-time transform chain (numpy, host side):
-  LoadRecord / ProcessMissValue / SepAndClipData / GetUnnormalizedRange / NormData / GetCoordinates / CombineData /
-  PadData / TransposeData / GenerateFPNTarget / TransAndReshape      rangedet/core/input.py:14-42,89-229,522-624
-  constants                                                          config/rangedet/rangedet_veh_wo_aug_4_18e.py:245-282
-so that padded columns are exact zeros, masks are 0/1 floats and the tensors carry the names the graph consumes
-(config:400-404): input_data, coord_s1, pc_vehicle_frame_s{1,2,4}, range_image_mask_s{1,2,4}.
-``make_weights`` draws seeded parameters under the reference's MXNet names.
+``raw_record`` draws a record with the npz schema of datasets/create_range_image_roidb.py:119-124,164; ``make_batch`` runs
+such records through the device transform chain (rd_input_transform: LoadRecord ... TransAndReshape,
+rangedet/core/input.py:14-42,89-229,522-624, constants config/rangedet/rangedet_veh_wo_aug_4_18e.py:245-282) and returns the
+tensors under the names the graph consumes (config:400-404): input_data, coord_s1, pc_vehicle_frame_s{1,2,4},
+range_image_mask_s{1,2,4}.  ``make_weights`` draws seeded parameters under the reference's MXNet names.
 """
 import numpy as np
 
@@ -54,76 +52,16 @@ def raw_record(idx, H=64, W=2650):
     return dict(range_image=ri, pc_vehicle_frame=pc, inclination=incl, azimuth=az)
 
 
-def _fill_noise(data, miss, width):
-    shifted = data[:, list(range(1, width)) + [0], :]
-    data[miss, :] = shifted[miss, :]
-    return data
+def make_batch(idxs, W=2650, pad_W=2656, H=64, lib=None, alloc=None):
+    """Synthetic records `idxs` through the DEVICE transform chain (rd_input_transform): the named float32 device tensors
+    (with batch dim) the graph consumes.  Needs the GPU -- the numpy restatement of the chain is test infrastructure and lives
+    in oracle/input_ref.py."""
+    from .input_transform import DeviceInputTransform
+    return DeviceInputTransform(pad_hw=(H, pad_W), lib=lib, alloc=alloc)([raw_record(i, H, W) for i in idxs])
 
 
-def transform(rec, pad_hw=(64, 2656)):
-    """Test-mode transform chain -> the named float32 arrays one frame feeds to the graph (batch dim added)."""
-    ri = rec['range_image'].astype(np.float32).copy()
-    pc = rec['pc_vehicle_frame'].astype(np.float32).copy()
-    mask = ri[..., 0:1] > 0                                   # LoadRecord (input.py:40-42)
-    pc[~mask[..., 0]] = 0
-    H, W, _ = ri.shape
-    # ProcessMissValue (input.py:105-137)
-    rmask = (ri[..., 0] > 0)
-    miss = ri[:, :, 0] == -1
-    ri = _fill_noise(ri, miss, W)
-    pc = _fill_noise(pc, miss, W)
-    rmask = _fill_noise(rmask[:, :, None].copy(), miss, W).squeeze()
-    still = ri[:, :, 0] == -1
-    r0 = ri[:, :, 0]
-    dn = r0[[H - 2, H - 1] + list(range(H - 2)), :]
-    up = r0[list(range(2, H)) + [0, 1], :]
-    rt = r0[:, [W - 2, W - 1] + list(range(W - 2))]
-    lf = r0[:, list(range(2, W)) + [0, 1]]
-    car = still & ((dn != -1) | (up != -1) | (rt != -1) | (lf != -1))
-    ri[still, :] = np.array([80, 0, 0, -1], np.float32)
-    pc[still, :] = 0
-    ri[car, :] = np.array([0, 0, 0, -1], np.float32)
-    pc[car, :] = 0
-    rmask = rmask.astype(np.float32)[:, :, None]
-    # SepAndClipData / GetUnnormalizedRange / NormData / GetCoordinates / CombineData
-    f = {
-        'range_value': ri[:, :, 0].copy(), 'intensity': ri[:, :, 1].copy(), 'elongation': ri[:, :, 2].copy(),
-        'pc_vehicle_frame_x': pc[:, :, 0].copy(), 'pc_vehicle_frame_y': pc[:, :, 1].copy(),
-        'pc_vehicle_frame_z': pc[:, :, 2].copy(),
-        'inclination': np.tile(rec['inclination'].astype(np.float32)[:, None], (1, W)),
-    }
-    f['azimuth'] = np.arctan2(f['pc_vehicle_frame_y'], f['pc_vehicle_frame_x'])
-    for n, (lo, hi) in CLIP.items():
-        f[n] = np.clip(f[n], lo, hi)
-    unnorm = f['range_value'][:, :, None].copy()
-    for n, (mean, var) in NORM.items():
-        f[n] = (f[n] - mean) / (var ** 0.5)
-    coord = np.stack([f['pc_vehicle_frame_x'], f['pc_vehicle_frame_y'], f['pc_vehicle_frame_z']], 2)
-    data = np.stack([f[n] for n in COMBINE], 2)
-
-    def pad(a):                                                # PadData (input.py:539-544)
-        out = np.zeros((pad_hw[0], pad_hw[1], a.shape[-1]), np.float32)
-        out[:a.shape[0], :a.shape[1]] = a
-        return out
-
-    data, rmask, pcp, unnorm, coord = (pad(a).transpose(2, 0, 1) for a in (data, rmask, pc, unnorm, coord))
-    out = {'input_data': data[None], 'coord_s1': coord[None]}
-    for s in FPN_STRIDES:                                      # GenerateFPNTarget + TransAndReshape
-        lo, hi = INTERVAL[s]
-        m = ((lo <= unnorm) & (unnorm < hi)).astype(np.float32)
-        sl = slice(s // 2, None, s)
-        out['range_image_mask_s%d' % s] = (rmask * m)[:, :, sl].reshape(-1)[None].astype(np.float32)
-        out['pc_vehicle_frame_s%d' % s] = pcp[:, :, sl].reshape(3, -1).transpose(1, 0)[None].astype(np.float32).copy()
-    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
-
-
-def make_frame(idx, W=2650, pad_W=2656, H=64):
-    return transform(raw_record(idx, H, W), (H, pad_W))
-
-
-def make_batch(idxs, W=2650, pad_W=2656, H=64):
-    frames = [make_frame(i, W, pad_W, H) for i in idxs]
-    return {k: np.concatenate([f[k] for f in frames], 0) for k in frames[0]}
+def make_frame(idx, W=2650, pad_W=2656, H=64, lib=None, alloc=None):
+    return make_batch([idx], W, pad_W, H, lib, alloc)
 
 
 # ---- weights --------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ from conftest import BOTH, HIP_ONLY
 from emu_util import small_shapes
 from oracle import cpu_ops as O
 from oracle import graph_ref as G
+from oracle import input_ref as IR
 from rangedet_amd import lib as R
 from rangedet_amd import mx, synth
 from rangedet_amd.config import rangedet_veh_wo_aug_4_18e as cfgmod
@@ -109,7 +110,7 @@ def test_e2e_small_f32(be):
         sym = cfg[6].test_symbol
     plan = lower(sym, small_shapes(H, W), R.RD_F32, 1)
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
-    fr = synth.make_frame(0, W=Wr, pad_W=W, H=H)
+    fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
     ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
     outs = ex.forward(fr)
     ref = G.forward(fr, P, cfg=Cfg, num_fgs=k)
@@ -160,7 +161,7 @@ def test_e2e_nms3d_branch_f32(be):
     st = [s for s in plan.steps if s["kind"] == "nms3d"]
     assert len(st) == 1 and st[0]["N"] == k and st[0]["max_keep"] == mk and abs(st[0]["thr"] - thr) < 1e-7
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
-    fr = synth.make_frame(0, W=Wr, pad_W=W, H=H)
+    fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
     ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
     outs = ex.forward(fr)
     be.alloc.sync()
@@ -209,7 +210,7 @@ def test_e2e_kitti_two_class_f32(be):
     shapes['input_data'] = (cfgmod.KITTI_INPUT_CHANNELS, H, W)
     plan = lower(sym, shapes, R.RD_F32, 1)
     P = synth.make_weights(seed=5, width=W, in_ch=cfgmod.KITTI_INPUT_CHANNELS, cls_bias=-0.5, num_classes=2)
-    fr = synth.make_frame(1, W=W, pad_W=W, H=H)
+    fr = IR.make_frame(1, W=W, pad_W=W, H=H)
     fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])     # range, x, y, z, intensity
     ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
     outs = ex.forward(fr)
@@ -248,7 +249,7 @@ def test_full_size_bf16_properties(be):
     from rangedet_amd.pipeline import RangeDetPipeline
     P = synth.make_weights(seed=18)
     pipe = RangeDetPipeline(P, dtype=R.RD_BF16, wnms_cap=4096, batch=3, lib=be.lib, alloc=be.alloc)
-    fr = synth.make_batch([0, 1, 0])
+    fr = IR.make_batch([0, 1, 0])
     r1 = pipe.run(fr)
     sc1 = np.array(be.alloc.to_numpy(r1["fg_cls_score"]))
     bx1 = np.array(be.alloc.to_numpy(r1["decoded_bbox"]))
@@ -270,6 +271,120 @@ def test_full_size_bf16_properties(be):
         assert np.isfinite(d8).all() and np.all(d8[:, 3:6] > 0) and np.all(d8[:, 7] > 0.5)
 
 
+_FULL = {}
+
+
+def _full_size_oracle():
+    """graph_ref.forward on frames 0 and 1 at 64 x 2650 (pad 2656), all 50 000 candidates -- ~13 s per frame on the GPU box's
+    host cores; computed once per session and shared by the fp32 and bf16 full-size tests."""
+    if not _FULL:
+        P = synth.make_weights(seed=18)
+        fr = IR.make_batch([0, 1])
+        _FULL.update(P=P, fr=fr, ref=G.forward(fr, P, num_fgs=50000))
+    return _FULL["P"], _FULL["fr"], _FULL["ref"]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_full_size_f32_parity_vs_oracle(be):
+    """BASELINE configs 2 + 3 at the PRODUCTION shape -- rangedet_veh_wo_aug_4_18e, 64 x 2650 padded to 2656 (43 x 8 conv
+    tiles per frame, the W = 166 / 332 tails, the 2650 -> 2656 pad), batch 2, all 297 472 points, top-50 000 -- fp32 HIP path
+    against the graph oracle on identical inputs:
+      * logits and box regressions (deltas) of EVERY pixel within 1e-4 (north_star's fp32 bound);
+      * get_sorted_foreground picks the same flat indices wherever the oracle's neighbouring scores differ by > 1e-6;
+      * Decode3DBbox of the path's own sorted deltas within 1e-4 of the oracle's decode of those same deltas (device libm);
+      * end to end, boxes within 1e-4 + the propagated delta error (printed);
+      * weighted NMS of the path's own (score, box) rows: survivor indices equal, rows bit-equal, to the oracle (== reference)."""
+    from rangedet_amd.pipeline import RangeDetPipeline
+    P, fr, ref = _full_size_oracle()
+    B, k = 2, 50000
+    pipe = RangeDetPipeline(P, dtype=R.RD_F32, batch=B, wnms_cap=8192, lib=be.lib, alloc=be.alloc)
+    pipe.exe = Executor(pipe.plan, P, lib=be.lib, alloc=be.alloc, keep_sorted_idx=True)
+    res = pipe.run(fr)
+    ex = pipe.exe
+    sfg = [s for s in pipe.plan.steps if s["kind"] == "sorted_fg"][0]
+    logit, delta = ex.read_flat(sfg["score"]), ex.read_flat(sfg["delta"])
+    e_l, e_d = np.abs(logit - ref["logit"]).max(), np.abs(delta - ref["delta"]).max()
+    print("full size fp32: logit maxerr %.2e, delta maxerr %.2e" % (e_l, e_d))
+    assert logit.shape == (B, 297472) and e_l < 1e-4 and e_d < 1e-4
+    sc = np.array(be.alloc.to_numpy(res["fg_cls_score"]))
+    bx = np.array(be.alloc.to_numpy(res["decoded_bbox"]))
+    idx = ex.sorted_idx()
+    assert np.abs(sc - ref["fg_cls_score"]).max() < 1e-5 and np.all(np.diff(sc, axis=1) <= 0)
+    sdelta, spc = ex.read_flat(sfg["out_delta"]), ex.read_flat(sfg["out_pc"])
+    assert np.abs(bx - O.decode3d(sdelta, spc, False)).max() < 1e-4           # decode alone: device libm vs glibc
+    for b in range(B):
+        rs = ref["fg_cls_score"][b]
+        gap = np.abs(np.diff(rs))
+        ok = np.ones(k, bool)
+        ok[1:] &= gap > 1e-6
+        ok[:-1] &= gap > 1e-6
+        ok &= rs > 1e-6
+        assert ok.sum() > k // 2
+        assert np.array_equal(idx[b][ok], ref["sorted_idx"][b][ok])             # same points, same order
+        e_b = np.abs(bx[b][ok] - ref["decoded_bbox"][b][ok]).max()
+        # corners are centre +- exp(log l)/2 * cos/sin: d corner / d delta <= ~3 m for a car-sized box, so the bound is
+        # 1e-4 (libm) + 3 * (measured delta error)
+        print("frame %d: %d of %d rows with separated scores, box maxerr %.2e (delta err %.2e)" % (b, ok.sum(), k, e_b, e_d))
+        assert e_b < 1e-4 + 3.0 * e_d
+        got = res["frames"][b]
+        dets, rows, keep, d8 = G.postprocess(sc[b], bx[b])
+        assert got["num_candidates"] == dets.shape[0] and dets.shape[0] > 200
+        assert got["keep_inds"].tolist() == list(keep)                          # WNMS survivor indices bit-exact
+        assert np.abs(got["wnms_rows"] - rows).max() < 1e-5 and np.abs(got["det_xyzlwhyaws"] - d8).max() < 1e-4
+        # and against the oracle's own end-to-end result (inputs differ by the <=1e-4 box error): same survivors
+        dets_r, rows_r, keep_r, d8_r = G.postprocess(ref["fg_cls_score"][b], ref["decoded_bbox"][b])
+        print("frame %d: %d candidates, %d kept (oracle end to end: %d, %d)" % (b, dets.shape[0], len(keep), dets_r.shape[0], len(keep_r)))
+        assert dets.shape[0] == dets_r.shape[0] and list(keep) == list(keep_r)
+        assert np.abs(got["det_xyzlwhyaws"] - d8_r).max() < 2e-3
+
+
+# bf16 error model for the tolerance below: every conv layer rounds its output activation to bf16 (relative 2^-9, uniform ->
+# rms 2^-9/sqrt(3)) and uses weights rounded the same way; errors of independent layers add in quadrature, so along the
+# deepest path of the graph (res1 4 + res2a 6 + res2 6 + res3a 10 + res3 10 + agg2 5 + agg2a 3 + agg3 5 + tower 4 = 53
+# conv layers) the relative rms error of a pre-output activation is ~ 2^-9 * sqrt(2 * 53 / 3) = 1.2 %.  The 1x1 output conv
+# is exact in fp32 on those activations, so logits / deltas inherit that fraction of the SPREAD of their value; residual adds
+# re-inject un-rounded signal (lower), ReLU clipping correlates errors (higher): the test allows 2.5x the model for the rms
+# and 6 rms (Gaussian tail over 6e5 samples, x safety) for the maximum.
+BF16_REL_RMS = 2.0 ** -9 * np.sqrt(2 * 53 / 3.0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_full_size_bf16_vs_f32_oracle(be):
+    """The throughput mode (bf16 persistent kernels, fused Meta-Kernel, fused tower outputs) at the production shape against
+    the SAME fp32 oracle output, with a tolerance derived from bf16 rounding depth (see BF16_REL_RMS) instead of a smoke
+    threshold: rms and max error of logits / deltas relative to their spread, and the agreement of the final detections."""
+    from rangedet_amd.pipeline import RangeDetPipeline
+    P, fr, ref = _full_size_oracle()
+    pipe = RangeDetPipeline(P, dtype=R.RD_BF16, batch=2, wnms_cap=8192, lib=be.lib, alloc=be.alloc)
+    res = pipe.run(fr)
+    sfg = [s for s in pipe.plan.steps if s["kind"] == "sorted_fg"][0]
+    logit, delta = pipe.exe.read_flat(sfg["score"]), pipe.exe.read_flat(sfg["delta"])
+    for name, got, want in (("logit", logit, ref["logit"]), ("delta", delta, ref["delta"])):
+        err = got - want
+        axes = (0, 1) if want.ndim == 3 else None
+        spread = want.std(axis=axes)                  # per regression channel for the deltas
+        rms = np.sqrt((err ** 2).mean(axis=axes)) / spread
+        mx = np.abs(err).max(axis=axes) / spread
+        print("full size bf16 vs fp32 oracle, %s: rms/std %s  max/std %s  (model rms %.4f)" %
+              (name, np.round(rms, 4), np.round(mx, 4), BF16_REL_RMS))
+        assert np.all(rms < 2.5 * BF16_REL_RMS) and np.all(mx < 6 * 2.5 * BF16_REL_RMS)
+    sc = np.array(be.alloc.to_numpy(res["fg_cls_score"]))
+    assert np.abs(sc - ref["fg_cls_score"]).max() < 6 * 2.5 * BF16_REL_RMS * ref["logit"].std() * 0.25   # sigmoid' <= 1/4
+    for b in range(2):
+        dets_r, rows_r, keep_r, d8_r = G.postprocess(ref["fg_cls_score"][b], ref["decoded_bbox"][b])
+        got = res["frames"][b]
+        # detections: the bf16 path finds the same objects -- every oracle detection has a bf16 detection whose centre is
+        # within 0.3 m (and vice versa for all but the few boxes that sit on the score threshold)
+        d8 = got["det_xyzlwhyaws"]
+        dist = np.linalg.norm(d8[:, None, :2] - d8_r[None, :, :2], axis=2)
+        print("frame %d: bf16 %d detections, oracle %d; unmatched oracle %d, unmatched bf16 %d" %
+              (b, len(d8), len(d8_r), int((dist.min(0) > 0.3).sum()), int((dist.min(1) > 0.3).sum())))
+        assert abs(len(d8) - len(d8_r)) <= max(3, len(d8_r) // 20)
+        assert (dist.min(0) > 0.3).mean() < 0.05 and (dist.min(1) > 0.3).mean() < 0.05
+
+
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_interleaved_pipelines_match_single(be):
     """Two batches in flight on two launch streams (pipeline.InterleavedPipelines, what bench.py runs) give, batch by batch,
@@ -278,7 +393,7 @@ def test_interleaved_pipelines_match_single(be):
     H, Wr, W, k = 16, 250, 256, 2000
     P = synth.make_weights(seed=18, width=W, cls_bias=-1.0)
     kw = dict(dtype=R.RD_BF16, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n=k, wnms_cap=2048, batch=2)
-    batches = [synth.make_batch([2 * i, 2 * i + 1], W=Wr, pad_W=W, H=H) for i in range(4)]
+    batches = [IR.make_batch([2 * i, 2 * i + 1], W=Wr, pad_W=W, H=H) for i in range(4)]
     single = RangeDetPipeline(P, lib=be.lib, alloc=be.alloc, **kw)
     want = [single.run(b_)["frames"] for b_ in batches]
     multi = InterleavedPipelines(P, n=2, lib=be.lib, alloc=be.alloc, **kw)
@@ -308,7 +423,7 @@ def test_kitti_full_size_bf16_properties(be):
     shapes = small_shapes(H, W)
     shapes['input_data'] = (cfgmod.KITTI_INPUT_CHANNELS, H, W)
     P = synth.make_weights(seed=5, width=W, in_ch=cfgmod.KITTI_INPUT_CHANNELS, num_classes=2)
-    fr = synth.make_frame(2, W=W, pad_W=W, H=H)
+    fr = IR.make_frame(2, W=W, pad_W=W, H=H)
     fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])
     logits = {}
     for dt in (R.RD_BF16, R.RD_F32):
@@ -338,7 +453,7 @@ def test_pipeline_postprocess_matches_oracle(be):
     from rangedet_amd.pipeline import RangeDetPipeline
     H, Wr, W, k = 16, 250, 256, 2000
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.8)
-    fr = synth.make_frame(1, W=Wr, pad_W=W, H=H)
+    fr = IR.make_frame(1, W=Wr, pad_W=W, H=H)
     pipe = RangeDetPipeline(P, dtype=R.RD_F32, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n=k, wnms_cap=2048)
     res = pipe.run(fr)
     sc, bx = res["fg_cls_score"].cpu().numpy()[0], res["decoded_bbox"].cpu().numpy()[0]
@@ -356,7 +471,7 @@ def test_pipeline_nms3d_branch_matches_harness(be):
     from rangedet_amd.pipeline import RangeDetPipeline
     H, Wr, W, k = 16, 250, 256, 2000
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.8)
-    frs = [synth.make_frame(i, W=Wr, pad_W=W, H=H) for i in (1, 2)]
+    frs = [IR.make_frame(i, W=Wr, pad_W=W, H=H) for i in (1, 2)]
     fr = {n: np.concatenate([f[n] for f in frs]) for n in frs[0] if isinstance(frs[0][n], np.ndarray)}
     pipe = RangeDetPipeline(P, dtype=R.RD_F32, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n=k, batch=2, wnms=False)
     assert any(s["kind"] == "nms3d" for s in pipe.plan.steps)
@@ -389,14 +504,22 @@ def test_evaluate_loop_and_export(be, tmp_path):
     H, W, Wp = 16, 250, 256
     P = synth.make_weights(seed=18, width=Wp, cls_bias=-0.8)
     roidb = [dict(synth.raw_record(i, H=H, W=W), rec_id=i) for i in range(3)]
+    # record 1 goes through the pc_url path: an npz with the schema datasets/create_range_image_roidb.py writes
+    seg = tmp_path / "segment-123_with_camera_labels"
+    seg.mkdir()
+    r1 = roidb[1]
+    np.savez(seg / "1550083467346370.npz", range_image=r1['range_image'].astype(np.float64), pc_vehicle_frame=r1['pc_vehicle_frame'],
+             inclination=r1['inclination'], azimuth=r1['azimuth'])
+    roidb[1] = dict(pc_url=str(seg / "1550083467346370.npz"), rec_id=1, gt_bbox_imu=np.zeros((0, 8), np.float32))
     ann, out = evaluate.run(roidb, P, batch=2, pre_nms_top_n=2000)
     assert sorted(out) == [0, 1, 2] and set(ann) == set(out)
     pipe = RangeDetPipeline(P, feat_size=(H, W), pad_field=(H, Wp), batch=1, pre_nms_top_n=2000)
     for i in range(3):
-        ref = pipe.run(synth.make_frame(i, W=W, pad_W=Wp, H=H))["det_xyzlwhyaws"]
+        ref = pipe.run(IR.make_frame(i, W=W, pad_W=Wp, H=H))["det_xyzlwhyaws"]
         got = out[i]['det_xyzlwhyaws']['TYPE_VEHICLE']
         assert got.shape == ref.shape and got.shape[0] > 0 and np.abs(got - ref).max() < 1e-3   # bf16 graph both ways
-        assert out[i]['meta_info'] == {'name': 'synthetic', 'timestamp_micros': i}
+        assert out[i]['meta_info'] == ({'name': 'synthetic', 'timestamp_micros': i} if i != 1 else
+                                       {'name': '123', 'timestamp_micros': 1550083467346370})
     pk = tmp_path / "checkpoint_output_dict_18e.pkl"
     with open(pk, "wb") as f:
         import pickle
@@ -415,7 +538,7 @@ def test_e2e_bf16_tolerance(be):
     cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
     plan = lower(cfg[6].test_symbol, small_shapes(H, W), R.RD_BF16, 1)
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
-    fr = synth.make_frame(0, W=Wr, pad_W=W, H=H)
+    fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
     ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
     ex.forward(fr)
     ref = G.forward(fr, P, num_fgs=k)

@@ -12,6 +12,7 @@ from conftest import BOTH, HIP_ONLY
 from emu_util import bf16_round, empty_nhwc, from_nhwc, to_nhwc, bf16_bits_to_f32
 from oracle import cpu_ops as O
 from oracle import graph_ref as G
+from oracle import input_ref as IR
 from rangedet_amd import lib as R
 from rangedet_amd import synth
 from rangedet_amd.runtime import bn_affine
@@ -485,7 +486,7 @@ def test_score_filter_and_12to8(be):
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_input_transform(be):
-    """rd_input_transform against the numpy restatement of the reference's transform chain (synth.transform; parity
+    """rd_input_transform against the numpy restatement of the reference's transform chain (oracle/input_ref.transform; parity
     unpinned: the reference chain needs mxnet/numba to import).  Everything is selection / copy / one IEEE subtract and
     divide, hence bit-exact, except the azimuth channel (atan2f)."""
     from rangedet_amd.input_transform import make_norm
@@ -512,7 +513,7 @@ def test_input_transform(be):
     norm = make_norm()
     L.call("rd_input_transform", be.ptr(ri), be.ptr(pc), be.ptr(inc), ctypes.addressof(norm), B, H, W, Hp, Wp,
            *[be.ptr(bufs[k]) for k in names], be.stream)
-    ref = [synth.transform(r, (Hp, Wp)) for r in recs]
+    ref = [IR.transform(r, (Hp, Wp)) for r in recs]
     assert any((r['range_image'][..., 0] == -1).any() for r in recs)
     for k in names:
         got = be.down(bufs[k], np.float32, shapes[k])

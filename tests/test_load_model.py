@@ -52,6 +52,25 @@ def test_hand_assembled_bytes_and_dtypes(tmp_path):
     assert isinstance(out, list) and np.array_equal(out[0], w) and np.array_equal(out[1], i64)
 
 
+def test_v3_numpy_shape_records(tmp_path):
+    """V3 records (MXNet built with numpy shape semantics): ndim is a signed int32; -1 = unknown shape = a "none" array,
+    ndim 0 = a scalar that carries one element."""
+    sc = np.array(2.5, np.float32)
+    v = np.arange(6, dtype=np.float32).reshape(2, 3)
+    b = struct.pack("<QQQ", 0x112, 0, 3)
+    b += struct.pack("<Ii", 0xF993FACA, 0) + struct.pack("<i", 0) + struct.pack("<iii", 1, 0, 0) + sc.tobytes()
+    b += struct.pack("<Ii", 0xF993FACA, 0) + struct.pack("<i", -1)
+    b += struct.pack("<Ii", 0xF993FACA, 0) + struct.pack("<i2q", 2, 2, 3) + struct.pack("<iii", 1, 0, 0) + v.tobytes()
+    b += struct.pack("<Q", 0)
+    f = tmp_path / "v3.params"
+    f.write_bytes(b)
+    out = LM.load(str(f))
+    assert out[0].shape == () and out[0] == np.float32(2.5) and out[1] is None and np.array_equal(out[2], v)
+    f.write_bytes(struct.pack("<QQQ", 0x112, 0, 1) + struct.pack("<Ii", 0xF993FAC9, 0) + struct.pack("<i", -1))
+    with pytest.raises(LM.ParamsFormatError, match="negative ndim"):
+        LM.load(str(f))
+
+
 def test_errors(tmp_path):
     f = tmp_path / "bad.params"
     f.write_bytes(struct.pack("<QQQ", 0x113, 0, 0))
@@ -68,3 +87,18 @@ def test_errors(tmp_path):
         LM.load(str(f))
     with pytest.raises(AssertionError):
         LM.get_latest_ckpt_epoch(str(tmp_path / "nothing"))
+
+
+def test_evaluate_load_record_reads_the_reference_npz_schema(tmp_path):
+    """rangedet_amd.evaluate.load_record == LoadRecord.apply (rangedet/core/input.py:23-38): the npz written by
+    datasets/create_range_image_roidb.py:119-124,164 holds 'range_image' / 'pc_vehicle_frame' / 'inclination' / 'azimuth';
+    arrays come back as float32."""
+    from rangedet_amd import evaluate
+    rec = synth.raw_record(3, H=8, W=40)
+    f = tmp_path / "1550083467346370.npz"
+    np.savez(f, range_image=rec['range_image'].astype(np.float64), pc_vehicle_frame=rec['pc_vehicle_frame'].astype(np.float64),
+             inclination=rec['inclination'], azimuth=rec['azimuth'], range_image_mask=np.ones((8, 40)))
+    got = evaluate.load_record(dict(pc_url=str(f)))
+    assert got['range_image'].dtype == np.float32 and got['pc_vehicle_frame'].dtype == np.float32
+    assert np.array_equal(got['range_image'], rec['range_image']) and np.array_equal(got['inclination'], rec['inclination'])
+    assert evaluate.load_record(rec) is rec

@@ -6,7 +6,7 @@ from rangedet_amd import lib as rdlib, synth
 from rangedet_amd.pipeline import RangeDetPipeline
 P = synth.make_weights(seed=18)
 pipe = RangeDetPipeline(P, dtype=rdlib.RD_BF16, wnms_cap=4096, batch=8)
-fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(8))).items()}
+fr = synth.make_batch(list(range(8)))
 for _ in range(3): pipe.enqueue(fr)
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -14,7 +14,7 @@ dt = rdlib.RD_F32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else rdlib.RD_BF
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=dt, batch=B)
-fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(B))).items()}
+fr = synth.make_batch(list(range(B)))
 pipe.enqueue(fr)
 torch.cuda.synchronize()
 ex = pipe.exe

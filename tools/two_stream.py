@@ -15,7 +15,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 P = synth.make_weights(seed=18)
 pipes = [RangeDetPipeline(P, dtype=rdlib.RD_BF16, wnms_cap=4096, batch=8) for _ in range(3)]
 streams = [torch.cuda.Stream() for _ in range(3)]
-fr = [{k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(8 * i, 8 * i + 8))).items()} for i in range(2)]
+fr = [synth.make_batch(list(range(8 * i, 8 * i + 8))) for i in range(2)]
 
 
 def run(nstreams, n):

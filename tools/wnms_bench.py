@@ -11,7 +11,7 @@ from rangedet_amd import lib as rdlib, synth  # noqa: E402
 from rangedet_amd.pipeline import RangeDetPipeline  # noqa: E402
 
 pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=rdlib.RD_BF16, wnms_cap=4096, batch=8)
-fr = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(list(range(8))).items()}
+fr = synth.make_batch(list(range(8)))
 pipe.enqueue(fr)
 torch.cuda.synchronize()
 res = [p.collect() for p in pipe.post]
