@@ -7,6 +7,7 @@
  *                             rangedet/symbol/backbone/meta_kernel.py:166-240, dla_backbone.py:92-97
  *   rd_conv2d_bn_act          mx.sym.Convolution + BatchNorm (+ReLU, +residual)   mxnext/simple.py:123-158,
  *                             mxnext/complicate.py:26-45, dla_backbone.py:18-56, head/builder.py:221-240
+ *   rd_conv3x3_bn_act_ex      BasicBlock conv2 (+ stride (1,2), + projection shortcut)   dla_backbone.py:18-56,139-143
  *   rd_deconv2d_bn_act        mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
  *                             dla_backbone.py:117-127
  *   rd_head_out               1x1 logit / delta convs + cast + per-class flatten  head/builder.py:242-261,99-154
@@ -100,6 +101,24 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
                      const float* shift, const void* residual, int r_cstride, int r_coff, void* y,
                      int y_cstride, int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw,
                      int stride_w, int flags, int dtype, void* stream);
+/* Second conv of a BasicBlock in its extended forms (dla_backbone.py:18-56; bf16, persistent kernel):
+ *   stride_w 2  (`conv2` of the first unit of a down-sampling stage, dla_backbone.py:139-143): computed on the pixel-pair view
+ *               of x -- [H][Win][cs] with Win even read as [H][Win/2][2*cs] -- as a stride-1 conv with six taps, so only the
+ *               stored pixels are computed; weights packed by rd_pack_conv3x3_ex_host(stride_w = 2, x_cstride);
+ *   sc_x != NULL  the block's projection shortcut  BN(Convolution 1x1 (stride_w) of the block input)  (dla_backbone.py:44-51)
+ *               is accumulated onto the conv's accumulators in the epilogue (no shortcut tensor, no second launch).  The two
+ *               BatchNorm scales must be FOLDED into the two weight sets (fold_scale of the packers), `scale` = NULL and
+ *               `shift` = shift_conv + shift_shortcut; RD_ADD is implied, `residual` must be NULL.
+ * Otherwise the contract of rd_conv2d_bn_act (3x3, pad 1).  sc_x: [B][H][Win][sc_cstride], channels [sc_coff, sc_coff+sc_cin). */
+size_t rd_conv3x3_ex_packed_bytes(int cin, int cout, int stride_w, int x_cstride);
+int rd_pack_conv3x3_ex_host(const float* w_oihw_host, const float* fold_scale_host, int cout, int cin, int stride_w,
+                            int x_cstride, void* packed_host);
+size_t rd_conv1x1_sc_packed_bytes(int cin, int cout);
+int rd_pack_conv1x1_sc_host(const float* w_oi_host, const float* fold_scale_host, int cout, int cin, void* packed_host);
+int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale, const float* shift,
+                         const void* residual, int r_cstride, int r_coff, const void* sc_x, int sc_cstride, int sc_coff,
+                         int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
+                         int cout, int stride_w, int flags, void* stream);
 /* Last conv of a head tower (3x3, cout 128, BN + ReLU, bf16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
  * rpn_{cls,reg}_conv_3 + BN + ReLU, then rpn_cls_logit / rpn_reg_delta with bias): the 128-channel result is consumed in
  * the epilogue and never written.  out[b*out_batch_stride + (n_off + h*W + w)*nout + o], float32, like rd_head_out; nout <= 8.

@@ -37,6 +37,12 @@ struct Conv3Args {
   const unsigned char* hw;   // packed head weights: [hi | lo][ks 0..7][64 lanes][8 bf16] = 16 KB (pack_head_frag)
   const float* hb;           // [hn] bias
   float* ho; long ho_bs, ho_off; int hn;   // out[b*ho_bs + (ho_off + h*W + w)*hn + o]
+  // SC variant: the block's 1x1 projection shortcut (dla_backbone.py:44-51) is accumulated onto the tile in the epilogue:
+  // acc[px][co] += sum_ci scw[co][ci] * sx[px][ci] (same output pixel grid), so neither the shortcut tensor nor a second
+  // launch exists.  BN scales are folded into both weight sets by the packer (one affine for the sum: shift only).
+  const bf16_t* sx; int s_cs, s_co; long s_bs;
+  const unsigned char* scw;  // packed [ks][Cout/32][64 lanes][8 bf16] (pack_sc_frag)
+  int s_nks;                 // 16-channel k-steps of the shortcut input (<= 8)
 };
 
 // Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
@@ -90,6 +96,23 @@ inline void pack_head_frag(const float* w, int nout, int cin, void* out) {
         }
 }
 
+// packed 1x1 projection-shortcut weights of the SC variant: [ks][Cout/32][64 lanes][8 bf16], lane (mm, hi) of fragment
+// (ks, cb) holds scale[co] * w[co = 32*cb + conv_row_perm(mm)][ci = 16*ks + 8*hi + j]  (w: (cout, cin) row-major).
+inline size_t sc_frag_bytes(int cin, int cout) { return (size_t)((cin + 15) / 16) * (cout / 32) * 1024; }
+inline void pack_sc_frag(const float* w, const float* scale, int cin, int cout, void* out) {
+  bf16_t* o = (bf16_t*)out;
+  const int nks = (cin + 15) / 16;
+  for (int ks = 0; ks < nks; ++ks)
+    for (int cb = 0; cb < cout / 32; ++cb)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = cb * 32 + conv_row_perm(lane & 31);
+        for (int j = 0; j < 8; ++j) {
+          const int ci = ks * 16 + (lane >> 5) * 8 + j;
+          *o++ = f32_to_bf16(ci < cin ? (scale ? scale[co] : 1.f) * w[(size_t)co * cin + ci] : 0.f);
+        }
+      }
+}
+
 // Tap sets.  TS = 0: all nine taps (convs).  A transposed-conv phase only has taps in two of the three columns:
 // TS = 1 -> dw in {-1, 0}, TS = 2 -> dw in {0, +1}; its unit is 6 steps instead of 9 (no MFMAs on zero weights).
 constexpr int c3_nsteps(int TS) { return TS == 0 ? 9 : 6; }
@@ -119,9 +142,10 @@ constexpr int c3_younger(int R, int IPW, int s, int NS) {
 // That conv is applied to each 32-pixel fragment while it sits, already rounded to bf16, in the epilogue's transpose
 // scratch (same LDS image and MFMA scheme as head_out_mfma_kernel, k_misc.h: weights as a bf16 hi + lo pair), and the
 // 128-channel result is never written to HBM.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false>
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false>
 __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   static_assert(!HEAD || (NCT == 4 && TS == 0), "fused output conv: cout 128, all nine taps");
+  static_assert(!(HEAD && SC), "a head tower has no shortcut");
   using Cfg = C3Cfg<NCT>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int NR = 4 + NCT;                    // fragment reads per k-step
@@ -356,6 +380,44 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
     const bf16_t* __restrict__ rrow0 = a.res + (size_t)b * a.r_bs + (size_t)oh0 * a.Wo * a.r_cs + a.r_co;
     const int sh = a.sw - 1;   // stride 2: shift by 1, keep even columns
+    if constexpr (SC) {
+      // projection shortcut: B operand = this wave's pixels of the block input straight from global memory (lane (m, hi)
+      // of k-step ks: channels 16*ks + 8*hi .. +8 of its pixel, one 16-byte load), A operand = the packed weight fragment
+      // (1 KB coalesced, L2 resident), accumulated onto the conv's own accumulators.  Dead pixels read pixel (0, 0).
+      // Two pixel fragments (one output row of the wave) at a time: 2 x MK x 4 registers of pixels in flight.
+      const bf16_t* __restrict__ sb = a.sx + (size_t)b * a.s_bs + a.s_co + 8 * ehi;
+      const unsigned char* __restrict__ wq = a.scw + el * 16;
+      auto shortcut = [&](auto MKc) {
+        constexpr int MK = decltype(MKc)::value;            // k-steps held in registers (>= a.s_nks)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+          s16x8 sxq[2][MK];
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int tc = 32 * i2 + em, ow = ct * C3_TW + tc, oh = oh0 + ih;
+            const bool live = tc < C3_TW && ow < a.W && oh < a.H;
+            const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.s_cs : 0);
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks)
+              if (ks < a.s_nks) sxq[i2][ks] = *(const s16x8*)(sp + 16 * ks);
+          }
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks)
+            if (ks < a.s_nks) {
+#pragma unroll
+              for (int j = 0; j < NCT; ++j) {
+                const s16x8 wf = *(const s16x8*)(wq + (size_t)(ks * NCT + j) * 1024);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+                  acc[2 * ih + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, sxq[i2][ks], acc[2 * ih + i2][j], 0, 0, 0);
+              }
+            }
+          C3_FENCE();
+        }
+      };
+      shortcut(std::integral_constant<int, 8>{});
+      C3_FENCE();
+    }
     // FL >= 0: the flag combination is a compile-time constant (no per-value selects); FL < 0: read a.flags
     auto epilogue = [&](auto FL) {
       constexpr int F = decltype(FL)::value;
@@ -528,6 +590,8 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   Conv3Args a;
   memset(&a, 0, sizeof(a));
   if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
+  const bool sc = head && head->sx;
+  if (sc) { a.sx = head->sx; a.s_cs = head->s_cs; a.s_co = head->s_co; a.s_bs = head->s_bs; a.scw = head->scw; a.s_nks = head->s_nks; }
   a.sw = sw; a.Wo = (W - 1) / sw + 1;
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
   a.w = (const unsigned char*)w; a.scale = scale; a.shift = shift;
@@ -546,6 +610,14 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
 #endif
+  if (sc) {
+    RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
+#define C3_LAUNCH_SC(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
+    if (cout == 128) { if (ts == 0) C3_LAUNCH_SC(4, 0); else C3_LAUNCH_SC(4, 1); }
+    else { if (ts == 0) C3_LAUNCH_SC(2, 0); else C3_LAUNCH_SC(2, 1); }
+#undef C3_LAUNCH_SC
+    return check_launch("conv3x3_stream_kernel<sc>");
+  }
   if (head) {
     hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
     return check_launch("conv3x3_stream_kernel<head>");

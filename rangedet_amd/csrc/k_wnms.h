@@ -739,6 +739,7 @@ struct TieSort {
     sync();
   }
 };
+constexpr int TIE_STACK_BYTES = 3 * 40 * 4;
 constexpr int TIE_LDS_K = 16384;   // keys + indices + range bitmap in LDS up to this K (130 KB); beyond it: global scratch
 __global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restrict__ dets, int cap,
                                                             const int* __restrict__ d_count, int* __restrict__ order,
@@ -754,12 +755,13 @@ __global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restr
     if (i + 1 < K && !(dets[(size_t)i * 12 + 11] > dets[(size_t)(i + 1) * 12 + 11])) unsorted = 1;
   }
   if (!__ballot(unsorted)) return;
-  __shared__ int stack[3 * 40];
+  int* stack = (int*)smem;                       // [3 * 40] introsort range stack, then (LDS variant) keys / indices / bitmap
+  unsigned char* lds = smem + TIE_STACK_BYTES;
   TieSort T;
   T.n = K; T.lane = lane;
   const int nbit = (K + 31) >> 5;
   if (cap <= TIE_LDS_K) {
-    T.sc = (float*)smem; T.ix = (int*)(smem + (size_t)cap * 4); T.segbit = (unsigned*)(smem + (size_t)cap * 8); T.fence = false;
+    T.sc = (float*)lds; T.ix = (int*)(lds + (size_t)cap * 4); T.segbit = (unsigned*)(lds + (size_t)cap * 8); T.fence = false;
   } else {
     T.sc = (float*)scratch; T.ix = scratch + cap; T.segbit = (unsigned*)(scratch + 2 * (size_t)cap); T.fence = true;
   }

@@ -44,7 +44,10 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
 }
 template <class K>
 inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // (a kernel with static LDS cannot take the full 160 KB as dynamic: the attribute call then fails, the launch with the
+  // size actually requested still works -- do not leave that status behind for the next check_launch)
+  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    (void)hipGetLastError();
 }
 inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4>);
@@ -54,6 +57,10 @@ inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<2, 0, 1>);
   allow_big_lds(conv3x3_stream_kernel<2, 0, 2>);
   allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
@@ -219,6 +226,73 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
   return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
                      y_coff, B, H, Win, Wout, Wout, cin, cout, stride_w, 1, 0, flags, dtype, (hipStream_t)stream);
 }
+// ---- 3x3 conv of a BasicBlock, extended forms (bf16, persistent kernel) -----------------------------------------------------
+// stride (1,2) on the pixel-pair view: x [H][W][cs] with W even IS [H][W/2][2*cs] -- channels [0, cs) of view pixel w2 are
+// pixel 2*w2, channels [cs, 2cs) pixel 2*w2+1 -- and  out[w2] = sum_dh ( W[dh,-1].odd[w2-1] + W[dh,0].even[w2] + W[dh,+1].odd[w2] )
+// is a stride-1 conv over the view with the six taps dw2 in {-1, 0} (tap set 1): two thirds of the multiply-adds of the
+// stride-1-then-drop form and only the stored pixels are computed.
+static int ex_view_cin(int cin, int x_cstride, int stride_w) { return stride_w == 2 ? x_cstride + cin : cin; }
+size_t rd_conv3x3_ex_packed_bytes(int cin, int cout, int stride_w, int x_cstride) {
+  return conv_packed_bytes(stride_w == 2 ? 6 : 9, ex_view_cin(cin, x_cstride, stride_w), cout, RD_BF16);
+}
+int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, int cin, int stride_w, int x_cstride, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv3x3_ex: null pointer");
+  RD_REQUIRE(stride_w == 1 || stride_w == 2, RD_ESHAPE, "pack_conv3x3_ex: stride_w %d", stride_w);
+  RD_REQUIRE(cout == 64 || cout == 128, RD_ESHAPE, "pack_conv3x3_ex: cout %d", cout);
+  RD_REQUIRE(stride_w == 1 || (x_cstride >= cin && x_cstride % 8 == 0), RD_ESHAPE, "pack_conv3x3_ex: x_cstride %d for cin %d", x_cstride, cin);
+  auto wv = [&](int co, int ci, int dh, int dw) {
+    return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)co * cin + ci) * 3 + (dh + 1)) * 3 + (dw + 1)];
+  };
+  if (stride_w == 1) {
+    pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); });
+  } else {
+    pack_taps_frag(6, x_cstride + cin, cout, out, [&](int co, int c2, int s) -> float {
+      const int dh = s / 2 - 1, dw2 = s % 2 - 1;
+      if (c2 < cin) return dw2 == 0 ? wv(co, c2, dh, 0) : 0.f;                               // even pixel
+      if (c2 >= x_cstride && c2 - x_cstride < cin) return wv(co, c2 - x_cstride, dh, dw2 == -1 ? -1 : 1);   // odd pixel
+      return 0.f;
+    });
+  }
+  return RD_OK;
+}
+size_t rd_conv1x1_sc_packed_bytes(int cin, int cout) { return sc_frag_bytes(cin, cout); }
+int rd_pack_conv1x1_sc_host(const float* w, const float* fold_scale, int cout, int cin, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv1x1_sc: null pointer");
+  RD_REQUIRE((cout == 64 || cout == 128) && cin >= 1 && cin <= 128, RD_ESHAPE, "pack_conv1x1_sc: cout %d, cin %d (1..128)", cout, cin);
+  pack_sc_frag(w, fold_scale, cin, cout, out);
+  return RD_OK;
+}
+int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale, const float* shift,
+                         const void* residual, int r_cstride, int r_coff, const void* sc_x, int sc_cstride, int sc_coff,
+                         int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
+                         int cout, int stride_w, int flags, void* stream) {
+  RD_REQUIRE(x && w_packed && y, RD_EINVAL, "conv3x3_ex: null pointer");
+  RD_REQUIRE(B > 0 && H > 0 && Win > 0 && cin > 0 && (cout == 64 || cout == 128), RD_ESHAPE, "conv3x3_ex: shape / cout %d", cout);
+  RD_REQUIRE(stride_w == 1 || (stride_w == 2 && Win % 2 == 0), RD_ESHAPE, "conv3x3_ex: stride_w %d with Win %d (stride 2 needs an even width)", stride_w, Win);
+  RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "conv3x3_ex: y channels exceed stride");
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "conv3x3_ex: x channel stride/offset");
+  RD_REQUIRE(!(sc_x && residual) && !(sc_x && !sc_w_packed), RD_EINVAL, "conv3x3_ex: shortcut conv and residual are exclusive");
+  RD_REQUIRE(!((flags & RD_ADD) && !residual && !sc_x), RD_EINVAL, "conv3x3_ex: RD_ADD without residual / shortcut");
+  RD_REQUIRE(getenv("RD_CONV_V1") == nullptr, RD_EINVAL, "conv3x3_ex: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
+  allow_conv_lds();
+  const int v = stride_w;                      // pixels per view pixel
+  const int Wv = Win / v;
+  Conv3Args e;
+  memset(&e, 0, sizeof(e));
+  int fl = flags;
+  if (sc_x) {
+    RD_REQUIRE(sc_cin >= 1 && sc_cin <= 128 && sc_cstride % 8 == 0 && sc_coff % 8 == 0 && sc_coff + ((sc_cin + 15) / 16) * 16 <= sc_cstride,
+               RD_ESHAPE, "conv3x3_ex: shortcut input channels %d (stride %d, offset %d)", sc_cin, sc_cstride, sc_coff);
+    // the shortcut reads the block input at the OUTPUT pixel grid: stride 2 = the even pixel of each pair of the view
+    e.sx = (const bf16_t*)sc_x; e.s_cs = sc_cstride * v; e.s_co = sc_coff; e.s_bs = (long)H * Wv * sc_cstride * v;
+    e.scw = (const unsigned char*)sc_w_packed; e.s_nks = (sc_cin + 15) / 16;
+    fl &= ~RD_ADD;                             // the add happens on the accumulators
+  }
+  return launch_conv3(x, x_cstride * v, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride, y_coff, B, H,
+                      Wv, ex_view_cin(cin, x_cstride, stride_w), cout, fl, 1, (hipStream_t)stream, stride_w == 2 ? 1 : 0,
+                      sc_x ? &e : nullptr);
+}
+
 // ---- last tower conv + the tower's 1x1 output conv in one launch (bf16) ---------------------------------------------
 size_t rd_head_packed_bytes(void) { return 16384; }
 int rd_pack_head_weight_host(const float* w, int nout, int cin, void* out_host) {
@@ -432,7 +506,7 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int* ord = order;
   if (!ord && tie_order == RD_TIE_REFERENCE) {   // the reference's own order: std::sort replayed on the device
-    const size_t lds = Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + ((size_t)Kcap / 32 + 2) * 4 : 0;
+    const size_t lds = TIE_STACK_BYTES + (Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + ((size_t)Kcap / 32 + 2) * 4 : 0);
     allow_big_lds(wnms_tie_order_kernel);
     hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(64), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
                        w.scratch);

@@ -36,6 +36,13 @@ SIGNATURES = {
     "rd_pack_deconv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_conv3x3_ex_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rd_pack_conv3x3_ex_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_conv1x1_sc_packed_bytes": (c_size_t, [c_int, c_int]),
+    "rd_pack_conv1x1_sc_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rd_conv3x3_bn_act_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                     c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
     "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p]),
@@ -138,6 +145,24 @@ class Lib:
         cout, cin, kh, kw = w.shape
         out = np.zeros(self.cdll.rd_conv_packed_bytes(kh * kw, cin, cout, dtype), dtype=np.uint8)
         self.call("rd_pack_conv_weight_host", w.ctypes.data, cout, cin, kh, kw, dtype, out.ctypes.data)
+        return out
+
+    def pack_conv3x3_ex(self, w_oihw, stride_w, x_cstride, fold_scale=None):
+        w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+        cout, cin = w.shape[:2]
+        assert w.shape[2:] == (3, 3)
+        fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride), dtype=np.uint8)
+        self.call("rd_pack_conv3x3_ex_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, stride_w,
+                  x_cstride, out.ctypes.data)
+        return out
+
+    def pack_conv1x1_sc(self, w_oi, fold_scale=None):
+        w = np.ascontiguousarray(w_oi, dtype=np.float32).reshape(w_oi.shape[0], -1)
+        cout, cin = w.shape
+        fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_conv1x1_sc_packed_bytes(cin, cout), dtype=np.uint8)
+        self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, out.ctypes.data)
         return out
 
     def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype):

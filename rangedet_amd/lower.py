@@ -4,6 +4,8 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
   relu(BN(Convolution(x)))                         -> rd_conv2d_bn_act                         (dla_backbone.py:24-32, builder.py:221-240)
   relu(BN(Convolution(x)) + shortcut)              -> rd_conv2d_bn_act + RD_ADD|RD_RELU_POST   (dla_backbone.py:34-56)
   BN(Convolution 1x1)   (projection shortcut)      -> rd_conv2d_bn_act, no activation          (dla_backbone.py:44-51)
+  bf16: relu(BN(Conv3x3(h)) + BN(Conv1x1(x)))      -> ONE rd_conv3x3_bn_act_ex: the projection shortcut is accumulated in the 3x3
+                                                      kernel's epilogue; stride (1,2) 3x3 convs run on the pixel-pair view
   skip + relu(BN(Deconvolution(u)))                -> rd_deconv2d_bn_act per phase, RD_RELU_PRE|RD_ADD   (dla_backbone.py:117-126)
   meta_baseline_bias(...) + BN + relu + 1x1 + BN + relu   -> rd_meta_kernel_fwd                (meta_kernel.py:166-240, dla_backbone.py:92-97)
   concat(data, agg3)                               -> producers write straight into one buffer (dla_backbone.py:153-154)
@@ -196,7 +198,8 @@ class Lowering:
         Wout = (x.W + 2 * pad[1] - k[1]) // st[1] + 1
         return k, st[1], Wout
 
-    def _conv_bn(self, conv, bn, flags, residual, dest):
+    def _conv_bn(self, conv, bn, flags, residual, dest, sc=None):
+        """sc = (conv1x1, bn) of a projection shortcut to fuse into this 3x3 conv's epilogue (bf16), or None."""
         if not conv.attrs["no_bias"]:
             raise NotImplementedError("Convolution %s with bias followed by BatchNorm" % conv.name)
         x = self.emit_act(conv.inputs[0])
@@ -205,9 +208,33 @@ class Lowering:
         if cout not in (64, 128):
             raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
         out = self._out(cout, x.H, Wout, dest)
+        # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
+        ex = self.dtype == RD_BF16 and k == (3, 3) and (sc is not None or (sw == 2 and x.W % 2 == 0 and
+                                                                             not os.environ.get("RD_NO_S2_VIEW")))
+        kw = {}
+        if sc is not None:
+            scx = self.emit_act(sc[0].inputs[0])
+            kw["sc"] = dict(name=sc[0].name, bn=sc[1].name, eps=sc[1].attrs["eps"], cin=scx.C, cmap=scx.cmap)
+            kw["sc_x"] = scx                      # top level: the executor's buffer liveness pass looks at step values
         self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual, cin=x.C,
-                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap)
+                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw)
         return out
+
+    def _fusable_projection(self, main_conv, sc):
+        """sc = BN(Convolution 1x1, no bias) with the main 3x3 conv's stride, at most 128 input channels, and (stride 2) an even
+        input width: the shortcut the persistent 3x3 kernel can accumulate in its epilogue (bf16 only)."""
+        if self.dtype != RD_BF16 or os.environ.get("RD_NO_FUSE_SC"):
+            return None
+        if not (sc.op == "BatchNorm" and sc.inputs[0].op == "Convolution"):
+            return None
+        c = sc.inputs[0]
+        if c.attrs["kernel"] != (1, 1) or not c.attrs["no_bias"] or c.attrs["stride"] != main_conv.attrs["stride"] or \
+                c.attrs["num_filter"] != main_conv.attrs["num_filter"] or self.consumers.get(sc.uid, 0) != 1:
+            return None
+        x0 = self.emit_act(c.inputs[0])
+        if x0.C > 128 or (c.attrs["stride"][1] == 2 and x0.W % 2) or c.attrs["stride"][1] not in (1, 2):
+            return None
+        return (c, sc)
 
     def _residual_block(self, add, dest):
         a, b = add.inputs
@@ -218,6 +245,9 @@ class Lowering:
                 break
         if main is None:
             raise NotImplementedError("relu(add) without a BN(conv3x3) branch at %s" % add.name)
+        proj = self._fusable_projection(main.inputs[0], sc)
+        if proj is not None:
+            return self._conv_bn(main.inputs[0], main, RD_ADD | RD_RELU_POST, None, dest, sc=proj)
         res = self.emit_act(sc)
         return self._conv_bn(main.inputs[0], main, RD_ADD | RD_RELU_POST, res, dest)
 

@@ -148,9 +148,26 @@ class Executor:
                     if lc >= 0:
                         wp[:, pc] = w[:, lc]
                 w = wp
-            b["w"] = A.upload(L.pack_conv_weight(w, dt))
             s, t = bn_affine(P, st["bn"], st["eps"])
-            b["scale"], b["shift"] = A.upload(s), A.upload(t)
+            if st.get("sc"):      # fused projection shortcut: both BN scales folded into the weights, one shift for the sum
+                sc = st["sc"]
+                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(w.shape[0], -1)
+                if sc.get("cmap"):
+                    wq = np.zeros((w.shape[0], len(sc["cmap"])), np.float32)
+                    for pc, lc in enumerate(sc["cmap"]):
+                        if lc >= 0:
+                            wq[:, pc] = wsc[:, lc]
+                    wsc = wq
+                ss, ts = bn_affine(P, sc["bn"], sc["eps"])
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s))
+                b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss))
+                b["scale"], b["shift"] = None, A.upload((t.astype(np.float64) + ts).astype(np.float32))
+            elif st.get("ex"):
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs))
+                b["scale"], b["shift"] = A.upload(s), A.upload(t)
+            else:
+                b["w"] = A.upload(L.pack_conv_weight(w, dt))
+                b["scale"], b["shift"] = A.upload(s), A.upload(t)
         elif k == "deconv":
             w = P[st["name"] + "_weight"]
             b["w"] = [A.upload(L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt)) for ph in range(st["stride_w"])]
@@ -211,6 +228,15 @@ class Executor:
                 L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]), B,
                        x.H, x.W, b["cin"], b["flags"], A.ptr(b["head_w"]), A.ptr(b["head_bias"]), self.p(h["out"]),
                        h["N"] * h["nout"], h["n_off"], h["nout"], st_)
+            elif k == "conv" and b.get("ex"):
+                x, o, r, sx = b["x"], b["out"], b["res"], b.get("sc_x")
+                cin = len(b["cmap"]) if b.get("cmap") else b["cin"]
+                L.call("rd_conv3x3_bn_act_ex", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]) if b["scale"] is not None else None,
+                       A.ptr(b["shift"]), self.p(r) if r else None, r.cs if r else 0, r.co if r else 0,
+                       self.p(sx) if sx else None, sx.cs if sx else 0, sx.co if sx else 0,
+                       (len(b["sc"]["cmap"]) if b["sc"].get("cmap") else b["sc"]["cin"]) if sx else 0,
+                       A.ptr(b["sc_w"]) if sx else None, self.p(o), o.cs, o.co, B, x.H, x.W, cin, b["cout"], b["stride_w"],
+                       b["flags"], st_)
             elif k == "conv":
                 x, o, r = b["x"], b["out"], b["res"]
                 L.call("rd_conv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]),

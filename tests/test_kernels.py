@@ -340,6 +340,83 @@ def test_wnms_two_rounds_vs_oracle(be, is3d):
     assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
 
 
+def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0):
+    """rd_conv3x3_bn_act_ex (bf16) vs torch fp32: conv2 of a BasicBlock with stride (1,stride), optional residual, optional fused
+    1x1 projection shortcut of a second input (scales folded into both weight sets by the packers)."""
+    rng = np.random.default_rng(seed)
+    dt = BF16
+    x = bf16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    sc2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh2 = rng.standard_normal(cout).astype(np.float32)
+    Wo = (W - 1) // stride + 1
+    L = be.lib
+    cs = -(-cin // 16) * 16
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, stride), padding=1).numpy()
+    xin = be.up(to_nhwc(x, dt, cstride=cs))
+    y = be.empty(B * H * Wo * cout * 2)
+    args_sc = (None, 0, 0, 0, None)
+    res_ptr = (None, 0, 0)
+    flags = R.RD_RELU_POST
+    if sc_cin:
+        x0 = bf16_round(rng.standard_normal((B, sc_cin, H, W)).astype(np.float32))
+        wsc = (rng.standard_normal((cout, sc_cin)) / np.sqrt(sc_cin)).astype(np.float32)
+        scs, shs = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+        s_cs = sc_cs or -(-sc_cin // 16) * 16
+        ref = ref * sc2[None, :, None, None] + (sh2 + shs)[None, :, None, None]
+        ref = ref + (F.conv2d(torch.from_numpy(x0), torch.from_numpy(wsc[:, :, None, None]), stride=(1, stride)).numpy() *
+                     scs[None, :, None, None])
+        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2))
+        args_sc = (be.ptr(be.up(to_nhwc(x0, dt, cstride=s_cs))), s_cs, 0, sc_cin, be.ptr(be.up(L.pack_conv1x1_sc(wsc, fold_scale=scs))))
+        scale_ptr, shift_ptr = None, be.ptr(be.up(sh2 + shs))
+        flags |= R.RD_ADD
+    else:
+        ref = ref * sc2[None, :, None, None] + sh2[None, :, None, None]
+        wp = be.up(L.pack_conv3x3_ex(w, stride, cs))
+        scale_ptr, shift_ptr = be.ptr(be.up(sc2)), be.ptr(be.up(sh2))
+        if residual:
+            r = bf16_round(rng.standard_normal((B, cout, H, Wo)).astype(np.float32))
+            ref = ref + r
+            res_ptr = (be.ptr(be.up(to_nhwc(r, dt))), cout, 0)
+            flags |= R.RD_ADD
+    ref = np.maximum(ref, 0)
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(xin), cs, 0, be.ptr(wp), scale_ptr, shift_ptr, *res_ptr, *args_sc, be.ptr(y), cout, 0,
+           B, H, W, cin, cout, stride, flags, be.stream)
+    got = from_nhwc(be.down(y, np.uint16, (B, H, Wo, cout)), dt, cout)
+    # folded scales re-round the weights (2^-9 relative each, averaging out over the >= 72-term sums) on top of the output
+    # rounding of _tol: 1.5x
+    tol = 1.5 * _tol(dt, ref)
+    assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
+
+
+CONV_EX_CASES = [
+    # B, H, W, cin, cout, stride, sc_cin, residual
+    (2, 5, 260, 64, 64, 2, None, False),     # stride 2 on the pixel-pair view, several column tiles
+    (1, 9, 132, 128, 128, 2, None, True),    # + residual at the output resolution, two row tiles
+    (1, 4, 70, 64, 64, 1, 8, False),         # res1_unit1: 3x3 64->64 + projection shortcut from the 8-channel input
+    (2, 9, 130, 128, 128, 1, 128, False),    # agg2_res_unit1: stride 1, 128-channel shortcut
+    (1, 5, 264, 64, 128, 2, 64, False),      # res2_unit1: stride 2 + 64->128 shortcut (even pixels of the block input)
+    (1, 3, 66, 128, 128, 2, 128, False),     # res3a_unit1
+    (1, 4, 64, 64, 64, 1, 64, False),        # agg1/agg3_res_unit1
+]
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", CONV_EX_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv3x3_ex(be, case):
+    run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]))
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_conv3x3_ex_errors(be):
+    L = be.lib
+    p = be.ptr(be.empty(1 << 16))
+    f = L.raw("rd_conv3x3_bn_act_ex")
+    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 64, 0, 1, 2, 33, 64, 64, 2, 4, be.stream) == R.RD_ESHAPE   # odd width
+    assert f(p, 64, 0, p, p, p, p, 64, 0, p, 64, 0, 64, p, p, 64, 0, 1, 2, 32, 64, 64, 1, 6, be.stream) == R.RD_EINVAL        # both
+    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 96, 0, 1, 2, 32, 64, 96, 1, 4, be.stream) == R.RD_ESHAPE   # cout
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
