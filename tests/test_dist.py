@@ -1,14 +1,15 @@
-"""N > 1 path on CPU: world-size-2 gloo run of the frame sharding + padded all_gather logic bench.py uses
-(no GPU, no kernels: the per-frame results are stand-ins; what is tested is the distribution contract)."""
+"""N > 1 path on CPU (gloo, world sizes 2 and 4): the SHIPPING sharding / packing / gather code of rangedet_amd.dist, driven by
+a real BatchPostProcessor (score filter + weighted NMS of the hipemu build) per rank -- frame f -> rank f % world, one
+all_gather per step of the padded records, every rank ends up with every frame's detections; checked against the oracle."""
 import os
 import socket
+import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
+import pytest
 import torch.multiprocessing as mp
 
-MAX_DET = 200
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -19,45 +20,85 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nframes, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = [f for f in range(nframes) if f % world == rank]          # frame f -> rank f % world
-    gathered = {}
-    for step, f in enumerate(mine):
-        rng = np.random.default_rng(f)
-        M = int(rng.integers(0, MAX_DET))
-        rows = np.zeros((MAX_DET, 12), np.float32)
-        rows[:M] = rng.standard_normal((M, 12))
-        payload = torch.from_numpy(np.concatenate([rows.reshape(-1), [float(M)], [float(f)]]).astype(np.float32))
-        bufs = [torch.zeros_like(payload) for _ in range(world)]
-        dist.all_gather(bufs, payload)                                # the one collective of the path
-        for b in bufs:
-            gathered[int(b[-1])] = (int(b[-2]), b[:-2].numpy().reshape(MAX_DET, 12).copy())
-    t = torch.tensor([float(len(mine))])
-    dist.all_reduce(t)                                                # max/sum-over-ranks bookkeeping like bench.py
+def _frame_inputs(f, n):
+    """Frame f's (n,) scores and (n,10) boxes, rows sorted by score like the graph's outputs (cluster_dets -> 4 corners, z0, z1)."""
+    from rangedet_amd import synth
+    d = synth.cluster_dets(6 + f % 3, 7, seed=100 + f, quant=(64 if f % 2 else None))
+    d = d[np.argsort(-d[:, 11], kind="stable")]
+    sc = np.zeros(n, np.float32)
+    bx = np.zeros((n, 10), np.float32)
+    k = d.shape[0]
+    sc[:k] = d[:, 11]
+    bx[:k, :8], bx[:k, 8], bx[:k, 9] = d[:, :8], d[:, 9], d[:, 9] + d[:, 10]
+    return sc, bx
+
+
+def _worker(rank, world, port, nframes, B, out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from emu_util import emu_lib, NumpyAllocator
+    from rangedet_amd import dist as rdist
+    from rangedet_amd.pipeline import BatchPostProcessor
+    r, w = rdist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    shard = rdist.FrameSharding()
+    L, A = emu_lib(), NumpyAllocator()
+    n, cap = 96, 64
+    post = BatchPostProcessor(B, n, 0.5, 0.1, 0.5, False, L, A, cap)
+    gat = rdist.DetectionGather(post, shard, A, L, max_det=16)
+    seen = {}
+    for step in range(shard.steps(nframes, B)):
+        frames = shard.frames_of_step(step, B)
+        sc = np.stack([_frame_inputs(f, n)[0] for f in frames])
+        bx = np.stack([_frame_inputs(f, n)[1] for f in frames])
+        post.enqueue_filter(sc.ctypes.data, n, bx.ctypes.data, n * 10)
+        post.enqueue_nms()
+        gat.enqueue()                                          # the one collective of the path
+        seen.update(gat.unpack(step))
     if rank == 0:
-        out.put((t.item(), {k: (v[0], float(np.abs(v[1]).sum())) for k, v in gathered.items()}))
+        out.put({f: (M, rows.tobytes()) for f, (rows, M) in seen.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_frame_sharding_and_gather_gloo():
-    world, nframes = 2, 8
+@pytest.mark.parametrize("world", [2, 4])
+def test_frame_sharding_and_gather_gloo(world):
+    from oracle import cpu_ops as O
+    nframes, B = 8, 2 if world == 2 else 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    total, got = q.get(timeout=120)
+    got = q.get(timeout=300)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert total == nframes and sorted(got) == list(range(nframes))   # every frame processed exactly once, all visible on rank 0
-    for f, (M, checksum) in got.items():
-        rng = np.random.default_rng(f)
-        M_ref = int(rng.integers(0, MAX_DET))
-        rows = rng.standard_normal((M_ref, 12)).astype(np.float32)
-        assert M == M_ref and abs(checksum - float(np.abs(rows).sum())) < 1e-2
+    steps = -(-(-(-nframes // world)) // B)
+    assert sorted(got) == list(range(world * steps * B))       # every frame exactly once, all visible on rank 0
+    for f in range(nframes):
+        sc, bx = _frame_inputs(f, 96)
+        dets = O.score_filter_to_dets(sc, bx, 0.5)
+        flat, keep = O.wnms_4c(dets, 0.1, 0.5, False, 100)
+        M, raw = got[f]
+        rows = np.frombuffer(raw, np.float32).reshape(-1, 12)
+        ref = np.array(flat, np.float32).reshape(-1, 12)
+        assert M == len(keep) and rows.shape[0] == min(M, 16)
+        assert np.array_equal(rows[:, [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11]].view(np.uint32),
+                              ref[:rows.shape[0]][:, [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11]].view(np.uint32))
+        assert np.abs(rows[:, 8] - ref[:rows.shape[0], 8]).max() < 1e-5     # yaw column: atan2f of the score filter
+
+
+def test_sharding_arithmetic():
+    from rangedet_amd.dist import FrameSharding, record_floats
+    s = FrameSharding(rank=3, world=8)
+    assert s.frames_of_step(0, 8) == [3 + 8 * j for j in range(8)] and s.frames_of_step(2, 8)[0] == 3 + 8 * 16
+    assert s.mine(20) == [3, 11, 19] and s.owner(19) == 3
+    assert FrameSharding(0, 8).steps(64, 8) == 1 and FrameSharding(0, 8).steps(65, 8) == 2 and FrameSharding(0, 1).steps(5, 2) == 3
+    assert record_floats() == 2401
+    every = sorted(f for r in range(8) for st in range(2) for f in FrameSharding(r, 8).frames_of_step(st, 4))
+    assert every == list(range(64))

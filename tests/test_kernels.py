@@ -533,7 +533,7 @@ def test_wnms_large_k(be):
     assert d.shape[0] == 20000
     rows, keep = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE)
     flat, rk = O.wnms_4c(d, 0.1, 0.5, False, 100)
-    assert len(rk) > 1000 and keep.tolist() == rk
+    assert len(rk) > 500 and keep.tolist() == rk
     assert np.array_equal(rows.view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
 
 
