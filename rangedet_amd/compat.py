@@ -12,12 +12,14 @@ _MAP = {
     "rangedet.symbol.backbone.meta_kernel": "rangedet_amd.symbol.backbone.meta_kernel",
     "rangedet.symbol.backbone.dla_backbone": "rangedet_amd.symbol.backbone.dla_backbone",
     "rangedet.symbol.head.builder": "rangedet_amd.symbol.head.builder",
+    "rangedet.core.input": "rangedet_amd.core.input",
+    "rangedet.core.detection_metric": "rangedet_amd.core.detection_metric",
     "processing_cxx": "rangedet_amd.processing_cxx",
 }
 
 
 def install_aliases(include_mxnet=True):
-    for pkg in ("rangedet", "rangedet.symbol", "rangedet.symbol.backbone", "rangedet.symbol.head"):
+    for pkg in ("rangedet", "rangedet.symbol", "rangedet.symbol.backbone", "rangedet.symbol.head", "rangedet.core"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = []

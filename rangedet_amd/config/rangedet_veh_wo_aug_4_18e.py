@@ -6,6 +6,9 @@ generation) are out of scope; ``get_config(True)`` raises.
 
 The ped / all_36e variants differ only in class + sampling + epochs; ``variant`` covers them.
 """
+from ..core import detection_metric as metric
+from ..core.input import (CombineData, FilterGTClass, GenerateFPNTarget, GetCoordinates, GetUnnormalizedRange, LoadGTInfo,
+                          LoadRecord, NormData, PadData, ProcessMissValue, SepAndClipData, TransAndReshape, TransposeData)
 from ..mxnext.complicate import normalizer_factory
 from ..symbol.backbone.dla_backbone import DLABackbone as Backbone
 from ..symbol.head.builder import RangeRCNN as Detector
@@ -23,17 +26,17 @@ KITTI_INPUT_CHANNELS = 5
 
 
 def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(64, 2656), fp16=True, batch_image=1,
-               pre_nms_top_n=None, wnms=True):
+               pre_nms_top_n=None, wnms=True, sampling_rate=4, end_epoch=18, name=None):
     _wnms = bool(wnms)
     if is_train:
         raise NotImplementedError("training is outside the hot path this package implements")
     V = _VARIANTS[variant]
-    _bi, _fs, _pf, _fp16 = batch_image, feat_size, pad_field, fp16
+    _bi, _fs, _pf, _fp16, _sr, _ee, _name = batch_image, feat_size, pad_field, fp16, sampling_rate, end_epoch, name
 
     class General:
         batch_image = _bi
         log_frequency = 100
-        name = __name__.rsplit(".")[-1]
+        name = _name or __name__.rsplit(".")[-1]
         fp16 = _fp16
         scale_loss_shift = 128
         feat_size = _fs
@@ -108,7 +111,7 @@ def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(6
 
     class DatasetParam:
         image_set = 'validation'
-        sampling_rate = 4
+        sampling_rate = _sr
         filter_class = V["filter_class"]
 
     backbone = Backbone(BackboneParam)
@@ -123,7 +126,7 @@ def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(6
 
     class OptimizeParam:
         class schedule:
-            end_epoch = 18
+            end_epoch = _ee
 
     class TestParam:
         min_score = {'veh': 0.5, 'ped': 0.4, 'cyc': 0.3}
@@ -144,9 +147,43 @@ def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(6
         mapping = {1: 1, 2: 2, 3: 3, 4: 4, 0: 5}
         test_mapping = {0: 1, 1: 2, 2: 4}
 
+    class ClipDataParam:                                  # config:245-255
+        clip_data_dict = {'range_value': (0, 80), 'intensity': (0, 1), 'elongation': (0, 1), 'pc_vehicle_frame_x': (-80, 80),
+                          'pc_vehicle_frame_y': (-80, 80), 'pc_vehicle_frame_z': (-5, 10), 'inclination': (-0.5, 0.1),
+                          'azimuth': (-6.283185307179586, 1.5707963267948966)}
+
+    class NormDataParam:                                  # config:257-267 (mean, variance)
+        norm_data_dict = {'range_value': (20.0, 1500.0), 'intensity': (0.1, 0.01), 'elongation': (7.2558375e-02, 2.6764875e-02),
+                          'pc_vehicle_frame_x': (1.5672500e+00, 3.0740625e+02), 'pc_vehicle_frame_y': (9.8824875e-01, 2.1913250e+02),
+                          'pc_vehicle_frame_z': (1.4, 1.0), 'inclination': (-8.8427375e-02, 9.9001750e-03),
+                          'azimuth': (-7.8061250e-03, 2.5494125e+00)}
+
+    class CombineDataParam:                               # config:269-282
+        combine_name_dict = {'input_data': ['range_value', 'intensity', 'elongation', 'pc_vehicle_frame_x', 'pc_vehicle_frame_y',
+                                            'pc_vehicle_frame_z', 'inclination', 'azimuth']}
+
+    class PadDataParam:                                   # config:291-314 (test branch)
+        pad_short, pad_long = General.pad_field
+        pad_name_list = ['input_data', 'range_image_mask', 'pc_vehicle_frame', 'unnormalized_range', 'coord']
+
+    class TransposeDataParam:                             # config:316-334 (test branch)
+        transpose_name_dict = {n: (2, 0, 1) for n in PadDataParam.pad_name_list}
+
+    class TransAndReshapeParam:                           # config:336-341 (test branch)
+        name_list = ['pc_vehicle_frame_s1', 'pc_vehicle_frame_s2', 'pc_vehicle_frame_s4',
+                     'range_image_mask_s1', 'range_image_mask_s2', 'range_image_mask_s4']
+
+    # the reference's test-time chain (config:380-399), built from this package's classes: the image-sized stages run as one
+    # fused device launch (rangedet_amd.core.input)
+    transform = [LoadRecord(), LoadGTInfo(), FilterGTClass(General.label_set), ProcessMissValue(), SepAndClipData(ClipDataParam),
+                 GetUnnormalizedRange(), NormData(NormDataParam), GetCoordinates(), CombineData(CombineDataParam),
+                 PadData(PadDataParam), TransposeData(TransposeDataParam), GenerateFPNTarget(FpnParam),
+                 TransAndReshape(TransAndReshapeParam)]
     pc_stride = ["pc_vehicle_frame_s{}".format(s) for s in RpnParam.fpn_strides]
     mask_stride = ["range_image_mask_s{}".format(s) for s in RpnParam.fpn_strides]
     data_name = ["input_data", "gt_bbox_imu", "gt_class", "rec_id"] + pc_stride + mask_stride + ['coord_s1']
-    transform, label_name, metric_list = [], [], []
+    label_name = []
+    metric_list = [metric.ScalarLoss("L1-s{}".format(s), ["rpn_reg_loss_s{}_output".format(s)], []) for s in FpnParam.fpn_strides] + \
+                  [metric.ScalarLoss("cls-s{}".format(s), ["rpn_cls_loss_s{}_output".format(s)], []) for s in FpnParam.fpn_strides]
     return General, KvstoreParam, RpnParam, RoiParam, BboxParam, DatasetParam, ModelParam, OptimizeParam, TestParam, \
         transform, data_name, label_name, metric_list, LabelMapParam
