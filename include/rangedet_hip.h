@@ -225,7 +225,13 @@ int rd_dets12_to_8_batched(const float* dets12, long dets12_bstride, int Mcap, c
 
 /* 8-point rotated IoU: boxes1 (n1,8) x boxes2 (n2,8) -> ious (n1,n2). */
 int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream);
-/* per proposal: max over gt of the cleaned IoU (NaN/Inf/>1/<0 -> 0).  proposals (n, p_stride>=8) */
+/* Custom op 'batch_rotated_iou', iou_type 'bev' (operator_py/batch_rotated_iou.py:11-49, shapes :69-91): proposal
+ * (B, N, p_stride >= 8: the 8 BEV corner coordinates lead each row; the op's rows are 10 wide), gt_bbox (B, n_gt <= 256, 8)
+ * -> iou_map (B, N) = max over the frame's GT boxes of the 8-point rotated IoU after NaN / Inf / > 1 / < 0 -> 0.
+ * argmax (B, N) int32, optional (NULL): index of the first GT box reaching that maximum (0 when every IoU is 0). */
+int rd_batch_rotated_iou(const float* proposal, int p_stride, const float* gt_bbox, float* iou_map, int* argmax, int B, long N,
+                         int n_gt, void* stream);
+/* one frame of the above without argmax.  proposals (n, p_stride>=8) */
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt,
                      void* stream);
 

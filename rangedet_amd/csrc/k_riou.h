@@ -93,24 +93,51 @@ __global__ __launch_bounds__(256) void riou8_kernel(const float* __restrict__ b1
   long r = i / n2, c = i - r * n2;
   out[i] = r_iou8(b1 + r * 8, b2 + c * 8);
 }
-// one thread per proposal, loop over the (<= 200) GT boxes held in LDS
-__global__ __launch_bounds__(256) void batch_max_iou_kernel(const float* __restrict__ prop, int pstride,
-                                                            const float* __restrict__ gt, float* __restrict__ out,
-                                                            long n, int ngt) {
+// Custom op 'batch_rotated_iou' ('bev', operator_py/batch_rotated_iou.py:11-49): per frame, per proposal the maximum over the
+// frame's ground-truth boxes of the cleaned IoU (NaN / Inf / > 1 / < 0 -> 0), and (optionally) the first index reaching it.
+// The GT boxes of the frame (<= 256 x 8 floats, the config pads to 200) and their axis-aligned bounds live in LDS; proposals
+// stream through, one thread each.  Pairs whose bounds are strictly disjoint are not clipped: for them every edge pair
+// fails the routine's own bounding-rectangle test (:131-136) and no corner lies inside the other box, so the reference
+// computes cnt = 0, area = 0 and returns exactly 0 (or hits the degenerate-area early return, also 0) -- skipping them is
+// result-neutral, bit for bit, and it removes > 99 % of the 34 M pairs of a 169 984 x 200 frame.
+__global__ __launch_bounds__(256) void batch_riou_kernel(const float* __restrict__ prop, int pstride, long prop_bs,
+                                                         const float* __restrict__ gt, long gt_bs, float* __restrict__ out,
+                                                         int* __restrict__ out_arg, long n, int ngt) {
   __shared__ float g[256 * 8];
+  __shared__ float gb[256 * 4];   // min x, max x, min y, max y
+  const int b = blockIdx.y;
+  gt += b * gt_bs;
   for (int i = threadIdx.x; i < ngt * 8; i += 256) g[i] = gt[i];
   __syncthreads();
-  long i = blockIdx.x * 256L + threadIdx.x;
+  for (int j = threadIdx.x; j < ngt; j += 256) {
+    const float* q = g + j * 8;
+    gb[4 * j + 0] = fminf(fminf(q[0], q[2]), fminf(q[4], q[6]));
+    gb[4 * j + 1] = fmaxf(fmaxf(q[0], q[2]), fmaxf(q[4], q[6]));
+    gb[4 * j + 2] = fminf(fminf(q[1], q[3]), fminf(q[5], q[7]));
+    gb[4 * j + 3] = fmaxf(fmaxf(q[1], q[3]), fmaxf(q[5], q[7]));
+  }
+  __syncthreads();
+  const long i = blockIdx.x * 256L + threadIdx.x;
   if (i >= n) return;
+  const float* p = prop + b * prop_bs + i * pstride;
   float box[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) box[k] = prop[i * pstride + k];
-  float best = 0.f;
+  for (int k = 0; k < 8; ++k) box[k] = p[k];
+  const float lx = fminf(fminf(box[0], box[2]), fminf(box[4], box[6])), hx = fmaxf(fmaxf(box[0], box[2]), fmaxf(box[4], box[6]));
+  const float ly = fminf(fminf(box[1], box[3]), fminf(box[5], box[7])), hy = fmaxf(fmaxf(box[1], box[3]), fmaxf(box[5], box[7]));
+  const bool finite = (lx == lx) && (hx == hx) && (ly == ly) && (hy == hy);   // a NaN coordinate: no shortcut, run the routine
+  float best = -1.f;
+  int arg = 0;
   for (int j = 0; j < ngt; ++j) {
-    float v = r_iou8(box, g + j * 8);
-    if (!(v == v) || isinf(v) || v > 1.0f || v < 0.f) v = 0.f;
-    best = j == 0 ? v : fmaxf(best, v);
+    float v = 0.f;
+    const bool apart = hx < gb[4 * j] || gb[4 * j + 1] < lx || hy < gb[4 * j + 2] || gb[4 * j + 3] < ly;
+    if (!(finite && apart)) {
+      v = r_iou8(box, g + j * 8);
+      if (!(v == v) || isinf(v) || v > 1.0f || v < 0.f) v = 0.f;
+    }
+    if (v > best) { best = v; arg = j; }          // first maximum, like numpy's argmax
   }
-  out[i] = best;
+  out[b * n + i] = best;
+  if (out_arg) out_arg[b * n + i] = arg;
 }
 }  // namespace rd

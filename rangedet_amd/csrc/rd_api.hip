@@ -612,11 +612,17 @@ int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, lo
   hipLaunchKernelGGL(riou8_kernel, dim3((unsigned)((n1 * n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, ious, n1, n2);
   return check_launch("rotated_iou_8pt");
 }
+int rd_batch_rotated_iou(const float* proposal, int p_stride, const float* gt_bbox, float* iou_map, int* argmax, int B, long N,
+                         int n_gt, void* stream) {
+  RD_REQUIRE(proposal && gt_bbox && iou_map, RD_EINVAL, "batch_rotated_iou: null pointer");
+  RD_REQUIRE(B > 0 && B <= 65535 && N > 0 && n_gt > 0 && n_gt <= 256 && p_stride >= 8, RD_ESHAPE,
+             "batch_rotated_iou: B %d, N %ld, n_gt %d (<= 256), proposal row %d floats (>= 8)", B, N, n_gt, p_stride);
+  hipLaunchKernelGGL(batch_riou_kernel, dim3((unsigned)((N + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, proposal, p_stride,
+                     N * (long)p_stride, gt_bbox, (long)n_gt * 8, iou_map, argmax, N, n_gt);
+  return check_launch("batch_rotated_iou");
+}
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt, void* stream) {
-  RD_REQUIRE(proposals && gt8 && out, RD_EINVAL, "batch_max_iou: null pointer");
-  RD_REQUIRE(n > 0 && n_gt > 0 && n_gt <= 256 && p_stride >= 8, RD_ESHAPE, "batch_max_iou: n_gt %d (<=256), p_stride %d (>=8)", n_gt, p_stride);
-  hipLaunchKernelGGL(batch_max_iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, proposals, p_stride, gt8, out, n, n_gt);
-  return check_launch("batch_max_iou");
+  return rd_batch_rotated_iou(proposals, p_stride, gt8, out, nullptr, 1, n, n_gt, stream);
 }
 
 // ---- greedy 3-D NMS (_contrib_NMS3D) ----------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
   sigmoid + Custom(get_sorted_foreground)          -> rd_sorted_foreground(apply_sigmoid=1)     (builder.py:459-461,512-521)
   contrib.Decode3DBbox                             -> rd_decode3d_bbox                          (builder.py:522-525)
   contrib.NMS3D (wnms=False)                       -> rd_nms3d                                  (builder.py:530-534)
+  Custom(batch_rotated_iou, iou_type='bev')        -> rd_batch_rotated_iou                      (builder.py:176-182)
 Anything that does not match raises NotImplementedError at lowering time -- there is no slow generic path.
 """
 import os
@@ -389,6 +390,8 @@ class Lowering:
             v = ("zeros", s.attrs["shape"])
         elif s.op == "Custom" and s.attrs["op_type"] == "get_sorted_foreground":
             v = ("flat", self._sorted_fg(s)[s.index])
+        elif s.op == "Custom" and s.attrs["op_type"] == "batch_rotated_iou":
+            v = ("flat", self._batch_riou(s))
         elif s.op == "Decode3DBbox":
             v = ("flat", self._decode(s))
         elif s.op == "NMS3D":
@@ -485,6 +488,27 @@ class Lowering:
         self.step("decode", delta=o_d, pc=o_p, out=out, k=k, box_type=o_d.shape[1], is_bin=int(s.attrs["is_bin"]))
         return out
 
+
+    def _batch_riou(self, s):
+        """Custom op 'batch_rotated_iou' (operator_py/batch_rotated_iou.py): proposal = a (B,N,10) box tensor of this graph,
+        gt_bbox = an input variable (B, n_gt, 8) -> iou_map (B,N)."""
+        key = ("briou", s.uid)
+        if key in self.memo:
+            return self.memo[key]
+        if s.attrs.get("iou_type", "bev") != "bev":
+            raise NotImplementedError("batch_rotated_iou: iou_type %r (only 'bev', the config's loss.iou_type)" % s.attrs.get("iou_type"))
+        prop, gt = s.inputs
+        kind, boxes = self.emit_value(prop)
+        gt = _strip_cast(gt)
+        if kind != "flat" or len(boxes.shape) != 2 or boxes.shape[1] != 10 or gt.op != "var":
+            raise NotImplementedError("batch_rotated_iou: proposal must be a (B,N,10) box tensor, gt_bbox an input variable")
+        gshape = self.want_input(gt.name)
+        if len(gshape) != 2 or gshape[1] != 8 or gshape[0] > 256:
+            raise ValueError("batch_rotated_iou: gt_bbox shape %s (need (n_gt <= 256, 8))" % (gshape,))   # batch_rotated_iou.py:78-85
+        out = FlatRef(self.new_buf(self.B * boxes.shape[0] * 4, persistent=True), (boxes.shape[0],))
+        self.step("batch_riou", boxes=boxes, gt=gt.name, N=boxes.shape[0], n_gt=gshape[0], out=out)
+        self.memo[key] = out
+        return out
 
     def _nms3d(self, s):
         key = ("nms3d", s.uid)

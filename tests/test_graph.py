@@ -602,3 +602,35 @@ def test_e2e_bf16_tolerance(be):
         rms, mx = np.sqrt((err ** 2).mean(axis=axes)) / spread, np.abs(err).max(axis=axes) / spread
         print("bf16 vs fp32 oracle (%s), %s: rms/std %s max/std %s (model rms %.4f)" % (be.name, name, np.round(rms, 4), np.round(mx, 4), model))
         assert np.all(rms < 2.5 * model) and np.all(mx < 6 * 2.5 * model)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_batch_rotated_iou_through_the_symbol_api(be):
+    """mx.sym.Custom(op_type='batch_rotated_iou') on the graph's decoded boxes (builder.py:176-182 attaches it to every level's
+    decoded boxes in training) is recorded, lowered to rd_batch_rotated_iou and equals the oracle on the graph's own boxes."""
+    emu = be.name == "emu"
+    H, Wr, W, k = (8, 30, 32, 150) if emu else (16, 250, 256, 2000)
+    cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
+    sym, Cfg = _reduced_symbol(cfg, H, W) if emu else (cfg[6].test_symbol, G.Cfg)
+    boxes_sym = sym.inputs[2]                                    # decoded_bbox of the Group (builder.py:77)
+    iou = mx.sym.Custom(proposal=boxes_sym, gt_bbox=mx.var("gt_bbox_veh_for_iou_pred"), op_type="batch_rotated_iou", iou_type="bev",
+                        name="batch_rotated_iou_veh")
+    grp = mx.sym.Group(list(sym.inputs) + [iou])
+    shapes = dict(small_shapes(H, W), gt_bbox_veh_for_iou_pred=(200, 8))
+    plan = lower(grp, shapes, R.RD_F32, 1)
+    assert [s["kind"] for s in plan.steps][-1] == "batch_riou" and plan.outputs[-1][1].shape == (k,)
+    P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
+    fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
+    ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
+    rb = G.forward(fr, P, cfg=Cfg, num_fgs=k)["decoded_bbox"][0]  # where the boxes will be (the oracle's, within 1e-3)
+    gt = np.tile(np.array([0, 0, 0, 1e-3, 1e-3, 1e-3, 1e-3, 0], np.float32), (200, 1))
+    gt[:20] = rb[::k // 20][:20, :8] + 0.2                        # GT boxes = shifted copies of some predictions
+    outs = ex.forward(dict(fr, gt_bbox_veh_for_iou_pred=gt[None]))
+    be.alloc.sync()
+    bx = np.array(be.alloc.to_numpy(outs[2]))[0]
+    got = np.array(be.alloc.to_numpy(outs[-1]))[0]
+    ref = O.batch_max_iou(bx[:, :8], gt)
+    assert got.shape == (k,) and np.abs(got - ref).max() < 1e-5 and (ref > 0.3).sum() >= 20
+    with pytest.raises(NotImplementedError):
+        lower(mx.sym.Group([mx.sym.Custom(proposal=boxes_sym, gt_bbox=mx.var("g"), op_type="batch_rotated_iou", iou_type="3d")]),
+              dict(shapes, g=(200, 7)), R.RD_F32, 1)

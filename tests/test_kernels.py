@@ -680,6 +680,69 @@ def test_rotated_iou_8pt(be):
     assert np.abs(be.down(mx, np.float32, (b1.shape[0],)) - O.batch_max_iou(b1, gt)).max() < 1e-5
 
 
+def _riou_case(B, N, n_real, seed):
+    """Proposals (B,N,10) like a level's decoded boxes and gt_bbox (B,200,8) like GetFixedLengthGTBbox's output: n_real real
+    boxes then the degenerate padding rows [0,0,0,EPS,EPS,EPS,EPS,0]; a share of the proposals are jittered copies of GT boxes,
+    some exact copies (the winding-dependent degenerate case), some sit on the origin (they meet the padding rows)."""
+    rng = np.random.default_rng(seed)
+    props, gts = [], []
+    for b in range(B):
+        g = synth.cluster_dets(n_real, 1, seed=seed + 7 * b)[:, :8]
+        gt = np.tile(np.array([0, 0, 0, 1e-3, 1e-3, 1e-3, 1e-3, 0], np.float32), (200, 1))
+        gt[:n_real] = g
+        far = synth.cluster_dets(max(1, N // 40), 40, seed=seed + 100 + b, spread=75.0, jitter=1.0)[:N, :8]
+        p = np.zeros((N, 10), np.float32)
+        p[:, :8] = np.resize(far, (N, 8))
+        near = rng.choice(N, N // 8, replace=False)
+        src = rng.integers(0, n_real, near.size)
+        p[near, :8] = g[src] + rng.normal(0, 0.3, (near.size, 1)).astype(np.float32) * np.tile([1, 0.5], 4)
+        p[near[:16], :8] = g[src[:16]]                                   # identical boxes
+        p[near[16:32], :8] = p[near[16:32], :8] * 0 + rng.normal(0, 5e-4, (16, 8)).astype(np.float32)   # on the origin
+        p[:, 8], p[:, 9] = -1.0, 0.8
+        props.append(p)
+        gts.append(gt)
+    return np.stack(props), np.stack(gts)
+
+
+def _check_batch_riou(be, prop, gt):
+    B, N, _ = prop.shape
+    L = be.lib
+    out, arg = be.empty(B * N * 4), be.empty(B * N * 4)
+    L.call("rd_batch_rotated_iou", be.ptr(be.up(prop)), 10, be.ptr(be.up(gt)), be.ptr(out), be.ptr(arg), B, N, gt.shape[1], be.stream)
+    got, ga = be.down(out, np.float32, (B, N)), be.down(arg, np.int32, (B, N))
+    hits = 0
+    for b in range(B):
+        m = O.rotated_iou_8pt(prop[b, :, :8], gt[b])                      # the full (N, 200) matrix of the oracle
+        m[np.isnan(m) | np.isinf(m) | (m > 1.0) | (m < 0)] = 0            # batch_rotated_iou.py:42-45
+        ref, ra = m.max(axis=1), m.argmax(axis=1)
+        assert np.abs(got[b] - ref).max() < 1e-5, np.abs(got[b] - ref).max()
+        top2 = np.sort(m, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0] > 1e-4)                          # a unique maximum (beyond the atan2f noise)
+        assert np.array_equal(ga[b][clear], ra[clear])
+        assert np.array_equal(ga[b][ref == 0], np.zeros((ref == 0).sum(), np.int32))   # all-zero row -> index 0, like argmax
+        hits += int((ref > 0).sum())
+    return hits
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_batch_rotated_iou(be):
+    """Custom op 'batch_rotated_iou' ('bev'): (B,N,10) proposals x (B,200,8) GT -> (B,N) max cleaned IoU (+ argmax) vs the
+    oracle's full IoU matrix, with GT padding rows, identical boxes and boxes on the origin."""
+    prop, gt = _riou_case(2, 700 if be.name == "emu" else 4000, 12, seed=5)
+    assert _check_batch_riou(be, prop, gt) > 100
+    with pytest.raises(R.RangeDetError):
+        be.lib.call("rd_batch_rotated_iou", be.ptr(be.up(prop)), 10, be.ptr(be.up(gt)), be.ptr(be.empty(64)), None, 2, 10, 300, be.stream)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_batch_rotated_iou_full_level(be):
+    """BASELINE config 3 at the reference's level-0 size: 169 984 proposals x 200 GT boxes per frame (batch_rotated_iou.py:12-13),
+    max and argmax against the oracle's 34 M-pair matrix."""
+    prop, gt = _riou_case(1, 169984, 60, seed=9)
+    assert _check_batch_riou(be, prop, gt) > 5000
+
+
 def nms3d_boxes(B, n_obj, rep, seed, jitter=0.05):
     """(B,N,10) score-sorted boxes: 4 BEV corners + z_low, z_high (the layout Decode3DBbox hands to NMS3D)."""
     out = []
