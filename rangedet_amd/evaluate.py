@@ -3,7 +3,7 @@ transform -> forward + post-processing -> `output_dict` / `annotation_dict` -> t
 (rangedet_amd.export) reads.
 
     python -m rangedet_amd.evaluate --roidb 'data/validation/*.roidb' --prefix experiments/<cfg>/checkpoint --epoch 18 \
-        [--out experiments/<cfg>/checkpoint_output_dict_18e.pkl] [--bin-dir <dir> --config-name <cfg>] [--batch 8]
+        [--out experiments/<cfg>/checkpoint_output_dict_18e.pkl] [--bin-dir <dir> --config-name <cfg>] [--batch 8] [--gpus 8]
     python -m rangedet_amd.evaluate --synthetic 16 --random-weights --out /tmp/out.pkl         (self-contained dry run)
 
 A roidb record is the dict datasets/create_range_image_roidb.py writes: `pc_url` (npz with the arrays `range_image`,
@@ -37,37 +37,101 @@ def meta_info(rec, rid):
     return {'name': name, 'timestamp_micros': int(url.split('/')[-1][:-4])}
 
 
-def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms_top_n=50000):
-    """-> (annotation_dict, output_dict) exactly as tools/test.py:166-233 builds them (frames without detections are absent)."""
+def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms_top_n=50000, shard=None, inflight=2,
+        wnms_cap=None):
+    """-> (annotation_dict, output_dict) exactly as tools/test.py:166-233 builds them (frames without detections are absent).
+
+    shard (rangedet_amd.dist.FrameSharding): this process handles the records shard.mine(len(roidb)) -- the reference runs one
+    DetModule per GPU off a shared queue (tools/test.py:143-161); here one process per GPU owns every world-th record and the
+    per-rank dictionaries are merged by merge_across_ranks.  Batches overlap: `inflight` pipelines on their own streams
+    (pipeline.InterleavedPipelines), batch i+1 is enqueued before batch i's results are read back.  A frame with more
+    candidates above min_score than the weighted NMS was sized for is re-run alone with a capacity that fits (the reference
+    has no such limit, nms.h:452-577), never truncated."""
+    from . import lib as rdlib
     from .input_transform import DeviceInputTransform
-    from .pipeline import RangeDetPipeline
-    H, W = np.asarray(load_record(roidb[0])['range_image']).shape[:2]
-    Wp = -(-W // 32) * 32
-    pipe = RangeDetPipeline(params, batch=batch, feat_size=(H, W), pad_field=(H, Wp), variant=variant, wnms=wnms,
-                            pre_nms_top_n=pre_nms_top_n)
-    to_inputs = DeviceInputTransform(pad_hw=(H, Wp), lib=pipe.lib, alloc=pipe.alloc)
-    cls = mapping[variant if variant in mapping else 'veh']
+    from .pipeline import InterleavedPipelines, RangeDetPipeline
+    mine = list(range(len(roidb))) if shard is None else shard.mine(len(roidb))
     output_dict, annotation_dict = {}, {}
-    for i0 in range(0, len(roidb), batch):
-        chunk = roidb[i0:i0 + batch]
-        recs = [load_record(r) for r in chunk]
-        recs += [recs[-1]] * (batch - len(recs))               # the last batch is padded with its last frame
-        res = pipe.run(to_inputs(recs))
-        frames = res['frames'] if batch > 1 else [res]
-        for j, rec in enumerate(chunk):
-            rid = rec.get('rec_id', i0 + j)
-            det = frames[j]['det_xyzlwhyaws']
+    if not mine:
+        return annotation_dict, output_dict
+    H, W = np.asarray(load_record(roidb[mine[0]])['range_image']).shape[:2]
+    Wp = -(-W // 32) * 32
+    cap = min(wnms_cap or 8192, pre_nms_top_n)
+    kw = dict(batch=batch, feat_size=(H, W), pad_field=(H, Wp), variant=variant, wnms=wnms, pre_nms_top_n=pre_nms_top_n)
+    multi = InterleavedPipelines(params, n=max(1, inflight), wnms_cap=cap, **kw)
+    pipe0 = multi.pipes[0]
+    to_inputs = DeviceInputTransform(pad_hw=(H, Wp), lib=pipe0.lib, alloc=pipe0.alloc)
+    cls = mapping[variant if variant in mapping else 'veh']
+    big = {}                                                   # capacity -> single-frame pipeline for overflowing frames
+
+    def rerun(rec):
+        K = min(pre_nms_top_n, rdlib.RD_WNMS_MAX_K)
+        if K not in big:
+            big[K] = RangeDetPipeline(params, wnms_cap=K, **dict(kw, batch=1))
+        return big[K].run(to_inputs([rec]))
+
+    def finish(j, chunk, recs, inputs):
+        for b, i in enumerate(chunk):
+            rec = roidb[i]
+            try:
+                fr = multi.pipes[j].post[b].collect()
+            except rdlib.RangeDetError as e:
+                if e.code != rdlib.RD_EWORKSPACE or not wnms:
+                    raise
+                fr = rerun(recs[b])
+            rid = rec.get('rec_id', i)
+            det = fr['det_xyzlwhyaws']
             if det.shape[0] == 0:
                 continue                                       # tools/test.py:204-205, 222-223
             output_dict[rid] = {'det_xyzlwhyaws': {cls: det}, 'meta_info': meta_info(rec, rid)}
             annotation_dict[rid] = rec.get('gt_bbox_imu')
+
+    pending = []                                               # (pipeline index, record indices, records, inputs kept alive)
+    done = 0
+    for i0 in range(0, len(mine), batch):
+        chunk = mine[i0:i0 + batch]
+        recs = [load_record(roidb[i]) for i in chunk]
+        padded = recs + [recs[-1]] * (batch - len(recs))       # the last batch is padded with its last frame
+        if len(pending) == len(multi.pipes):                   # the pipeline about to be reused must be read back first
+            finish(*pending.pop(0))
+        with multi.stream_context(multi._i % len(multi.pipes)):
+            inputs = to_inputs(padded)                         # the transform runs on the batch's own launch stream
+        j, _ = multi.enqueue(inputs)
+        pending.append((j, chunk, recs, inputs))
+        done += len(chunk)
         if progress:
-            progress(min(i0 + batch, len(roidb)), len(roidb))
+            progress(done, len(mine))
+    while pending:
+        finish(*pending.pop(0))
     return annotation_dict, output_dict
 
 
-def main(argv=None):
+def merge_across_ranks(annotation_dict, output_dict):
+    """All ranks' (annotation_dict, output_dict) merged on every rank (keys are global record ids, disjoint across ranks)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return annotation_dict, output_dict
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (annotation_dict, output_dict))
+    ann, out = {}, {}
+    for a, o in parts:
+        if set(a) & set(ann) or set(o) & set(out):
+            raise RuntimeError("two ranks produced the same record id")
+        ann.update(a)
+        out.update(o)
+    return dict(sorted(ann.items())), dict(sorted(out.items()))
+
+
+def _rank_main(rank, world, port, argv):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    main(argv, _spawned=True)
+
+
+def main(argv=None, _spawned=False):
     ap = argparse.ArgumentParser(description=__doc__.split('\n\n')[0])
+    ap.add_argument('--gpus', type=int, default=1, help="one process per GPU; records are sharded rank = index % gpus "
+                                                        "(under torch.distributed.run the launcher's world size is used)")
     ap.add_argument('--roidb', help="glob of .roidb pickles (lists of records)")
     ap.add_argument('--synthetic', type=int, default=0, help="use N synthetic records instead of --roidb")
     ap.add_argument('--prefix'), ap.add_argument('--epoch', type=int)
@@ -77,6 +141,25 @@ def main(argv=None):
     ap.add_argument('--bin-dir'), ap.add_argument('--config-name', default='rangedet_veh_wo_aug_4_18e')
     ap.add_argument('--nms3d', action='store_true', help="RpnParam.wnms = False: contrib.NMS3D instead of the weighted NMS")
     a = ap.parse_args(argv)
+    import os
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # torch.distributed.run or our own spawn
+    if a.gpus > 1 and not launched:
+        import socket
+        import torch.multiprocessing as mp
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        mp.spawn(_rank_main, args=(a.gpus, port, list(argv) if argv is not None else __import__("sys").argv[1:]), nprocs=a.gpus)
+        return
+    shard = None
+    if launched and int(os.environ["WORLD_SIZE"]) > 1:
+        import torch
+        from . import dist as rdist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        rdist.init_process_group("nccl", torch.device("cuda", local))
+        shard = rdist.FrameSharding()
     from . import synth
     if a.synthetic:
         roidb = [dict(synth.raw_record(i), rec_id=i) for i in range(a.synthetic)]
@@ -91,15 +174,22 @@ def main(argv=None):
     else:
         from .load_model import load_params
         params = load_params(a.prefix, a.epoch)
-    ann, out = run(roidb, params, batch=a.batch, wnms=not a.nms3d,
-                   progress=lambda d, n: print('%d of %d records' % (d, n), flush=True))
-    with open(a.out, 'wb') as fw:
-        pkl.dump(ann, fw)
-        pkl.dump(out, fw)
-    print('%d frames with detections of %d -> %s' % (len(out), len(roidb), a.out))
-    if a.bin_dir:
-        from . import export
-        export.main(a.out, a.config_name, a.bin_dir)
+    rank = shard.rank if shard else 0
+    ann, out = run(roidb, params, batch=a.batch, wnms=not a.nms3d, shard=shard,
+                   progress=(lambda d, n: print('%d of %d records' % (d, n), flush=True)) if rank == 0 else None)
+    ann, out = merge_across_ranks(ann, out)
+    if rank == 0:
+        with open(a.out, 'wb') as fw:
+            pkl.dump(ann, fw)
+            pkl.dump(out, fw)
+        print('%d frames with detections of %d -> %s' % (len(out), len(roidb), a.out))
+        if a.bin_dir:
+            from . import export
+            export.main(a.out, a.config_name, a.bin_dir)
+    if shard is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -58,6 +58,11 @@ def _worker(rank, world, port, nframes, B, out):
         post.enqueue_nms()
         gat.enqueue()                                          # the one collective of the path
         seen.update(gat.unpack(step))
+    # evaluate's per-rank dictionaries (record id -> result), merged on every rank
+    from rangedet_amd import evaluate
+    mine = shard.mine(nframes)
+    ann, outd = evaluate.merge_across_ranks({f: None for f in mine}, {f: {"rank": rank} for f in mine})
+    assert sorted(outd) == list(range(nframes)) and all(outd[f]["rank"] == f % world for f in outd) and sorted(ann) == sorted(outd)
     if rank == 0:
         out.put({f: (M, rows.tobytes()) for f, (rows, M) in seen.items()})
     dist.barrier()

@@ -543,6 +543,12 @@ def test_evaluate_loop_and_export(be, tmp_path):
         assert got.shape == ref.shape and got.shape[0] > 0 and np.abs(got - ref).max() < 1e-3   # bf16 graph both ways
         assert out[i]['meta_info'] == ({'name': 'synthetic', 'timestamp_micros': i} if i != 1 else
                                        {'name': '123', 'timestamp_micros': 1550083467346370})
+    # a weighted-NMS capacity far below the number of candidates: the frames overflow, are re-run alone with a capacity that
+    # fits, and give the same detections -- nothing is truncated (the reference has no capacity, nms.h:452-577)
+    ann2, out2 = evaluate.run(roidb, P, batch=2, pre_nms_top_n=2000, wnms_cap=64)
+    assert sorted(out2) == sorted(out)
+    for i in out:
+        assert np.array_equal(out2[i]['det_xyzlwhyaws']['TYPE_VEHICLE'], out[i]['det_xyzlwhyaws']['TYPE_VEHICLE'])
     pk = tmp_path / "checkpoint_output_dict_18e.pkl"
     with open(pk, "wb") as f:
         import pickle
