@@ -20,10 +20,10 @@
 namespace rd {
 
 struct MetaLayout {  // byte offsets inside the packed parameter block
-  size_t w1s, a2, b1p, t1, w0p, s2t2, total;
+  size_t w1s, a2, b1p, t1, w0p, s2t2, w0f, total;
   size_t wbytes;  // w1s + a2 (the part held in LDS for bf16)
 };
-inline MetaLayout meta_layout(int dt) {
+__host__ __device__ inline MetaLayout meta_layout(int dt) {
   MetaLayout L;
   const size_t w1s = dt == RD_BF16 ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
   const size_t a2 = dt == RD_BF16 ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
@@ -34,7 +34,8 @@ inline MetaLayout meta_layout(int dt) {
   L.t1 = L.b1p + 9 * 64 * 4;
   L.w0p = L.t1 + 9 * 64 * 4;
   L.s2t2 = L.w0p + 2 * 16 * 4 * 4;
-  L.total = L.s2t2 + 128 * 4;
+  L.w0f = L.s2t2 + 128 * 4;                          // bf16: A operand of the hidden-layer MFMA (64 lanes x 8 bf16)
+  L.total = L.w0f + (dt == RD_BF16 ? 1024 : 0);
   return L;
 }
 inline int meta_perm(int blk, int m) {  // MFMA row m of 32-block blk -> channel
@@ -94,12 +95,22 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
     }
   float* fw0 = (float*)(base + L.w0p);
   if (dt == RD_BF16) {
-    // A operands of the two v_mfma_f32_32x32x2_f32 that compute the hidden layer: row m = hidden unit m,
-    // k = (x, y | z, 1): instr 0 lane (m, hi) = W0[m][hi]; instr 1 lane (m, hi) = hi ? b0[m] : W0[m][2]
+    // A operand of the ONE v_mfma_f32_32x32x16_bf16 that computes the hidden layer, row m = hidden unit m.  Weights and
+    // relative coordinates are split into bf16 high + low parts (v = vh + vl, vh = bf16(v), vl = bf16(v - vh)) and the
+    // 16 K slots carry the three significant partial products -- (Wh + Wl)(xh + xl) + b up to the Wl*xl term (2^-18):
+    //   B (per pixel):  k 0..3 = xh yh zh 1 | k 4..7 = xl yl zl 0 | k 8..11 = xh yh zh 1 | k 12..15 = 0
+    //   A (per unit m): k 0..3 = Wh[0..2] bh | k 4..7 = Wh[0..2] 0 | k 8..11 = Wl[0..2] bl | k 12..15 = 0
+    // lane (m, hi) holds k = 8*hi .. 8*hi+7.
+    bf16_t* fa = (bf16_t*)(base + L.w0f);
     for (int lane = 0; lane < 64; ++lane) {
       const int m = lane & 31, hi = lane >> 5;
-      fw0[lane] = w0[m * 3 + hi];
-      fw0[64 + lane] = hi ? b0[m] : w0[m * 3 + 2];
+      float v[4] = {w0[m * 3], w0[m * 3 + 1], w0[m * 3 + 2], b0[m]};
+      for (int e = 0; e < 4; ++e) {
+        const bf16_t h = f32_to_bf16(v[e]);
+        const bf16_t l = f32_to_bf16(v[e] - bf16_to_f32(h));
+        fa[lane * 8 + e] = hi ? l : h;                               // k 0..3 : high parts | k 8..11: low parts
+        fa[lane * 8 + 4 + e] = (hi || e == 3) ? (bf16_t)0 : h;      // k 4..7 : high weights against the low coordinates
+      }
     }
   } else
   for (int hi = 0; hi < 2; ++hi)
@@ -319,7 +330,8 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 
 // ---- bf16 production kernel ----------------------------------------------------------------------------------------
 // Same math as meta_kernel<RD_BF16>, restructured so that the vector ALU is no longer the bottleneck:
-//   * the 3 -> 32 hidden layer runs on the matrix cores in exact fp32 (two v_mfma_f32_32x32x2_f32, k = x,y | z,1);
+//   * the 3 -> 32 hidden layer runs on the matrix cores as ONE bf16 MFMA on high/low split operands (error 2^-18, see
+//     pack_meta; the two v_mfma_f32_32x32x2_f32 it replaces cost 128 of the ~510 MFMA cycles of a tap);
 //     its D layout IS the B operand of MFMA #1 (the hidden-unit permutation is baked into the packed W1);
 //   * the element-wise stage uses packed fp32 FMAs, packed bf16 conversion and an integer packed max as ReLU;
 //   * point coordinates come from an LDS halo (one coalesced fetch per tile instead of 27 global loads per pixel);
@@ -392,8 +404,9 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
     }
   };
 
-  const f32x2* a0p = (const f32x2*)nullptr;
-  (void)a0p;
+  // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
+  const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(RD_BF16).w0f + lane * 16);
+  (void)cw0;
   int tile = blockIdx.x;
   if (tile < a.ntiles) fetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
@@ -408,7 +421,6 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
     const bool live = (h < a.H) && (w < a.W);
     const int cpl = (wv + 1) * HC + (px + 1);
     const float c0 = chalo[cpl], c1 = chalo[HR * HC + cpl], c2 = chalo[2 * HR * HC + cpl];
-    const float a0 = cw0[lane], a1 = cw0[64 + lane];
 
     f32x16 acc2[2];
 #pragma unroll
@@ -421,12 +433,18 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
       const int dh = k / 3 - 1, dw = k % 3 - 1;
       const int pl = (wv + 1 + dh) * HC + (px + 1 + dw);
       const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
-      // MFMA #0 (exact fp32): pre[j][px] = W0[j][0..2] . rel + b0[j]
+      // MFMA #0: pre[j][px] = W0[j][0..2] . rel + b0[j], one bf16 MFMA on high / low split operands (~fp32 accurate)
       f32x16 pre;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pre[r] = 0.f;
-      pre = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, hi ? r1 : r0, pre, 0, 0, 0);
-      pre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, hi ? 1.0f : r2, pre, 0, 0, 0);
+      {
+        const unsigned hxy = f32x2_to_bf16x2(r0, r1), hz1 = f32x2_to_bf16x2(r2, 1.0f);
+        const float l0 = r0 - __uint_as_float(hxy << 16), l1 = r1 - __uint_as_float(hxy & 0xffff0000u);
+        const float l2 = r2 - __uint_as_float(hz1 << 16);
+        const unsigned lxy = f32x2_to_bf16x2(l0, l1), lz0 = f32x2_to_bf16x2(l2, 0.f);
+        unsigned pk0[4] = {hxy, hz1, hi ? 0u : lxy, hi ? 0u : lz0};
+        s16x8 b0frag;
+        memcpy(&b0frag, pk0, 16);
+        pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0frag, b0frag, f32x16{}, 0, 0, 0);
+      }
       // MFMA #1: D1[ch][px] = (s1 W1)[ch][:] . relu(pre)[:] + s1*b1
       f32x16 d1[2];
 #pragma unroll
@@ -486,6 +504,220 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
       }
     }
     // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
+    if (live) {
+      bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int ob = 32 * ot + 16 * hi;
+        unsigned pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          pk[r >> 1] = f32x2_to_bf16x2(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
+                                       fmaxf(acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1], 0.f));
+        *(Slot16*)(yp + ob) = Slot16{pk[0], pk[1], pk[2], pk[3]};
+        *(Slot16*)(yp + ob + 8) = Slot16{pk[4], pk[5], pk[6], pk[7]};
+      }
+    }
+  }
+}
+
+
+// ---- bf16 production kernel, 16-wave form -------------------------------------------------------------------------------
+// Same arithmetic as meta_bf16_kernel, restructured for occupancy: a wave's tap is a serial chain MFMA #0 -> convert ->
+// MFMA #1 -> element-wise (VALU) -> MFMA #2, so with two waves per SIMD the matrix pipe idles through every VALU phase.  Here
+//   * the workgroup is 16 waves (four per SIMD, <= 128 registers each) on a tile of 8 rows x 64 columns (wave w: row w >> 1,
+//     32-pixel block w & 1);
+//   * the 108 KB of weights no longer live in LDS: the 12 KB a tap needs (W1 4 KB + A2 8 KB) stream from L2 through a
+//     two-slot LDS ring, fetched into registers at the start of the previous tap and published with that tap's single
+//     workgroup barrier -- LDS: ring 24 KB + constants 5 KB + data halo (10 x 66 px x 128 B) 82.5 KB + coordinate halo
+//     7.7 KB = 120 KB, one workgroup per CU;
+//   * everything else (MFMA-resident hidden layer, packed element-wise stage, register-prefetched halos) as before.
+constexpr size_t M16_TAPW = 4096 + 8192;                 // weight bytes of one tap: W1S[k] then A2[k]
+constexpr size_t M16_CONST = 9 * 64 * 4 * 2 + 512;       // b1p, t1, s2t2
+// TH rows x CB 32-pixel column blocks = TH*CB waves per workgroup; PF: the next tile's halo is prefetched into registers
+// during the current tile (costs registers), else it is loaded between tiles (costs one exposed memory latency per tile)
+template <int TH, int CB> struct M16Cfg {
+  static constexpr int TW = 32 * CB, HR = TH + 2, HC = TW + 2, NT = TH * CB * 64;
+  static constexpr size_t LDS = 2 * M16_TAPW + M16_CONST + (size_t)HR * HC * 128 + (size_t)3 * HR * HC * 4;
+};
+template <int TH, int CB, bool PF>
+__global__ __launch_bounds__(TH * CB * 64) void meta_bf16_kernel16(MetaArgs a) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  using Cfg = M16Cfg<TH, CB>;
+  constexpr int M16_TH = TH, M16_TW = Cfg::TW;
+  constexpr int PXB = 128, SPP = 8, HC = Cfg::HC, HR = Cfg::HR, NT = Cfg::NT;
+  HIP_DYNAMIC_SHARED(unsigned char, smem);
+  constexpr size_t W1S_B = 9 * 2 * 2 * 64 * 16, WB = W1S_B + 9 * 2 * 2 * 2 * 64 * 16;
+  unsigned char* wring = smem;                               // [2][M16_TAPW]
+  unsigned char* lc = smem + 2 * M16_TAPW;
+  unsigned char* halo = lc + M16_CONST;
+  float* chalo = (float*)(halo + HR * HC * PXB);             // [3][HR][HC]
+  const float* cb1 = (const float*)lc;                       // [9][64]
+  const float* ct1 = cb1 + 9 * 64;                           // [9][64]
+  const float* cs2 = ct1 + 9 * 64;                           // [64] s2, [64] t2
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int px = lane & 31, hi = lane >> 5, row = wv / CB, cblk = wv % CB;
+  const MetaLayout ML = meta_layout(RD_BF16);
+
+  for (size_t i = tid; i < (9 * 64 * 4 * 2) / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + ML.b1p))[i];
+  for (size_t i = tid; i < 512 / 16; i += NT) ((Slot16*)(lc + 9 * 64 * 4 * 2))[i] = ((const Slot16*)(a.packed + ML.s2t2))[i];
+  const s16x8 w0frag = *(const s16x8*)(a.packed + ML.w0f + lane * 16);
+  const bf16_t* data = (const bf16_t*)a.data;
+  bf16_t* yout = (bf16_t*)a.y;
+  const long HW = (long)a.H * a.W;
+
+  // weight stream: thread t < 768 owns 16-byte slot t of a tap's 12 KB
+  Slot16 wreg = Slot16{0u, 0u, 0u, 0u};
+  static_assert(NT >= 768, "the weight stream needs 768 threads");
+  auto wfetch = [&](int k) {
+    if (tid < 256) wreg = *(const Slot16*)(a.packed + ML.w1s + (size_t)k * 4096 + tid * 16);
+    else if (tid < 768) wreg = *(const Slot16*)(a.packed + ML.a2 + (size_t)k * 8192 + (tid - 256) * 16);
+  };
+  auto wcommit = [&](int slot) {
+    if (tid < 768) *(Slot16*)(wring + (size_t)slot * M16_TAPW + tid * 16) = wreg;
+  };
+
+  constexpr int DITEMS = HR * HC * SPP, DU = (DITEMS + NT - 1) / NT;
+  constexpr int CITEMS = 3 * HR * HC, CU = (CITEMS + NT - 1) / NT;
+  Slot16 dreg[DU];
+  float creg[CU];
+  auto fetch = [&](int tile) {
+    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
+    const int h0 = th * M16_TH, w0 = tw * M16_TW;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
+      const int r = pl / HC, c = pl - r * HC;
+      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      dreg[u] = Slot16{0u, 0u, 0u, 0u};
+      if (idx < DITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        dreg[u] = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int idx = u * NT + tid, ch = idx / (HR * HC), pl = idx - ch * (HR * HC);
+      const int r = pl / HC, c = pl - r * HC;
+      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      creg[u] = 0.f;                              // im2col zero padding: outside the image the coordinate is 0
+      if (idx < CITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+        creg[u] = a.coord[((size_t)b * 3 + ch) * HW + (long)ih * a.W + iw];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
+      if (idx < DITEMS) *(Slot16*)(halo + pl * PXB + ((s ^ ((pl >> 1) & 7)) << 4)) = dreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int idx = u * NT + tid;
+      if (idx < CITEMS) chalo[idx] = creg[u];
+    }
+  };
+
+  int tile = blockIdx.x;
+  int g = 0;                                                 // running tap count: tap g's weights sit in ring slot g & 1
+  if (tile < a.ntiles) {
+    if (PF) fetch(tile);
+    wfetch(0);
+    wcommit(0);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
+    const int h0 = th * M16_TH, w0 = tw * M16_TW;
+    // (the barrier that ended the previous tile's last tap already separates its halo reads from this commit)
+    if (!PF) fetch(tile);
+    commit();
+    __syncthreads();
+    if (PF && tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);   // in flight during this tile's math
+
+    const int h = h0 + row, w = w0 + 32 * cblk + px;
+    const bool live = (h < a.H) && (w < a.W);
+    const int cpl = (row + 1) * HC + (32 * cblk + px + 1);
+    const float c0 = chalo[cpl], c1 = chalo[HR * HC + cpl], c2 = chalo[2 * HR * HC + cpl];
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k, ++g) {
+      wfetch(k == 8 ? 0 : k + 1);                            // next tap's weights: global -> registers, landed by the tap's end
+      const unsigned char* w1s = wring + (size_t)(g & 1) * M16_TAPW;
+      const unsigned char* a2w = w1s + 4096;
+      const int dh = k / 3 - 1, dw = k % 3 - 1;
+      const int pl = (row + 1 + dh) * HC + (32 * cblk + px + 1 + dw);
+      const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
+      f32x16 pre;
+      {
+        const unsigned hxy = f32x2_to_bf16x2(r0, r1), hz1 = f32x2_to_bf16x2(r2, 1.0f);
+        const float l0 = r0 - __uint_as_float(hxy << 16), l1 = r1 - __uint_as_float(hxy & 0xffff0000u);
+        const float l2 = r2 - __uint_as_float(hz1 << 16);
+        const unsigned lxy = f32x2_to_bf16x2(l0, l1), lz0 = f32x2_to_bf16x2(l2, 0.f);
+        unsigned pk0[4] = {hxy, hz1, hi ? 0u : lxy, hi ? 0u : lz0};
+        s16x8 b0frag;
+        memcpy(&b0frag, pk0, 16);
+        pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0frag, b0frag, f32x16{}, 0, 0, 0);
+      }
+      // hidden vector as the two B fragments of MFMA #1 (ReLU on the packed pairs: negative bf16 = negative int16)
+      s16x8 hfrag[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned v = f32x2_to_bf16x2(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
+          pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+        }
+        memcpy(&hfrag[ks], pk, 16);
+      }
+      const unsigned char* hp = halo + pl * PXB;
+      const int swz = (pl >> 1) & 7;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {   // one 32-channel block at a time: 16 live MFMA #1 results instead of 32
+        f32x16 d1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *(const f32x4*)(cb1 + k * 64 + 32 * mt + 16 * hi + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d1[4 * q + e] = bq[e];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const s16x8 af = *(const s16x8*)(w1s + (((size_t)mt * 2 + ks) * 64 + lane) * 16);
+          d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hfrag[ks], d1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const Slot16 dv = *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+          const f32x4 t0 = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2);
+          const f32x4 t1v = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2 + 4);
+          unsigned pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 x2 = {__uint_as_float(dv[e] << 16), __uint_as_float(dv[e] & 0xffff0000u)};
+            const f32x2 w2 = {d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]};
+            const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
+            const f32x2 v2 = x2 * w2 + b2;
+            const unsigned v = f32x2_to_bf16x2(v2[0], v2[1]);
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+          }
+          s16x8 bfrag;
+          memcpy(&bfrag, pk, 16);
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot) {
+            const s16x8 af = *(const s16x8*)(a2w + ((((size_t)ot * 2 + mt) * 2 + s2) * 64 + lane) * 16);
+            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
+          }
+        }
+      }
+      wcommit((g + 1) & 1);      // slot (g+1)&1 was last read in tap g-1, which every wave left at the previous barrier
+      __syncthreads();           // tap g+1 may read its weights; after tap 8: every wave is done with this tile's halos
+    }
     if (live) {
       bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
 #pragma unroll

@@ -11,6 +11,7 @@
 #include "k_wnms.h"
 
 #include <algorithm>
+#include <string>
 #include <numeric>
 
 using namespace rd;
@@ -48,6 +49,16 @@ inline void allow_big_lds(K kernel) {
   // size actually requested still works -- do not leave that status behind for the next check_launch)
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     (void)hipGetLastError();
+}
+template <int TH, int CB, bool PF>
+inline void launch_meta16(MetaArgs a, hipStream_t st) {
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + 32 * CB - 1) / (32 * CB);
+  a.ntiles = a.B * a.tiles_h * a.tiles_w;
+  auto kern = meta_bf16_kernel16<TH, CB, PF>;
+  allow_big_lds(kern);
+  const size_t lds = M16Cfg<TH, CB>::LDS;
+  hipLaunchKernelGGL(kern, dim3(std::min(a.ntiles, conv_num_cus())), dim3(TH * CB * 64), lds, st, a);
 }
 inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4>);
@@ -400,7 +411,15 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t consts = 9 * 64 * 4 * 2 + 1024;
   ProfScope ps(RD_PROF_META, st);
-  if (dtype == RD_BF16) {
+  // RD_META_VARIANT (dev switch, A/B): "8" = the 8-wave form with LDS-resident weights; "8x2p" / "8x2n" / "4x3p" / "4x3n" = the
+  // streaming-weights form with TH x CB waves, halo prefetched into registers (p) or loaded between tiles (n)
+  static const std::string mv = getenv("RD_META_VARIANT") ? getenv("RD_META_VARIANT") : "4x3p";
+  if (dtype == RD_BF16 && mv != "8") {
+    if (mv == "8x2p") launch_meta16<8, 2, true>(a, st);
+    else if (mv == "8x2n") launch_meta16<8, 2, false>(a, st);
+    else if (mv == "4x3n") launch_meta16<4, 3, false>(a, st);
+    else launch_meta16<4, 3, true>(a, st);
+  } else if (dtype == RD_BF16) {
     const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
     allow_big_lds(meta_bf16_kernel<WAVES>);
     hipLaunchKernelGGL((meta_bf16_kernel<WAVES>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
