@@ -60,8 +60,12 @@ def conv_bytes(plan, esz, only_conv3=False):
             if s.get("res") is not None:
                 by += o.H * o.W * s["cout"] * esz
             by += s["cin"] * s["cout"] * s["k"][0] * s["k"][1] * esz
-            if s.get("sc"):   # fused projection shortcut: its input pixels (at the output grid) and its weights
-                by += (o.H * o.W * s["sc"]["cin"] + s["sc"]["cin"] * s["cout"]) * esz
+            if s.get("sc"):
+                # the block's projection shortcut runs inside this launch; the ALGORITHMIC bytes stay those of the reference's
+                # layer-by-layer graph: the 1x1 conv reads the block input, writes its output, and this conv
+                # reads that output back as its residual
+                sx = s["sc_x"]
+                by += (sx.H * sx.W * s["sc"]["cin"] + 2 * o.H * o.W * s["cout"] + s["sc"]["cin"] * s["cout"]) * esz
     return by
 
 

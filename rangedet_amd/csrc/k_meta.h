@@ -351,62 +351,77 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
   float* chalo = (float*)(halo + HR * HC * PXB);  // [3][HR][HC]
   const float* cb1 = (const float*)lc;            // [9][64]
   const float* ct1 = cb1 + 9 * 64;                // [9][64]
-  const float* cw0 = ct1 + 9 * 64;                // [2][64] MFMA #0 A operands
-  const float* cs2 = cw0 + 2 * 16 * 4;            // [64] s2, [64] t2
+  const float* cs2 = ct1 + 9 * 64 + 2 * 16 * 4;   // [64] s2, [64] t2
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int px = lane & 31, hi = lane >> 5;
 
   for (size_t i = tid; i < WB / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)a.packed)[i];
   for (size_t i = tid; i < CONST_B / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + WB))[i];
-  const unsigned char* w1s = lw;
-  const unsigned char* a2w = lw + W1S_B;
   const bf16_t* data = (const bf16_t*)a.data;
   bf16_t* yout = (bf16_t*)a.y;
   const long HW = (long)a.H * a.W;
 
-  // halo prefetch registers: data slots idx = u*NT + tid (u < DU), coordinate floats idx = u*NT + tid (u < CU)
+  // halo prefetch registers: data slots idx = u*NT + tid (u < DU), coordinate floats idx = u*NT + tid (u < CU).  Everything
+  // that only depends on the thread (halo row / column / slot, LDS addresses) is computed ONCE here; per tile only the image
+  // position and the bounds test remain (this kernel is instruction-issue bound: 70 % of the SIMD issue slots are taken,
+  // profiles/r02_meta_pmc.txt, so per-tile integer work counts)
   constexpr int DITEMS = HR * HC * SPP, DU = (DITEMS + NT - 1) / NT;
   constexpr int CITEMS = 3 * HR * HC, CU = (CITEMS + NT - 1) / NT;
   Slot16 dreg[DU];
   float creg[CU];
+  short drow[DU], dcol[DU], crow[CU], ccol[CU];
+  int dlds[DU], dsrc[DU];                          // LDS byte address of the slot; element offset of its 8 channels
+  int cch[CU];
+#pragma unroll
+  for (int u = 0; u < DU; ++u) {
+    const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
+    drow[u] = (short)(pl / HC); dcol[u] = (short)(pl - (pl / HC) * HC);
+    dlds[u] = idx < DITEMS ? pl * PXB + ((s ^ ((pl >> 1) & 7)) << 4) : -1;
+    dsrc[u] = a.d_co + s * 8;
+  }
+#pragma unroll
+  for (int u = 0; u < CU; ++u) {
+    const int idx = u * NT + tid, ch = idx / (HR * HC), pl = idx - ch * (HR * HC);
+    crow[u] = (short)(pl / HC); ccol[u] = (short)(pl - (pl / HC) * HC);
+    cch[u] = idx < CITEMS ? ch : -1;
+  }
   auto fetch = [&](int tile) {
     const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
-    const int h0 = th * WAVES, w0 = tw * 32;
+    const int h0 = th * WAVES - 1, w0 = tw * 32 - 1;
+    const bf16_t* dbase = data + (size_t)b * a.H * a.W * a.d_cs;
+    const float* cbase = a.coord + (size_t)b * 3 * HW;
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
-      const int r = pl / HC, c = pl - r * HC;
-      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      const int ih = h0 + drow[u], iw = w0 + dcol[u];
       dreg[u] = Slot16{0u, 0u, 0u, 0u};
-      if (idx < DITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-        dreg[u] = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * 8);
+      if (dlds[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        dreg[u] = *(const Slot16*)(dbase + ((size_t)ih * a.W + iw) * a.d_cs + dsrc[u]);
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u) {
-      const int idx = u * NT + tid, ch = idx / (HR * HC), pl = idx - ch * (HR * HC);
-      const int r = pl / HC, c = pl - r * HC;
-      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
+      const int ih = h0 + crow[u], iw = w0 + ccol[u];
       creg[u] = 0.f;                              // im2col zero padding: outside the image the coordinate is 0
-      if (idx < CITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-        creg[u] = a.coord[((size_t)b * 3 + ch) * HW + (long)ih * a.W + iw];
+      if (cch[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        creg[u] = cbase[(size_t)cch[u] * HW + (long)ih * a.W + iw];
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
-      if (idx < DITEMS) *(Slot16*)(halo + pl * PXB + ((s ^ ((pl >> 1) & 7)) << 4)) = dreg[u];
-    }
+    for (int u = 0; u < DU; ++u)
+      if (dlds[u] >= 0) *(Slot16*)(halo + dlds[u]) = dreg[u];
 #pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < CITEMS) chalo[idx] = creg[u];
-    }
+    for (int u = 0; u < CU; ++u)
+      if (cch[u] >= 0) chalo[u * NT + tid] = creg[u];
   };
 
   // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
   const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(RD_BF16).w0f + lane * 16);
-  (void)cw0;
+  // per-lane LDS addresses that do not depend on the tile: everything a tap adds to them is a compile-time constant
+  const unsigned char* w1l = lw + lane * 16;                 // + ((k*2 + mt)*2 + ks) * 1024
+  const unsigned char* a2l = lw + W1S_B + lane * 16;         // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
+  const float* cbl = cb1 + 16 * hi;                          // + k*64 + 32*mt + 4*q
+  const float* ctl = ct1 + 16 * hi;
+  const int pl0 = (wv + 1) * HC + (px + 1);                  // centre pixel of this lane in the halo
   int tile = blockIdx.x;
   if (tile < a.ntiles) fetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
@@ -419,8 +434,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
 
     const int h = h0 + wv, w = w0 + px;
     const bool live = (h < a.H) && (w < a.W);
-    const int cpl = (wv + 1) * HC + (px + 1);
-    const float c0 = chalo[cpl], c1 = chalo[HR * HC + cpl], c2 = chalo[2 * HR * HC + cpl];
+    const float c0 = chalo[pl0], c1 = chalo[HR * HC + pl0], c2 = chalo[2 * HR * HC + pl0];
 
     f32x16 acc2[2];
 #pragma unroll
@@ -428,230 +442,14 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
 
-#pragma unroll 1
+    // the nine taps, fully unrolled: tap offsets, weight / constant addresses are immediates of the LDS instructions
+#pragma unroll
     for (int k = 0; k < 9; ++k) {
+      constexpr int dummy = 0; (void)dummy;
       const int dh = k / 3 - 1, dw = k % 3 - 1;
-      const int pl = (wv + 1 + dh) * HC + (px + 1 + dw);
+      const int pl = pl0 + dh * HC + dw;
       const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
       // MFMA #0: pre[j][px] = W0[j][0..2] . rel + b0[j], one bf16 MFMA on high / low split operands (~fp32 accurate)
-      f32x16 pre;
-      {
-        const unsigned hxy = f32x2_to_bf16x2(r0, r1), hz1 = f32x2_to_bf16x2(r2, 1.0f);
-        const float l0 = r0 - __uint_as_float(hxy << 16), l1 = r1 - __uint_as_float(hxy & 0xffff0000u);
-        const float l2 = r2 - __uint_as_float(hz1 << 16);
-        const unsigned lxy = f32x2_to_bf16x2(l0, l1), lz0 = f32x2_to_bf16x2(l2, 0.f);
-        unsigned pk0[4] = {hxy, hz1, hi ? 0u : lxy, hi ? 0u : lz0};
-        s16x8 b0frag;
-        memcpy(&b0frag, pk0, 16);
-        pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0frag, b0frag, f32x16{}, 0, 0, 0);
-      }
-      // MFMA #1: D1[ch][px] = (s1 W1)[ch][:] . relu(pre)[:] + s1*b1
-      f32x16 d1[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bq = *(const f32x4*)(cb1 + k * 64 + 32 * mt + 16 * hi + 4 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d1[mt][4 * g + e] = bq[e];
-        }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        unsigned pk[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned v = f32x2_to_bf16x2(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
-          // ReLU on the packed pair: as signed 16-bit integers negative bf16 values are negative
-          pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
-        }
-        s16x8 bfrag;
-        memcpy(&bfrag, pk, 16);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const s16x8 af = *(const s16x8*)(w1s + ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 16);
-          d1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, d1[mt], 0, 0, 0);
-        }
-      }
-      // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
-      const unsigned char* hp = halo + pl * PXB;
-      const int swz = (pl >> 1) & 7;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const Slot16 dv = *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
-          const f32x4 t0 = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2);
-          const f32x4 t1v = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2 + 4);
-          unsigned pk[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const f32x2 x2 = {__uint_as_float(dv[e] << 16), __uint_as_float(dv[e] & 0xffff0000u)};
-            const f32x2 w2 = {d1[mt][8 * s2 + 2 * e], d1[mt][8 * s2 + 2 * e + 1]};
-            const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
-            const f32x2 v2 = x2 * w2 + b2;
-            const unsigned v = f32x2_to_bf16x2(v2[0], v2[1]);
-            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
-          }
-          s16x8 bfrag;
-          memcpy(&bfrag, pk, 16);
-          // MFMA #2: acc2[o][px] += A[o][(ch,k)] . a[ch]
-#pragma unroll
-          for (int ot = 0; ot < 2; ++ot) {
-            const s16x8 af = *(const s16x8*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 2 + s2) * 64 + lane) * 16);
-            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
-    if (live) {
-      bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot) {
-        const int ob = 32 * ot + 16 * hi;
-        unsigned pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2)
-          pk[r >> 1] = f32x2_to_bf16x2(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
-                                       fmaxf(acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1], 0.f));
-        *(Slot16*)(yp + ob) = Slot16{pk[0], pk[1], pk[2], pk[3]};
-        *(Slot16*)(yp + ob + 8) = Slot16{pk[4], pk[5], pk[6], pk[7]};
-      }
-    }
-  }
-}
-
-
-// ---- bf16 production kernel, 16-wave form -------------------------------------------------------------------------------
-// Same arithmetic as meta_bf16_kernel, restructured for occupancy: a wave's tap is a serial chain MFMA #0 -> convert ->
-// MFMA #1 -> element-wise (VALU) -> MFMA #2, so with two waves per SIMD the matrix pipe idles through every VALU phase.  Here
-//   * the workgroup is 16 waves (four per SIMD, <= 128 registers each) on a tile of 8 rows x 64 columns (wave w: row w >> 1,
-//     32-pixel block w & 1);
-//   * the 108 KB of weights no longer live in LDS: the 12 KB a tap needs (W1 4 KB + A2 8 KB) stream from L2 through a
-//     two-slot LDS ring, fetched into registers at the start of the previous tap and published with that tap's single
-//     workgroup barrier -- LDS: ring 24 KB + constants 5 KB + data halo (10 x 66 px x 128 B) 82.5 KB + coordinate halo
-//     7.7 KB = 120 KB, one workgroup per CU;
-//   * everything else (MFMA-resident hidden layer, packed element-wise stage, register-prefetched halos) as before.
-constexpr size_t M16_TAPW = 4096 + 8192;                 // weight bytes of one tap: W1S[k] then A2[k]
-constexpr size_t M16_CONST = 9 * 64 * 4 * 2 + 512;       // b1p, t1, s2t2
-// TH rows x CB 32-pixel column blocks = TH*CB waves per workgroup; PF: the next tile's halo is prefetched into registers
-// during the current tile (costs registers), else it is loaded between tiles (costs one exposed memory latency per tile)
-template <int TH, int CB> struct M16Cfg {
-  static constexpr int TW = 32 * CB, HR = TH + 2, HC = TW + 2, NT = TH * CB * 64;
-  static constexpr size_t LDS = 2 * M16_TAPW + M16_CONST + (size_t)HR * HC * 128 + (size_t)3 * HR * HC * 4;
-};
-template <int TH, int CB, bool PF>
-__global__ __launch_bounds__(TH * CB * 64) void meta_bf16_kernel16(MetaArgs a) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  using Cfg = M16Cfg<TH, CB>;
-  constexpr int M16_TH = TH, M16_TW = Cfg::TW;
-  constexpr int PXB = 128, SPP = 8, HC = Cfg::HC, HR = Cfg::HR, NT = Cfg::NT;
-  HIP_DYNAMIC_SHARED(unsigned char, smem);
-  constexpr size_t W1S_B = 9 * 2 * 2 * 64 * 16, WB = W1S_B + 9 * 2 * 2 * 2 * 64 * 16;
-  unsigned char* wring = smem;                               // [2][M16_TAPW]
-  unsigned char* lc = smem + 2 * M16_TAPW;
-  unsigned char* halo = lc + M16_CONST;
-  float* chalo = (float*)(halo + HR * HC * PXB);             // [3][HR][HC]
-  const float* cb1 = (const float*)lc;                       // [9][64]
-  const float* ct1 = cb1 + 9 * 64;                           // [9][64]
-  const float* cs2 = ct1 + 9 * 64;                           // [64] s2, [64] t2
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int px = lane & 31, hi = lane >> 5, row = wv / CB, cblk = wv % CB;
-  const MetaLayout ML = meta_layout(RD_BF16);
-
-  for (size_t i = tid; i < (9 * 64 * 4 * 2) / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + ML.b1p))[i];
-  for (size_t i = tid; i < 512 / 16; i += NT) ((Slot16*)(lc + 9 * 64 * 4 * 2))[i] = ((const Slot16*)(a.packed + ML.s2t2))[i];
-  const s16x8 w0frag = *(const s16x8*)(a.packed + ML.w0f + lane * 16);
-  const bf16_t* data = (const bf16_t*)a.data;
-  bf16_t* yout = (bf16_t*)a.y;
-  const long HW = (long)a.H * a.W;
-
-  // weight stream: thread t < 768 owns 16-byte slot t of a tap's 12 KB
-  Slot16 wreg = Slot16{0u, 0u, 0u, 0u};
-  static_assert(NT >= 768, "the weight stream needs 768 threads");
-  auto wfetch = [&](int k) {
-    if (tid < 256) wreg = *(const Slot16*)(a.packed + ML.w1s + (size_t)k * 4096 + tid * 16);
-    else if (tid < 768) wreg = *(const Slot16*)(a.packed + ML.a2 + (size_t)k * 8192 + (tid - 256) * 16);
-  };
-  auto wcommit = [&](int slot) {
-    if (tid < 768) *(Slot16*)(wring + (size_t)slot * M16_TAPW + tid * 16) = wreg;
-  };
-
-  constexpr int DITEMS = HR * HC * SPP, DU = (DITEMS + NT - 1) / NT;
-  constexpr int CITEMS = 3 * HR * HC, CU = (CITEMS + NT - 1) / NT;
-  Slot16 dreg[DU];
-  float creg[CU];
-  auto fetch = [&](int tile) {
-    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
-    const int h0 = th * M16_TH, w0 = tw * M16_TW;
-#pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
-      const int r = pl / HC, c = pl - r * HC;
-      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
-      dreg[u] = Slot16{0u, 0u, 0u, 0u};
-      if (idx < DITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-        dreg[u] = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      const int idx = u * NT + tid, ch = idx / (HR * HC), pl = idx - ch * (HR * HC);
-      const int r = pl / HC, c = pl - r * HC;
-      const int ih = h0 - 1 + r, iw = w0 - 1 + c;
-      creg[u] = 0.f;                              // im2col zero padding: outside the image the coordinate is 0
-      if (idx < CITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-        creg[u] = a.coord[((size_t)b * 3 + ch) * HW + (long)ih * a.W + iw];
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int idx = u * NT + tid, pl = idx / SPP, s = idx - pl * SPP;
-      if (idx < DITEMS) *(Slot16*)(halo + pl * PXB + ((s ^ ((pl >> 1) & 7)) << 4)) = dreg[u];
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < CITEMS) chalo[idx] = creg[u];
-    }
-  };
-
-  int tile = blockIdx.x;
-  int g = 0;                                                 // running tap count: tap g's weights sit in ring slot g & 1
-  if (tile < a.ntiles) {
-    if (PF) fetch(tile);
-    wfetch(0);
-    wcommit(0);
-  }
-  for (; tile < a.ntiles; tile += gridDim.x) {
-    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, b = tile / (a.tiles_w * a.tiles_h);
-    const int h0 = th * M16_TH, w0 = tw * M16_TW;
-    // (the barrier that ended the previous tile's last tap already separates its halo reads from this commit)
-    if (!PF) fetch(tile);
-    commit();
-    __syncthreads();
-    if (PF && tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);   // in flight during this tile's math
-
-    const int h = h0 + row, w = w0 + 32 * cblk + px;
-    const bool live = (h < a.H) && (w < a.W);
-    const int cpl = (row + 1) * HC + (32 * cblk + px + 1);
-    const float c0 = chalo[cpl], c1 = chalo[HR * HC + cpl], c2 = chalo[2 * HR * HC + cpl];
-
-    f32x16 acc2[2];
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
-
-#pragma unroll 1
-    for (int k = 0; k < 9; ++k, ++g) {
-      wfetch(k == 8 ? 0 : k + 1);                            // next tap's weights: global -> registers, landed by the tap's end
-      const unsigned char* w1s = wring + (size_t)(g & 1) * M16_TAPW;
-      const unsigned char* a2w = w1s + 4096;
-      const int dh = k / 3 - 1, dw = k % 3 - 1;
-      const int pl = (row + 1 + dh) * HC + (32 * cblk + px + 1 + dw);
-      const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
       f32x16 pre;
       {
         const unsigned hxy = f32x2_to_bf16x2(r0, r1), hz1 = f32x2_to_bf16x2(r2, 1.0f);
@@ -678,24 +476,26 @@ __global__ __launch_bounds__(TH * CB * 64) void meta_bf16_kernel16(MetaArgs a) {
       const unsigned char* hp = halo + pl * PXB;
       const int swz = (pl >> 1) & 7;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {   // one 32-channel block at a time: 16 live MFMA #1 results instead of 32
+      for (int mt = 0; mt < 2; ++mt) {
+        // MFMA #1: D1[ch][px] = (s1 W1)[ch][:] . relu(pre)[:] + s1*b1, one 32-channel block at a time
         f32x16 d1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = *(const f32x4*)(cb1 + k * 64 + 32 * mt + 16 * hi + 4 * q);
+          const f32x4 bq = *(const f32x4*)(cbl + k * 64 + 32 * mt + 4 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) d1[4 * q + e] = bq[e];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const s16x8 af = *(const s16x8*)(w1s + (((size_t)mt * 2 + ks) * 64 + lane) * 16);
+          const s16x8 af = *(const s16x8*)(w1l + ((k * 2 + mt) * 2 + ks) * 1024);
           d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hfrag[ks], d1, 0, 0, 0);
         }
+        // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const Slot16 dv = *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
-          const f32x4 t0 = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2);
-          const f32x4 t1v = *(const f32x4*)(ct1 + k * 64 + 32 * mt + 16 * hi + 8 * s2 + 4);
+          const f32x4 t0 = *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2);
+          const f32x4 t1v = *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2 + 4);
           unsigned pk[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -708,16 +508,16 @@ __global__ __launch_bounds__(TH * CB * 64) void meta_bf16_kernel16(MetaArgs a) {
           }
           s16x8 bfrag;
           memcpy(&bfrag, pk, 16);
+          // MFMA #2: acc2[o][px] += A[o][(ch,k)] . a[ch]
 #pragma unroll
           for (int ot = 0; ot < 2; ++ot) {
-            const s16x8 af = *(const s16x8*)(a2w + ((((size_t)ot * 2 + mt) * 2 + s2) * 64 + lane) * 16);
+            const s16x8 af = *(const s16x8*)(a2l + (((k * 2 + ot) * 2 + mt) * 2 + s2) * 1024);
             acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
           }
         }
       }
-      wcommit((g + 1) & 1);      // slot (g+1)&1 was last read in tap g-1, which every wave left at the previous barrier
-      __syncthreads();           // tap g+1 may read its weights; after tap 8: every wave is done with this tile's halos
     }
+    // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
     if (live) {
       bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
 #pragma unroll

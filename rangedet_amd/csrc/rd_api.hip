@@ -50,16 +50,6 @@ inline void allow_big_lds(K kernel) {
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     (void)hipGetLastError();
 }
-template <int TH, int CB, bool PF>
-inline void launch_meta16(MetaArgs a, hipStream_t st) {
-  a.tiles_h = (a.H + TH - 1) / TH;
-  a.tiles_w = (a.W + 32 * CB - 1) / (32 * CB);
-  a.ntiles = a.B * a.tiles_h * a.tiles_w;
-  auto kern = meta_bf16_kernel16<TH, CB, PF>;
-  allow_big_lds(kern);
-  const size_t lds = M16Cfg<TH, CB>::LDS;
-  hipLaunchKernelGGL(kern, dim3(std::min(a.ntiles, conv_num_cus())), dim3(TH * CB * 64), lds, st, a);
-}
 inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4>);
   allow_big_lds(conv3x3_stream_kernel<2>);
@@ -411,15 +401,7 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t consts = 9 * 64 * 4 * 2 + 1024;
   ProfScope ps(RD_PROF_META, st);
-  // RD_META_VARIANT (dev switch, A/B): "8" = the 8-wave form with LDS-resident weights; "8x2p" / "8x2n" / "4x3p" / "4x3n" = the
-  // streaming-weights form with TH x CB waves, halo prefetched into registers (p) or loaded between tiles (n)
-  static const std::string mv = getenv("RD_META_VARIANT") ? getenv("RD_META_VARIANT") : "4x3p";
-  if (dtype == RD_BF16 && mv != "8") {
-    if (mv == "8x2p") launch_meta16<8, 2, true>(a, st);
-    else if (mv == "8x2n") launch_meta16<8, 2, false>(a, st);
-    else if (mv == "4x3n") launch_meta16<4, 3, false>(a, st);
-    else launch_meta16<4, 3, true>(a, st);
-  } else if (dtype == RD_BF16) {
+  if (dtype == RD_BF16) {
     const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
     allow_big_lds(meta_bf16_kernel<WAVES>);
     hipLaunchKernelGGL((meta_bf16_kernel<WAVES>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
@@ -558,8 +540,9 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const int R1 = 256, nb1 = R1 / 64;
   static const bool one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;   // dev switch (tools/wnms_bench.py)
   const bool two = Kcap >= 4 * R1 && !one_round;
-  // pair tiles are strided over a fixed number of single-wave workgroups: enough to fill the CUs a few waves deep
-  const int pgrid = std::max(64, 4096 / B);
+  // pair tiles are strided over a fixed number of single-wave workgroups per frame: one tile each at the pipeline's typical K
+  // (1 - 2 k rows: <= 2048 tiles per round), grid-strided beyond that -- so the launch size does not grow with the capacity
+  const int pgrid = std::min(2048, std::max(64, nb * WN_CT * std::min(nb, 16)));
   hipLaunchKernelGGL(wnms_pairs_kernel, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
                      thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)nullptr, (const int*)nullptr,
                      (const unsigned long long*)nullptr, 0, two ? nb1 : nb);

@@ -338,7 +338,7 @@ def test_full_size_f32_parity_vs_oracle(be):
         same = idx[b] == ref["sorted_idx"][b]
         print("frame %d: score maxerr %.2e; %d of %d rows separated by > %.1e; %d of %d sorted indices equal overall" %
               (b, e_s, ok.sum(), k, sep, same.sum(), k))
-        assert ok.sum() > k // 20 and same.mean() > 0.9
+        assert ok.sum() > 500 and same.mean() > 0.9
         assert np.array_equal(idx[b][ok], ref["sorted_idx"][b][ok])             # same points, same order
         e_b = np.abs(bx[b][ok] - ref["decoded_bbox"][b][ok]).max()
         # corners are centre +- exp(log l)/2 * cos/sin: d corner / d delta <= ~3 m for a car-sized box, so the bound is
