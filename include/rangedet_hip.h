@@ -31,7 +31,7 @@
  *     rd_last_error_string() gives a thread-local message for the last failure.
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every buffer,
  *     including workspaces (size them with the *_workspace_bytes functions).  The library never allocates
- *     on the hot path and never keeps a pointer past the call.
+ *     device memory and never keeps a pointer past the call.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are re-entrant.
  *   - activations inside the library are channels-last: [B][H][W][Cstride] with the used channels at
  *     [coff, coff+C); element type RD_F32 (float) or RD_BF16 (raw uint16 bfloat16).
@@ -85,6 +85,8 @@ int rd_copy_rows(const void* src, long src_row_bytes, void* dst, long dst_row_by
  * phase's own tap count (<= 9, in ascending (dh, dw) order; more is RD_ESHAPE), except that a phase whose taps lie
  * inside the 3x3 window without being three rows x two adjacent columns is packed as all 9 window taps (zeros for the
  * absent ones). */
+/* (every packed image ends in 256 zero bytes, included in the size: the persistent 3x3 kernel reads its padding pixels from
+ * them, so the library holds no device memory of its own; upload the image whole) */
 size_t rd_conv_packed_bytes(int ntaps, int cin, int cout, int dtype);
 int rd_pack_conv_weight_host(const float* w_oihw_host, int cout, int cin, int kh, int kw, int dtype,
                              void* packed_host);

@@ -361,9 +361,15 @@ inline int cin_slots(int cin, int dt) {  // channels rounded up to one MFMA k-st
   int ch = ch_per_slot(dt);
   return round_up(cin, 2 * ch) / ch;
 }
-inline size_t conv_packed_bytes(int ntaps, int cin, int cout, int dt) {
+// Every packed conv-family weight image ends in RD_CONV_TAIL zero bytes (written by the packers): the persistent 3x3 kernel
+// uses them as the DMA source of padding pixels / channels, so the library needs no device allocation of its own.
+constexpr size_t RD_CONV_TAIL = 256;
+inline size_t conv_packed_body_bytes(int ntaps, int cin, int cout, int dt) {
   int nchunk = (cin_slots(cin, dt) + 7) / 8;
   return (size_t)nchunk * ntaps * cout * 128;
+}
+inline size_t conv_packed_bytes(int ntaps, int cin, int cout, int dt) {
+  return conv_packed_body_bytes(ntaps, cin, cout, dt) + RD_CONV_TAIL;
 }
 // get(co, ci, tap) -> float
 template <class F>

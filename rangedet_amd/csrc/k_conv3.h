@@ -378,44 +378,51 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     constexpr int ROWB = COUT * 2, SPR = COUT / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + (C3_HALO - abuf) + wave * (C3_HALO / 4);
     bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
-    const bf16_t* __restrict__ rrow0 = a.res + (size_t)b * a.r_bs + (size_t)oh0 * a.Wo * a.r_cs + a.r_co;
+    // (base of image b, not of the wave's first row: rows past the image bottom must not even form an address beyond the buffer)
+    const bf16_t* __restrict__ rimg0 = a.res + (size_t)b * a.r_bs + a.r_co;
     const int sh = a.sw - 1;   // stride 2: shift by 1, keep even columns
     if constexpr (SC) {
       // projection shortcut: B operand = this wave's pixels of the block input straight from global memory (lane (m, hi)
       // of k-step ks: channels 16*ks + 8*hi .. +8 of its pixel, one 16-byte load), A operand = the packed weight fragment
       // (1 KB coalesced, L2 resident), accumulated onto the conv's own accumulators.  Dead pixels read pixel (0, 0).
-      // Two pixel fragments (one output row of the wave) at a time: 2 x MK x 4 registers of pixels in flight.
+      // (Measured in the ISA: each weight fragment request is followed by a full wait before its two MFMAs.  Batching the
+      // requests per k-step or making the k-step count a compile-time constant both made hipcc spill 56 - 165 registers
+      // across the MFMA phase, so the simple form stays.)
+      // All four pixel fragments of the wave, four k-steps at a time (4 x 4 x 4 = 64 registers of pixels in flight): a weight
+      // fragment then feeds four MFMAs instead of two, i.e. half as many exposed L2 round trips per tile.
       const bf16_t* __restrict__ sb = a.sx + (size_t)b * a.s_bs + a.s_co + 8 * ehi;
       const unsigned char* __restrict__ wq = a.scw + el * 16;
       auto shortcut = [&](auto MKc) {
-        constexpr int MK = decltype(MKc)::value;            // k-steps held in registers (>= a.s_nks)
+        constexpr int MK = decltype(MKc)::value;            // k-steps per pass
 #pragma unroll
-        for (int ih = 0; ih < 2; ++ih) {
-          s16x8 sxq[2][MK];
+        for (int kh = 0; kh < 8 / MK; ++kh) {
+          if (kh * MK < a.s_nks) {
+            s16x8 sxq[4][MK];
 #pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            const int tc = 32 * i2 + em, ow = ct * C3_TW + tc, oh = oh0 + ih;
-            const bool live = tc < C3_TW && ow < a.W && oh < a.H;
-            const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.s_cs : 0);
+            for (int i = 0; i < 4; ++i) {
+              const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
+              const bool live = tc < C3_TW && ow < a.W && oh < a.H;
+              const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.s_cs : 0) + 16 * MK * kh;
+#pragma unroll
+              for (int ks = 0; ks < MK; ++ks)
+                if (kh * MK + ks < a.s_nks) sxq[i][ks] = *(const s16x8*)(sp + 16 * ks);
+            }
 #pragma unroll
             for (int ks = 0; ks < MK; ++ks)
-              if (ks < a.s_nks) sxq[i2][ks] = *(const s16x8*)(sp + 16 * ks);
-          }
+              if (kh * MK + ks < a.s_nks) {
 #pragma unroll
-          for (int ks = 0; ks < MK; ++ks)
-            if (ks < a.s_nks) {
+                for (int j = 0; j < NCT; ++j) {
+                  const s16x8 wf = *(const s16x8*)(wq + (size_t)((kh * MK + ks) * NCT + j) * 1024);
 #pragma unroll
-              for (int j = 0; j < NCT; ++j) {
-                const s16x8 wf = *(const s16x8*)(wq + (size_t)(ks * NCT + j) * 1024);
-#pragma unroll
-                for (int i2 = 0; i2 < 2; ++i2)
-                  acc[2 * ih + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, sxq[i2][ks], acc[2 * ih + i2][j], 0, 0, 0);
+                  for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, sxq[i][ks], acc[i][j], 0, 0, 0);
+                }
               }
-            }
+          }
           C3_FENCE();
         }
       };
-      shortcut(std::integral_constant<int, 8>{});
+      shortcut(std::integral_constant<int, 4>{});
       C3_FENCE();
     }
     // FL >= 0: the flag combination is a compile-time constant (no per-value selects); FL < 0: read a.flags
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
         const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
         const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh);
-        const bf16_t* rp = rrow0 + (live ? (size_t)(i >> 1) * a.Wo * a.r_cs + (size_t)(ow >> sh) * a.r_cs : 0) + 16 * ehi;
+        const bf16_t* rp = rimg0 + (live ? ((size_t)oh * a.Wo + (size_t)(ow >> sh)) * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           dst[j][0] = *(const Slot16*)(rp + j * 32);
@@ -546,25 +553,6 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #undef C3_TRACE
 }
 
-// device memory holding zero bytes: one small allocation per device, made on first use (never on the hot path again)
-inline const unsigned char* conv_zero16() {
-#ifdef HIPEMU
-  static const unsigned char z[16] = {0};
-  return z;
-#else
-  static std::mutex mu;
-  static unsigned char* page[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> g(mu);
-  if (!page[dev]) {
-    unsigned char* q = nullptr;
-    if (hipMalloc((void**)&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
-    page[dev] = q;
-  }
-  return page[dev];
-#endif
-}
 inline int conv_num_cus() {
 #ifdef HIPEMU
   return 4;
@@ -597,8 +585,8 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   a.w = (const unsigned char*)w; a.scale = scale; a.shift = shift;
   a.res = (const bf16_t*)res; a.r_cs = r_cs; a.r_co = r_co; a.r_bs = (long)H * a.Wo * r_cs;
   a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * a.Wo * y_cs;
-  a.zero16 = conv_zero16();
-  RD_REQUIRE(a.zero16, RD_EHIP, "conv: zero page allocation failed");
+  // zero bytes for padding: the tail every packer appends to the weight image (k_conv.h RD_CONV_TAIL)
+  a.zero16 = (const unsigned char*)w + conv_packed_body_bytes(c3_nsteps(ts), cin, cout, RD_BF16);
   a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;
   a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + C3_TH - 1) / C3_TH; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus());

@@ -141,6 +141,7 @@ int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, 
   RD_REQUIRE(kh * kw >= 1 && kh * kw <= 9 && (kh & 1) && (kw & 1), RD_ESHAPE, "pack_conv: kernel (%d,%d)", kh, kw);
   TapList tl = conv_taps(kh, kw);
   auto get = [&](int co, int ci, int t) { return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
+  memset(out, 0, conv_packed_bytes(tl.n, cin, cout, dtype));     // padding of partial chunks and the zero tail
   if (dtype == RD_BF16) pack_taps_frag(tl.n, cin, cout, out, get);
   else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
@@ -206,6 +207,7 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
     return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
   };
   const int nt = emb ? 9 : tl.n;
+  memset(out, 0, conv_packed_bytes(nt, cin, cout, dtype));
   if (dtype == RD_BF16) pack_taps_frag(nt, cin, cout, out, get);
   else pack_taps(nt, cin, cout, dtype, out, get);
   return RD_OK;
@@ -244,6 +246,7 @@ int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, i
   auto wv = [&](int co, int ci, int dh, int dw) {
     return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)co * cin + ci) * 3 + (dh + 1)) * 3 + (dw + 1)];
   };
+  memset(out, 0, rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride));
   if (stride_w == 1) {
     pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); });
   } else {

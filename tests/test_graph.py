@@ -338,8 +338,13 @@ def test_full_size_f32_parity_vs_oracle(be):
         same = idx[b] == ref["sorted_idx"][b]
         print("frame %d: score maxerr %.2e; %d of %d rows separated by > %.1e; %d of %d sorted indices equal overall" %
               (b, e_s, ok.sum(), k, sep, same.sum(), k))
-        assert ok.sum() > 500 and same.mean() > 0.9
+        assert ok.sum() > 500 and same.mean() > 0.8
         assert np.array_equal(idx[b][ok], ref["sorted_idx"][b][ok])             # same points, same order
+        # ... and EVERY row picked by the HIP path is a legitimate pick: its oracle score equals the oracle's score at that
+        # sorted position up to the fp32 noise (rows that differ are swaps inside groups of numerically tied scores)
+        mask = np.concatenate([fr["range_image_mask_s%d" % s_] for s_ in (1, 2, 4)], 1)[b]
+        full = (1.0 / (1.0 + np.exp(-ref["logit"][b].astype(np.float64)))) * mask
+        assert np.abs(full[idx[b]] - rs).max() < 4 * e_s + 1e-7
         e_b = np.abs(bx[b][ok] - ref["decoded_bbox"][b][ok]).max()
         # corners are centre +- exp(log l)/2 * cos/sin: d corner / d delta <= ~3 m for a car-sized box, so the bound is
         # 1e-4 (libm) + 3 * (measured delta error)
