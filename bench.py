@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (pipelines on separate streams)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
+    ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
+                    help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
     ap.add_argument("--wnms-cap", type=int, default=8192, help="rows per frame the weighted NMS is sized for (checked every step)")
     args = ap.parse_args()
 
@@ -178,7 +180,8 @@ def main():
 
     params = synth.make_weights(seed=18)
     Bf = args.batch
-    multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=args.wnms_cap, batch=Bf)
+    multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=args.wnms_cap, batch=Bf,
+                                 tie_order=args.tie_order)
     pipe = multi.pipes[0]   # (per-kernel profiling replay and the roofline figures use one pipeline on the default stream)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
     # (synthetic raw records through the device transform chain, rd_input_transform)
@@ -320,7 +323,7 @@ def main():
                                    "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, %d frames per step per GPU, " % Bf + ""
                                    "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "batches_in_flight_per_gpu": len(multi.pipes), "parallelism": "frame-parallel dp%d" % world,
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"])),
-                       "wnms_cap": int(pipe.bpost.cap), "max_candidates_seen": int(max_cand[0]),
+                       "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames},
             "roofline": roof, "meta_kernel": meta_info, "meta_dla_forward": backbone_info,

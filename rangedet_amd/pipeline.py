@@ -192,9 +192,14 @@ class _FrameView:
 
 class RangeDetPipeline:
     def __init__(self, params, dtype=rdlib.RD_BF16, feat_size=(64, 2650), pad_field=(64, 2656), batch=1,
-                 pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None, wnms=True):
+                 pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None, wnms=True, tie_order="reference",
+                 hash_scale=100):
         """wnms=False builds the graph with contrib.NMS3D inside (RpnParam.wnms = False, builder.py:530-534) and runs the
-        matching harness branch (tools/test.py:193-196) instead of the weighted NMS."""
+        matching harness branch (tools/test.py:193-196) instead of the weighted NMS.
+        tie_order: "reference" = rows with equal scores are processed in the order the reference's std::sort leaves them
+        (nms.h:786-792, replayed on the device); "stable" = in index order (no extra kernel).  hash_scale: the BBoxHash cell
+        size tools/test.py:216 passes (100).  wnms_cap: rows per frame the weighted NMS is sized for; collect() raises when a
+        frame had more candidates above min_score (the device never truncates silently: the true count comes back)."""
         self.cfg = cfgmod.get_config(False, variant=variant, feat_size=feat_size, pad_field=pad_field,
                                      batch_image=batch, pre_nms_top_n={variant: pre_nms_top_n}, wnms=wnms)
         self.wnms = bool(wnms)
@@ -210,7 +215,8 @@ class RangeDetPipeline:
         self._filter_done = None
         if self.wnms:
             self.bpost = BatchPostProcessor(batch, self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
-                                            TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap)
+                                            TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap, hash_scale=hash_scale,
+                                            tie_order=tie_order)
         else:
             self.bpost = Nms3dPostProcessor(batch, self.k, RpnParam.all_proposal.rpn_post_nms_top_n[cname],
                                             TestParam.min_score[cname], self.lib, self.alloc)

@@ -1,8 +1,15 @@
+# Round profile (run on the GPU box through gpurun): bench line, rocprofv3 kernel-trace stats with one and two batches in
+# flight, PMC passes (separate --pmc runs, kernel-trace only), per-plan-step timing.  Results under gpurun_out/p; copy the
+# summaries into profiles/ (see profiles/README.md).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/p
-timeout -s KILL 300 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/p/bench.json
+timeout -s KILL 400 python bench.py --steps 100 --warmup 5 2>/dev/null | tail -1 > gpurun_out/p/bench.json
 # per-kernel durations: one batch in flight (kernels of two batches overlapping would inflate each other's durations; the
 # bench's roofline block times its kernels in a serial replay on one stream, which is what this pass must agree with)
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > gpurun_out/p/stats.log 2>&1
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats2 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/p/stats2.log 2>&1
-i=0; for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do i=$((i+1)); timeout -s KILL 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/p/pmc$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > gpurun_out/p/pmc$i.log 2>&1; done
-find gpurun_out/p -name "*.csv" | head -20; du -sh gpurun_out/p
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > gpurun_out/p/stats.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats2 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/p/stats2.log 2>&1
+i=0; for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do i=$((i+1)); timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/p/pmc$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > gpurun_out/p/pmc$i.log 2>&1; done
+python tools/pmc_summary.py 8 gpurun_out/p/pmc1 gpurun_out/p/pmc2 gpurun_out/p/pmc3 > gpurun_out/p/pmc_traffic.json 2>gpurun_out/p/pmc_summary.err
+timeout -s KILL 200 python tools/profile_steps.py bf16 3 8 > gpurun_out/p/steps.txt 2>&1
+for d in stats stats2; do f=$(find gpurun_out/p/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/p/${d}_kernel_stats.csv; done
+rm -rf gpurun_out/p/pmc1 gpurun_out/p/pmc2 gpurun_out/p/pmc3 gpurun_out/p/stats gpurun_out/p/stats2
+ls -la gpurun_out/p; tail -c 400 gpurun_out/p/bench.json
