@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void wnms_merge_big_kernel(const float* __restr
 // finished ranges are insertion-sorted independently, one lane per range.  Strictly decreasing input (the common case in
 // the pipeline: rows arrive sorted, ties are rare) is recognised up front: every correct sort returns the identity.
 struct TieSort {
-  float* sc; int* ix; unsigned* segbit; int n, lane; bool fence;
+  float* sc; int* ix; unsigned* segbit; unsigned* tmbit; unsigned* idbit; int n, lane; bool fence;
   __device__ __forceinline__ void sync() const {
     if (fence) __threadfence();
     __builtin_amdgcn_wave_barrier();
@@ -697,18 +697,36 @@ struct TieSort {
       adjust_heap(first, 0, l - first, vs, vi);
     }
   }
-  __device__ void run(int* stack) const {
+  // SORTED INPUT (the pipeline's case: rows arrive in score order, ties are few).  A range that holds no member of a tie
+  // group ends, whatever introsort does inside it, as the identity: a correct sort puts an element without a tie partner
+  // at its rank, and in sorted input rank == index.  Such ranges are not replayed at all (idbit: filled with p -> p at the
+  // end); only ranges that contain tied rows are -- a few dozen partitions instead of K / 12.
+  __device__ bool has_tie(int f, int l) const {
+    for (int p0 = f; p0 < l; p0 += 64) {
+      const int p = p0 + lane;
+      const int i = p < l ? ix[p] : 0;
+      const bool t = p < l && ((tmbit[i >> 5] >> (i & 31)) & 1u);
+      if (__ballot(t)) return true;
+    }
+    return false;
+  }
+  __device__ void run(int* stack, bool sorted_input) const {
     if (n < 2) return;
     int sp = 0, first = 0, last = n, depth = 2 * (31 - __clz(n));
     for (;;) {
-      while (last - first > 16) {                                      // __introsort_loop
+      bool skipped = sorted_input && !has_tie(first, last);
+      while (!skipped && last - first > 16) {                          // __introsort_loop
         if (depth == 0) { heap_sort(first, last); break; }
         --depth;
         const int cut = partition_pivot(first, last);
         stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; ++sp;
         last = cut;
+        skipped = sorted_input && !has_tie(first, last);
       }
-      if (first < n) mark(first);
+      if (first < n && lane == 0) {
+        segbit[first >> 5] |= 1u << (first & 31);
+        if (skipped) idbit[first >> 5] |= 1u << (first & 31);
+      }
       if (sp == 0) break;
       --sp;
       first = stack[3 * sp]; last = stack[3 * sp + 1]; depth = stack[3 * sp + 2];
@@ -718,8 +736,10 @@ struct TieSort {
     const int nwords = (n + 31) >> 5;
     for (int w = lane; w < nwords; w += 64) {
       unsigned bits = segbit[w];
+      const unsigned idb = idbit[w];
       while (bits) {
-        const int s = (w << 5) + __ffs(bits) - 1;
+        const int b0 = __ffs(bits) - 1;
+        const int s = (w << 5) + b0;
         bits &= bits - 1u;
         int e = n;                                                      // next range start
         {
@@ -727,6 +747,10 @@ struct TieSort {
           int ww = w;
           while (!rest && ++ww < nwords) rest = segbit[ww];
           if (rest) e = (ww << 5) + __ffs(rest) - 1;
+        }
+        if ((idb >> b0) & 1u) {
+          for (int i = s; i < e; ++i) ix[i] = i;
+          continue;
         }
         for (int i = s + 1; i < e; ++i) {
           const float v = sc[i]; const int vi = ix[i];
@@ -748,27 +772,45 @@ __global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restr
   dets += blockIdx.z * bs.dets; order += blockIdx.z * order_stride; scratch += blockIdx.z * bs.ints;
   const int lane = threadIdx.x;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
-  // identity for the unused tail; strictly decreasing scores -> identity everywhere
-  int unsorted = 0;
+  // identity for the unused tail; strictly decreasing scores -> identity everywhere; non-increasing (sorted with ties) ->
+  // only the ranges holding tied rows are replayed
+  int tied = 0, rising = 0;
   for (int i = lane; i < cap; i += 64) {
     order[i] = i;
-    if (i + 1 < K && !(dets[(size_t)i * 12 + 11] > dets[(size_t)(i + 1) * 12 + 11])) unsorted = 1;
+    if (i + 1 < K) {
+      const float a0 = dets[(size_t)i * 12 + 11], a1 = dets[(size_t)(i + 1) * 12 + 11];
+      if (a0 == a1) tied = 1;
+      else if (!(a0 > a1)) rising = 1;
+    }
   }
-  if (!__ballot(unsorted)) return;
-  int* stack = (int*)smem;                       // [3 * 40] introsort range stack, then (LDS variant) keys / indices / bitmap
+  const bool any_tied = __ballot(tied) != 0ull, any_rising = __ballot(rising) != 0ull;
+  if (!any_tied && !any_rising) return;
+  int* stack = (int*)smem;                       // [3 * 40] introsort range stack, then (LDS variant) keys / indices / bitmaps
   unsigned char* lds = smem + TIE_STACK_BYTES;
   TieSort T;
   T.n = K; T.lane = lane;
-  const int nbit = (K + 31) >> 5;
+  const int nbit = (K + 31) >> 5, nbcap = cap / 32 + 2;
   if (cap <= TIE_LDS_K) {
     T.sc = (float*)lds; T.ix = (int*)(lds + (size_t)cap * 4); T.segbit = (unsigned*)(lds + (size_t)cap * 8); T.fence = false;
   } else {
     T.sc = (float*)scratch; T.ix = scratch + cap; T.segbit = (unsigned*)(scratch + 2 * (size_t)cap); T.fence = true;
   }
+  T.tmbit = T.segbit + nbcap; T.idbit = T.tmbit + nbcap;
   for (int i = lane; i < K; i += 64) { T.sc[i] = dets[(size_t)i * 12 + 11]; T.ix[i] = i; }
-  for (int i = lane; i < nbit; i += 64) T.segbit[i] = 0u;
+  for (int i = lane; i < nbit; i += 64) { T.segbit[i] = 0u; T.tmbit[i] = 0u; T.idbit[i] = 0u; }
   T.sync();
-  T.run(stack);
+  if (!any_rising) {   // tie membership by original index: a row whose score equals a neighbour's
+    for (int w = lane; w < nbit; w += 64) {
+      unsigned bits = 0u;
+      for (int b = 0; b < 32; ++b) {
+        const int i = (w << 5) + b;
+        if (i < K && ((i > 0 && T.sc[i] == T.sc[i - 1]) || (i + 1 < K && T.sc[i] == T.sc[i + 1]))) bits |= 1u << b;
+      }
+      T.tmbit[w] = bits;
+    }
+    T.sync();
+  }
+  T.run(stack, !any_rising);
   for (int i = lane; i < K; i += 64) order[i] = T.ix[i];
 }
 

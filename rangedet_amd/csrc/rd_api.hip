@@ -21,7 +21,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t wnms_ws_bytes(int cap) {
   const size_t nw = (size_t)(cap + 63) / 64;
   return align256((size_t)cap * PREP_F * 4) + 3 * align256((size_t)cap * nw * 8) + 4 * align256((size_t)cap * 4) +
-         align256(((size_t)cap + 2) * 8 + ((size_t)cap / 32 + 2) * 4) + align256(nw * 8) + 256 + align256(sort_ws_bytes(cap)) + 256;
+         align256(((size_t)cap + 2) * 8 + 3 * ((size_t)cap / 32 + 2) * 4) + align256(nw * 8) + 256 + align256(sort_ws_bytes(cap)) + 256;
 }
 inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   WnmsWs w;
@@ -37,7 +37,7 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   w.alive = (int*)p; p += align256((size_t)cap * 4);
   w.ovf = (int*)p; p += align256((size_t)cap * 4);
   // merge overflow list / tie-order keys (cap + 2 ints + cap + 2 floats, or cap floats + cap ints + a cap-bit map)
-  w.scratch = (int*)p; p += align256(((size_t)cap + 2) * 8 + ((size_t)cap / 32 + 2) * 4);
+  w.scratch = (int*)p; p += align256(((size_t)cap + 2) * 8 + 3 * ((size_t)cap / 32 + 2) * 4);
   w.supp_state = (unsigned long long*)p; p += align256(nw * 8);
   w.nalive = (int*)p; w.novf = (int*)p + 1; p += 256;
   w.sort_ws = p;
@@ -510,7 +510,7 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   bs.ints = (long)(per / 4); bs.keep = keep_bstride; bs.out = out_bstride;
   const int* ord = order;
   if (!ord && tie_order == RD_TIE_REFERENCE) {   // the reference's own order: std::sort replayed on the device
-    const size_t lds = TIE_STACK_BYTES + (Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + ((size_t)Kcap / 32 + 2) * 4 : 0);
+    const size_t lds = TIE_STACK_BYTES + (Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + 3 * ((size_t)Kcap / 32 + 2) * 4 : 0);
     allow_big_lds(wnms_tie_order_kernel);
     hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(64), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
                        w.scratch);

@@ -510,6 +510,12 @@ def test_tie_order_replays_std_sort(be):
         cases.append(-np.sort(-q))                            # sorted, ties
         cases.append(np.full(n, 0.75, np.float32))            # all equal
         cases.append(-np.sort(-rng.uniform(0.5, 1, n).astype(np.float32)))   # strictly sorted: identity fast path
+    for n, ng in ((500, 1), (900, 3), (1500, 6), (1500, 40), (2500, 10), (3000, 2)):   # the pipeline's regime: sorted, a few ties
+        q = -np.sort(-rng.uniform(0.5, 1, n).astype(np.float32))
+        for _ in range(ng):
+            j, g = int(rng.integers(0, n - 4)), int(rng.integers(2, 5))
+            q[j:j + g] = q[j]
+        cases.append(q)
     cases.append(O.antiqsort_keys(600))                       # adversarial input: depth limit reached -> heap sort
     cases.append(O.antiqsort_keys(2000))
     for sc in cases:
