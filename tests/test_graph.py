@@ -358,8 +358,13 @@ def test_full_size_f32_parity_vs_oracle(be):
         # and against the oracle's own end-to-end result (inputs differ by the <=1e-4 box error): same survivors
         dets_r, rows_r, keep_r, d8_r = G.postprocess(ref["fg_cls_score"][b], ref["decoded_bbox"][b])
         print("frame %d: %d candidates, %d kept (oracle end to end: %d, %d)" % (b, dets.shape[0], len(keep), dets_r.shape[0], len(keep_r)))
-        assert dets.shape[0] == dets_r.shape[0] and list(keep) == list(keep_r)
-        assert np.abs(got["det_xyzlwhyaws"] - d8_r).max() < 2e-3
+        # (row numbers refer to each run's own candidate list, in which rows with numerically tied scores may be swapped:
+        # compare the surviving BOXES -- a one-to-one match within the box tolerance)
+        assert dets.shape[0] == dets_r.shape[0] and len(keep) == len(keep_r)
+        dist = np.abs(got["det_xyzlwhyaws"][:, None, :] - d8_r[None, :, :]).max(axis=2)
+        match = dist.argmin(axis=1)
+        assert dist.min(axis=1).max() < 2e-3 and len(set(match.tolist())) == len(keep_r)
+        assert (np.asarray(keep) != np.asarray(keep_r)).sum() <= 4               # identical but for a few swapped neighbours
 
 
 # bf16 error model for the tolerance below: every conv layer rounds its output activation to bf16 (relative 2^-9, uniform ->
