@@ -59,6 +59,9 @@ extern "C" {
 #define RD_RELU_PRE 1  /* ReLU directly after the BN affine (before the residual add)        */
 #define RD_ADD 2       /* add `residual`                                                     */
 #define RD_RELU_POST 4 /* ReLU after the residual add                                        */
+#define RD_SCALE_FOLDED 8 /* bf16 3x3 family only: the packer folded the BatchNorm scale into the weights (fold_scale argument of
+                           * the packers); `scale` must be NULL.  The shift then enters the accumulators through one extra MFMA
+                           * per accumulator and the epilogue has no multiply-add (what the production lowering uses) */
 
 int rd_version(void);
 const char* rd_last_error_string(void);
@@ -93,6 +96,9 @@ int rd_pack_conv_weight_host(const float* w_oihw_host, int cout, int cin, int kh
 int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase);
 int rd_pack_deconv_weight_host(const float* w_iohw_host, int cin, int cout, int kh, int kw, int stride_w,
                                int pad_w, int phase, int dtype, void* packed_host);
+/* the same with fold_scale_host (cout) multiplied into the weights before rounding (for RD_SCALE_FOLDED launches; NULL = none) */
+int rd_pack_deconv_weight_folded_host(const float* w_iohw_host, const float* fold_scale_host, int cin, int cout, int kh, int kw,
+                                      int stride_w, int pad_w, int phase, int dtype, void* packed_host);
 
 /* ---- conv family ------------------------------------------------------------------------------------ */
 /* y = act( scale[c]*conv(x, w) + shift[c] (+ residual) ).  stride_h == 1 always (the backbone strides W

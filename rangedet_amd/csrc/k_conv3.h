@@ -142,7 +142,11 @@ constexpr int c3_younger(int R, int IPW, int s, int NS) {
 // That conv is applied to each 32-pixel fragment while it sits, already rounded to bf16, in the epilogue's transpose
 // scratch (same LDS image and MFMA scheme as head_out_mfma_kernel, k_misc.h: weights as a bf16 hi + lo pair), and the
 // 128-channel result is never written to HBM.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false>
+// FOLD: the BatchNorm scale is folded into the packed weights (a.scale == nullptr) and the shift enters the accumulators
+// through one rank-1 MFMA per accumulator at the start of every tile (A = the shift as a bf16 high + low pair in k = 0, 1;
+// B = ones) -- 4 * NCT MFMAs of the tile's 36 * 8 * NCT..., in exchange for which the epilogue has no multiply-add left:
+// it reads the accumulators, adds the residual if any, converts and clamps.
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   static_assert(!HEAD || (NCT == 4 && TS == 0), "fused output conv: cout 128, all nine taps");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
@@ -160,6 +164,18 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   if (tid < COUT) {
     Sc[tid] = a.scale ? a.scale[tid] : 1.f;
     Sc[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
+  // FOLD: per channel block j the dword {bf16 hi, bf16 lo} of this lane's shift (A-operand row m = channel
+  // 32*j + conv_row_perm(m), k = 0 and 1 live in the hi == 0 half of the wave), and the B operand of ones
+  unsigned bzw[NCT];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) {
+      const float t = a.shift ? a.shift[32 * j + conv_row_perm(m)] : 0.f;
+      const bf16_t th = f32_to_bf16(t);
+      const bf16_t tl = f32_to_bf16(t - bf16_to_f32(th));
+      bzw[j] = hi ? 0u : ((unsigned)th | ((unsigned)tl << 16));
+    }
   }
   int tpt = 0;
 #define C3_TRACE() { if (a.trace && tid == 0 && tpt < 7) a.trace[(size_t)blockIdx.x * 8 + tpt++] = wall_clock64(); }
@@ -350,8 +366,25 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   }
 
   for (int k = 0; k < ntl; ++k) {
-    {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0
-      C3_STEP_(0, C3_MMZ) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
+    {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
+      if constexpr (FOLD) {
+        const unsigned one2 = hi ? 0u : 0x3F803F80u;            // B: k = 0, 1 -> 1.0 (bf16), the rest 0
+        unsigned ob[4] = {one2, 0u, 0u, 0u};
+        s16x8 ones;
+        memcpy(&ones, ob, 16);
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {
+          unsigned ab[4] = {bzw[n % NCT], 0u, 0u, 0u};
+          s16x8 bz;
+          memcpy(&bz, ab, 16);
+          acc[n / NCT][n % NCT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bz, ones, f32x16{}, 0, 0, 0);
+        }
+        C3_FENCE();
+        C3_STEP(0)
+      } else {
+        C3_STEP_(0, C3_MMZ)
+      }
+      C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
       abuf = C3_HALO - abuf;
     }
@@ -461,8 +494,10 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
           sh[g4] = *(const f32x4*)(Sc + COUT + j * 32 + 16 * ehi + 4 * g4);
         }
       };
-      sc_load(0, scq[0], shq[0]);
-      if constexpr (SC_HOIST) sc_load(1, scq[1], shq[1]);
+      if constexpr (!FOLD) {
+        sc_load(0, scq[0], shq[0]);
+        if constexpr (SC_HOIST) sc_load(1, scq[1], shq[1]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (do_add && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
@@ -470,7 +505,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         for (int j = 0; j < NCT; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
           const int cur = SC_HOIST ? j : (i * NCT + j) & 1;
-          if constexpr (!SC_HOIST) sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
+          if constexpr (!SC_HOIST && !FOLD) sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
           const int cb = j * 32 + 16 * ehi;
           unsigned pk[8];
 #pragma unroll
@@ -479,9 +514,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
             for (int h2 = 0; h2 < 2; ++h2) {
               const int r = 4 * g4 + 2 * h2;
               const f32x2 av = {acc[i][j][r], acc[i][j][r + 1]};
-              const f32x2 s2 = {scq[cur][g4][2 * h2], scq[cur][g4][2 * h2 + 1]};
-              const f32x2 t2 = {shq[cur][g4][2 * h2], shq[cur][g4][2 * h2 + 1]};
-              f32x2 v = av * s2 + t2;                                  // v_pk_fma_f32
+              f32x2 v = av;                                            // FOLD: scale in the weights, shift in the accumulator
+              if constexpr (!FOLD) {
+                const f32x2 s2 = {scq[cur][g4][2 * h2], scq[cur][g4][2 * h2 + 1]};
+                const f32x2 t2 = {shq[cur][g4][2 * h2], shq[cur][g4][2 * h2 + 1]};
+                v = av * s2 + t2;                                      // v_pk_fma_f32
+              }
               if (relu_f32) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
               if (do_add) {   // bf16 -> f32 is a 16-bit shift of the packed pair
                 const unsigned w2 = rv[i & 1][j][r >> 3][(r >> 1) & 3];
@@ -579,6 +617,9 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   memset(&a, 0, sizeof(a));
   if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
   const bool sc = head && head->sx;
+  const bool fold = (flags & RD_SCALE_FOLDED) != 0;
+  RD_REQUIRE(!fold || !scale, RD_EINVAL, "conv3: RD_SCALE_FOLDED takes no scale array (the packer folded it into the weights)");
+  flags &= ~RD_SCALE_FOLDED;
   if (sc) { a.sx = head->sx; a.s_cs = head->s_cs; a.s_co = head->s_co; a.s_bs = head->s_bs; a.scw = head->scw; a.s_nks = head->s_nks; }
   a.sw = sw; a.Wo = (W - 1) / sw + 1;
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
@@ -587,7 +628,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * a.Wo * y_cs;
   // zero bytes for padding: the tail every packer appends to the weight image (k_conv.h RD_CONV_TAIL)
   a.zero16 = (const unsigned char*)w + conv_packed_body_bytes(c3_nsteps(ts), cin, cout, RD_BF16);
-  a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;
+  a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;   // (without RD_SCALE_FOLDED)
   a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + C3_TH - 1) / C3_TH; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus());
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
@@ -600,19 +641,25 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
 #endif
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
-#define C3_LAUNCH_SC(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
+    RD_REQUIRE(fold, RD_EINVAL, "conv3 + shortcut: the weights must carry the folded scales (RD_SCALE_FOLDED)");
+#define C3_LAUNCH_SC(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, true, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
     if (cout == 128) { if (ts == 0) C3_LAUNCH_SC(4, 0); else C3_LAUNCH_SC(4, 1); }
     else { if (ts == 0) C3_LAUNCH_SC(2, 0); else C3_LAUNCH_SC(2, 1); }
 #undef C3_LAUNCH_SC
     return check_launch("conv3x3_stream_kernel<sc>");
   }
   if (head) {
-    hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
+    if (fold) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true, false, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
     return check_launch("conv3x3_stream_kernel<head>");
   }
-#define C3_LAUNCH(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
-  if (cout == 128) { if (ts == 0) C3_LAUNCH(4, 0); else if (ts == 1) C3_LAUNCH(4, 1); else C3_LAUNCH(4, 2); }
-  else { if (ts == 0) C3_LAUNCH(2, 0); else if (ts == 1) C3_LAUNCH(2, 1); else C3_LAUNCH(2, 2); }
+#define C3_LAUNCH(N, T_)                                                                                                        \
+  {                                                                                                                             \
+    if (fold) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, false, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a); \
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a);                     \
+  }
+  if (cout == 128) { if (ts == 0) C3_LAUNCH(4, 0) else if (ts == 1) C3_LAUNCH(4, 1) else C3_LAUNCH(4, 2) }
+  else { if (ts == 0) C3_LAUNCH(2, 0) else if (ts == 1) C3_LAUNCH(2, 1) else C3_LAUNCH(2, 2) }
 #undef C3_LAUNCH
   return check_launch("conv3x3_stream_kernel");
 }

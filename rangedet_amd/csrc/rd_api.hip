@@ -58,10 +58,17 @@ inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<2, 0, 1>);
   allow_big_lds(conv3x3_stream_kernel<2, 0, 2>);
   allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 2, false, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, false, true>);
+  allow_big_lds(conv3x3_stream_kernel<2, 0, 2, false, false, true>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
@@ -190,6 +197,10 @@ int rd_deconv_phase_taps(int kh, int kw, int stride_w, int pad_w, int phase) {
 }
 int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
                                int phase, int dtype, void* out) {
+  return rd_pack_deconv_weight_folded_host(w, nullptr, cin, cout, kh, kw, stride_w, pad_w, phase, dtype, out);
+}
+int rd_pack_deconv_weight_folded_host(const float* w, const float* fold_scale, int cin, int cout, int kh, int kw, int stride_w,
+                                      int pad_w, int phase, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_deconv: null pointer");
   RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_deconv: dtype");
   RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
@@ -204,7 +215,7 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
       if (src < 0) return 0.f;
       t = src;
     }
-    return w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
+    return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)ci * cout + co) * kh + tl.kh[t]) * kw + tl.kw[t]];
   };
   const int nt = emb ? 9 : tl.n;
   memset(out, 0, conv_packed_bytes(nt, cin, cout, dtype));
@@ -224,6 +235,7 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
   RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "conv2d: y channels exceed stride");
   const int pad = (kw - 1) / 2;
   const int Wout = (Win + 2 * pad - kw) / stride_w + 1;  // mx Convolution output size
+  RD_REQUIRE(!(flags & RD_SCALE_FOLDED), RD_EINVAL, "conv2d: RD_SCALE_FOLDED is taken by rd_conv3x3_bn_act_ex / rd_conv2d_bn_act_head_out / rd_deconv2d_bn_act");
   TapList tl = conv_taps(kh, kw);
   allow_conv_lds();
   return launch_conv(tl, x, x_cstride, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride,
@@ -291,7 +303,9 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
     e.sx = (const bf16_t*)sc_x; e.s_cs = sc_cstride * v; e.s_co = sc_coff; e.s_bs = (long)H * Wv * sc_cstride * v;
     e.scw = (const unsigned char*)sc_w_packed; e.s_nks = (sc_cin + 15) / 16;
     fl &= ~RD_ADD;                             // the add happens on the accumulators
+    fl |= RD_SCALE_FOLDED;                     // (both scales are in the two weight sets)
   }
+  RD_REQUIRE(!(fl & RD_SCALE_FOLDED) || !scale, RD_EINVAL, "conv3x3_ex: folded weights take no scale array");
   return launch_conv3(x, x_cstride * v, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride, y_coff, B, H,
                       Wv, ex_view_cin(cin, x_cstride, stride_w), cout, fl, 1, (hipStream_t)stream, stride_w == 2 ? 1 : 0,
                       sc_x ? &e : nullptr);
@@ -347,6 +361,8 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
                           cout, flags, 1, (hipStream_t)stream, ts, nullptr);
     }
   }
+  RD_REQUIRE(!(flags & RD_SCALE_FOLDED), RD_ESHAPE, "deconv2d: RD_SCALE_FOLDED needs the persistent 3x3 kernel (bf16, cout 64/128, "
+             "taps inside the 3x3 window, Wout == stride_w * Win)");
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
                      y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
                      (hipStream_t)stream);

@@ -12,7 +12,7 @@ import numpy as np
 
 RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
 RD_F32, RD_BF16 = 0, 1
-RD_RELU_PRE, RD_ADD, RD_RELU_POST = 1, 2, 4
+RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED = 1, 2, 4, 8
 RD_WNMS_MAX_K = 65536
 RD_TIE_STABLE, RD_TIE_REFERENCE = 0, 1
 PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7}
@@ -34,6 +34,7 @@ SIGNATURES = {
     "rd_pack_conv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_deconv_phase_taps": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "rd_pack_deconv_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_pack_deconv_weight_folded_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_ex_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -166,15 +167,16 @@ class Lib:
         self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, out.ctypes.data)
         return out
 
-    def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype):
+    def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype, fold_scale=None):
         w = np.ascontiguousarray(w_iohw, dtype=np.float32)
         cin, cout, kh, kw = w.shape
         nt = self.cdll.rd_deconv_phase_taps(kh, kw, stride_w, pad_w, phase)
         if nt < 0:
             raise RangeDetError(nt, "deconv phase taps")
         out = np.zeros(self.cdll.rd_conv_packed_bytes(nt, cin, cout, dtype), dtype=np.uint8)
-        self.call("rd_pack_deconv_weight_host", w.ctypes.data, cin, cout, kh, kw, stride_w, pad_w, phase, dtype,
-                  out.ctypes.data)
+        fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
+        self.call("rd_pack_deconv_weight_folded_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cin, cout, kh, kw,
+                  stride_w, pad_w, phase, dtype, out.ctypes.data)
         return out
 
     def pack_head_weight(self, w):

@@ -210,15 +210,18 @@ class Lowering:
             raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
         out = self._out(cout, x.H, Wout, dest)
         # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
-        ex = self.dtype == RD_BF16 and k == (3, 3) and (sc is not None or (sw == 2 and x.W % 2 == 0 and
-                                                                             not os.environ.get("RD_NO_S2_VIEW")))
+        # and, unless RD_NO_FOLD is set, every bf16 3x3 conv with the BatchNorm scale folded into its weights (RD_SCALE_FOLDED)
+        fold = self.dtype == RD_BF16 and k == (3, 3) and not os.environ.get("RD_NO_FOLD")
+        s2view = sw == 2 and x.W % 2 == 0 and not os.environ.get("RD_NO_S2_VIEW")
+        ex = self.dtype == RD_BF16 and k == (3, 3) and (sc is not None or s2view or (fold and sw == 1))
+        kw_fold = dict(fold=bool(ex and (fold or sc is not None)), s2view=bool(ex and s2view))
         kw = {}
         if sc is not None:
             scx = self.emit_act(sc[0].inputs[0])
             kw["sc"] = dict(name=sc[0].name, bn=sc[1].name, eps=sc[1].attrs["eps"], cin=scx.C, cmap=scx.cmap)
             kw["sc_x"] = scx                      # top level: the executor's buffer liveness pass looks at step values
         self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual, cin=x.C,
-                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw)
+                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw_fold, **kw)
         return out
 
     def _fusable_projection(self, main_conv, sc):
@@ -272,7 +275,8 @@ class Lowering:
                 if (res.C, res.H, res.W) != (cout, x.H, Wout):
                     raise ValueError("agg add shape mismatch at %s" % add.name)
                 self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
-                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD)
+                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD,
+                          fold=self.dtype == RD_BF16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD"))
                 return out
         raise NotImplementedError("elemwise_add %s is not skip + relu(BN(Deconvolution))" % add.name)
 

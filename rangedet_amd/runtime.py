@@ -162,6 +162,10 @@ class Executor:
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s))
                 b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss))
                 b["scale"], b["shift"] = None, A.upload((t.astype(np.float64) + ts).astype(np.float32))
+            elif st.get("ex") and st.get("fold"):   # scale folded into the weights, the shift enters through the accumulators
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s))
+                b["scale"], b["shift"] = None, A.upload(t)
+                b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
             elif st.get("ex"):
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs))
                 b["scale"], b["shift"] = A.upload(s), A.upload(t)
@@ -170,9 +174,13 @@ class Executor:
                 b["scale"], b["shift"] = A.upload(s), A.upload(t)
         elif k == "deconv":
             w = P[st["name"] + "_weight"]
-            b["w"] = [A.upload(L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt)) for ph in range(st["stride_w"])]
             s, t = bn_affine(P, st["bn"], st["eps"])
-            b["scale"], b["shift"] = A.upload(s), A.upload(t)
+            fs = s if st.get("fold") else None
+            b["w"] = [A.upload(L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt, fold_scale=fs))
+                      for ph in range(st["stride_w"])]
+            b["scale"], b["shift"] = (None if st.get("fold") else A.upload(s)), A.upload(t)
+            if st.get("fold"):
+                b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
         elif k == "meta":
             s1, t1 = bn_affine(P, st["bn1"], st["eps1"])
             s2, t2 = bn_affine(P, st["bn2"], st["eps2"])
@@ -225,7 +233,8 @@ class Executor:
                 L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
             elif k == "conv" and b.get("head"):
                 x, h = b["x"], b["head"]
-                L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]), B,
+                L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]),
+                       A.ptr(b["scale"]) if b["scale"] is not None else None, A.ptr(b["shift"]), B,
                        x.H, x.W, b["cin"], b["flags"], A.ptr(b["head_w"]), A.ptr(b["head_bias"]), self.p(h["out"]),
                        h["N"] * h["nout"], h["n_off"], h["nout"], st_)
             elif k == "conv" and b.get("ex"):
@@ -245,8 +254,8 @@ class Executor:
             elif k == "deconv":
                 x, o, r = b["x"], b["out"], b["res"]
                 for ph in range(b["stride_w"]):
-                    L.call("rd_deconv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"][ph]), A.ptr(b["scale"]),
-                           A.ptr(b["shift"]), self.p(r), r.cs, r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"],
+                    L.call("rd_deconv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"][ph]),
+                           A.ptr(b["scale"]) if b["scale"] is not None else None, A.ptr(b["shift"]), self.p(r), r.cs, r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"],
                            b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["pad_w"], ph, b["flags"], dt, st_)
             elif k == "meta":
                 x, o = b["x"], b["out"]

@@ -127,6 +127,13 @@ def test_conv_fused_with_head_out(be, case):
     act = bf16_round(np.maximum(ref, 0).astype(np.float32))
     want = np.einsum('oc,bchw->bhwo', hw, act).reshape(B, H * W, nout) + hb
     assert np.abs(b[:, off:off + H * W] - want).max() < 2 ** -7 * max(1.0, np.abs(want).max())
+    # the production form: scale folded into the 3x3 weights (RD_SCALE_FOLDED), shift through the accumulators
+    o3 = be.empty(B * N * nout * 4)
+    wpf = be.up(L.pack_conv3x3_ex(w, 1, cs, fold_scale=sc))
+    L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wpf), None, be.ptr(dsh), B, H, W, cin,
+           R.RD_RELU_POST | R.RD_SCALE_FOLDED, be.ptr(dhp), be.ptr(dhb), be.ptr(o3), N * nout, off, nout, be.stream)
+    c = be.down(o3, np.float32, (B, N, nout))
+    assert np.abs(c[:, off:off + H * W] - want).max() < 1.5 * 2 ** -7 * max(1.0, np.abs(want).max())
     buf = be.ptr(be.empty(1 << 16))
     assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 9, be.stream) == R.RD_ESHAPE
     assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 6, buf, buf, buf, 100, 0, 8, be.stream) == R.RD_EINVAL
@@ -158,6 +165,14 @@ def test_deconv2d_bn_act(be, case):
     ref = np.maximum(ref * sc[None, :, None, None] + sh[None, :, None, None], 0) + res
     got = from_nhwc(be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, Wout, cout)), dt, cout)
     assert np.abs(got - ref).max() <= _tol(dt, ref)
+    if dt == BF16:   # the production form: BatchNorm scale folded into the weights, shift through the accumulators
+        y2 = be.empty(B * H * Wout * cout * 4)
+        for ph in range(s):
+            wp = be.up(L.pack_deconv_weight(w, s, pw, ph, dt, fold_scale=sc))
+            L.call("rd_deconv2d_bn_act", be.ptr(xin), cin, 0, be.ptr(wp), None, be.ptr(dsh), be.ptr(rin), cout, 0, be.ptr(y2), cout, 0,
+                   B, H, W, cin, cout, k[0], k[1], s, pw, ph, R.RD_RELU_PRE | R.RD_ADD | R.RD_SCALE_FOLDED, dt, be.stream)
+        got2 = from_nhwc(be.down(y2, np.uint16, (B, H, Wout, cout)), dt, cout)
+        assert np.abs(got2 - ref).max() <= 1.5 * _tol(dt, ref)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -349,7 +364,7 @@ def test_wnms_two_rounds_vs_oracle(be, is3d):
     assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
 
 
-def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0):
+def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0, fold=False):
     """rd_conv3x3_bn_act_ex (bf16) vs torch fp32: conv2 of a BasicBlock with stride (1,stride), optional residual, optional fused
     1x1 projection shortcut of a second input (scales folded into both weight sets by the packers)."""
     rng = np.random.default_rng(seed)
@@ -381,8 +396,10 @@ def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_
         flags |= R.RD_ADD
     else:
         ref = ref * sc2[None, :, None, None] + sh2[None, :, None, None]
-        wp = be.up(L.pack_conv3x3_ex(w, stride, cs))
-        scale_ptr, shift_ptr = be.ptr(be.up(sc2)), be.ptr(be.up(sh2))
+        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2 if fold else None))
+        scale_ptr, shift_ptr = (None if fold else be.ptr(be.up(sc2))), be.ptr(be.up(sh2))
+        if fold:
+            flags |= R.RD_SCALE_FOLDED
         if residual:
             r = bf16_round(rng.standard_normal((B, cout, H, Wo)).astype(np.float32))
             ref = ref + r
@@ -408,12 +425,22 @@ CONV_EX_CASES = [
     (1, 3, 66, 128, 128, 2, 128, False),     # res3a_unit1
     (1, 4, 64, 64, 64, 1, 64, False),        # agg1/agg3_res_unit1
 ]
+CONV_FOLD_CASES = [   # RD_SCALE_FOLDED without a shortcut: plain / residual, stride 1 / 2, cout 64 / 128, partial tiles
+    (2, 9, 130, 128, 128, 1, None, True), (1, 5, 70, 64, 64, 1, None, False), (1, 4, 20, 72, 128, 1, None, False),
+    (1, 9, 132, 128, 128, 2, None, True), (2, 3, 64, 64, 64, 2, None, False), (1, 11, 63, 8, 64, 1, None, False),
+]
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", CONV_EX_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_conv3x3_ex(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]))
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv3x3_ex_folded_scale(be, case):
+    run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
