@@ -50,17 +50,26 @@ struct Conv3Args {
 // a halo row is 64 pixels x 64 B = two fragments).  Against 4 x 126 tiles: 10/8 instead of 6/4 halo rows per output row
 // (less HBM and LDS-DMA traffic per pixel) and a finer column grid (2656 = 42.8 tiles of 62: 99.6 % of the computed
 // columns are real, 95.8 % with 126; 664: 97 % instead of 88 %; 166: 89 % instead of 66 %).
+//
+// FPW = pixel fragments per wave.  FPW 4 is the tile above (one workgroup per CU, one wave per SIMD with the whole register
+// file).  FPW 2: tile = 4 rows x 62 columns (halo 6 x 64), wave w owns row w; half the accumulators (256 registers per wave)
+// and 75 KB of LDS, so TWO workgroups share a CU (two waves per SIMD): each is its own asynchronous pipeline with its own
+// barriers, and one's barrier waits, DMA-issue stalls and epilogue run under the other's MFMAs.  The price is 6/4 instead
+// of 10/8 halo rows per output row, so it is for the MFMA-bound 128-channel layers, not for the HBM-bound 64-channel ones.
 constexpr int C3_TW = 62;                  // output columns per tile (halo = 64 columns exactly)
-constexpr int C3_TH = 8;                   // output rows per tile
-constexpr int C3_HALO = 10 * 64 * 64;      // bytes of one halo image
-constexpr int C3_HPW = 10;                 // 1-KB halo pieces per wave and unit (40 in all)
 constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row
-template <int NCT> struct C3Cfg {
-  static constexpr int R = NCT == 4 ? 7 : 10;  // ring depth (slabs)
-  static constexpr int IPW = NCT / 2;          // slab DMA instructions per wave per step
+template <int NCT, int FPW = 4> struct C3Cfg {
+  static constexpr int TH = 2 * FPW;                     // output rows per tile (8 or 4)
+  static constexpr int HROWS = TH + 2;                   // halo rows
+  static constexpr int HALO = HROWS * 64 * 64;           // bytes of one halo image
+  static constexpr int HPW = HROWS;                      // 1-KB halo pieces per wave and unit (4 * HROWS in all)
+  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
+  static constexpr int IPW = NCT / 2;                    // slab DMA instructions per wave per step
   static constexpr int SLAB = NCT * 2048;
-  static constexpr size_t LDS = 2 * C3_HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
+  static constexpr size_t LDS = 2 * HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
 };
+constexpr int C3_TH = C3Cfg<4, 4>::TH;     // (the FPW 4 geometry, for code that sizes things before choosing a variant)
+constexpr int C3_HALO = C3Cfg<4, 4>::HALO;
 
 // packed bf16 conv-family weights: [32-ch chunk][tap][ks (2)][Cout/32][64 lanes][8 bf16], lane (mm, hi) of a fragment
 // holds W[co = 32*cb + conv_row_perm(mm)][ci = 32*chunk + 16*ks + 8*hi + j][tap].   get(co, ci, tap) -> float
@@ -122,16 +131,20 @@ constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw
 // Halo pieces (C3_HPW = 10 per wave and unit) per step ordinal: 2 each at ordinals 0..4 of a 9-step unit; 4, 4, 2 at
 // ordinals 0..2 of a 6-step unit; the last ones are issued at least two steps before the wait that must cover them
 // (ordinal NS-2).
-constexpr int c3_halo_last(int NS) { return NS == 9 ? 4 : 2; }
-constexpr int c3_halo_pieces(int s, int NS) { return NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)); }
-constexpr int c3_halo_first(int s, int NS) { int n = 0; for (int t = 0; t < s; ++t) n += c3_halo_pieces(t, NS); return n; }
+// (HP = 6, the 4-row tile: 2 each at ordinals 0..2 of a 9-step unit, 3 each at ordinals 0..1 of a 6-step unit.)
+constexpr int c3_halo_last(int NS, int HP) { return HP == 10 ? (NS == 9 ? 4 : 2) : (NS == 9 ? 2 : 1); }
+constexpr int c3_halo_pieces(int s, int NS, int HP) {
+  return HP == 10 ? (NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)))
+                  : (NS == 9 ? (s <= 2 ? 2 : 0) : (s <= 1 ? 3 : 0));
+}
+constexpr int c3_halo_first(int s, int NS, int HP) { int n = 0; for (int t = 0; t < s; ++t) n += c3_halo_pieces(t, NS, HP); return n; }
 // DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (ordinal s of its unit):
 // the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions plus its
 // halo pieces.  At ordinal NS-2 the wait must also cover the last halo piece: the following step reads the next halo.
-constexpr int c3_younger(int R, int IPW, int s, int NS) {
+constexpr int c3_younger(int R, int IPW, int s, int NS, int HP) {
   int n = (R - 3) * IPW;
-  for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((s - d) % NS) + NS) % NS, NS);
-  const int cap = (NS - 3 - c3_halo_last(NS)) * IPW;
+  for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((s - d) % NS) + NS) % NS, NS, HP);
+  const int cap = (NS - 3 - c3_halo_last(NS, HP)) * IPW;
   if (s == NS - 2 && n > cap) n = cap;
   return n;
 }
@@ -146,14 +159,16 @@ constexpr int c3_younger(int R, int IPW, int s, int NS) {
 // through one rank-1 MFMA per accumulator at the start of every tile (A = the shift as a bf16 high + low pair in k = 0, 1;
 // B = ones) -- 4 * NCT MFMAs of the tile's 36 * 8 * NCT..., in exchange for which the epilogue has no multiply-add left:
 // it reads the accumulators, adds the residual if any, converts and clamps.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false>
-__global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
-  static_assert(!HEAD || (NCT == 4 && TS == 0), "fused output conv: cout 128, all nine taps");
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4>
+__global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(!HEAD || (NCT == 4 && TS == 0 && FPW == 4), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
-  using Cfg = C3Cfg<NCT>;
+  static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
+  using Cfg = C3Cfg<NCT, FPW>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
-  constexpr int NR = 4 + NCT;                    // fragment reads per k-step
-  constexpr int NM = 4 * NCT;                    // MFMAs per k-step
+  constexpr int C3_HALO = Cfg::HALO, C3_HPW = Cfg::HPW, C3_TH = Cfg::TH;   // (shadow the FPW 4 file-scope constants)
+  constexpr int NR = FPW + NCT;                  // fragment reads per k-step
+  constexpr int NM = FPW * NCT;                  // MFMAs per k-step
   constexpr int NS = c3_nsteps(TS);              // steps (taps) per unit
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,12 +274,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int c = d + m;                                  // 1 + dw + m with dw = d - 1
-    aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * 8192;
+    aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * (FPW / 2) * C3_ROWB;
   }
   const int boff = RING + lane * 16;
 
-  f32x16 acc[4][NCT];
-  s16x8 fa[2][4], fb[2][NCT];
+  f32x16 acc[FPW][NCT];
+  s16x8 fa[2][FPW], fb[2][NCT];
 #define C3_FENCE() __builtin_amdgcn_sched_barrier(0)
   // fragment read k of a k-step, in the order the MFMA sequence needs them: fa[0], fb[0..NCT-1], fa[1..3]
 #define C3_RD(BUF, K, AADDR, BADDR, KS)                                                                   \
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
   {                                                                                                                  \
     constexpr int T_ = c3_tap(TS, (S)), TN_ = c3_tap(TS, ((S) + 1) % NS);                                            \
     constexpr int dh_ = T_ / 3, dw_ = T_ % 3, ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                        \
-    constexpr int NH_ = c3_halo_pieces((S), NS), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
+    constexpr int NH_ = c3_halo_pieces((S), NS, C3_HPW), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
     const int acur_ = (aoff[dw_] + abuf + dh_ * C3_ROWB) ^ 32;                                                         \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
@@ -349,14 +364,14 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
       if (n < NR) C3_RD(0, n, anext_, bnext_, 0)                                                                     \
     }                                                                                                                \
     if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RD(0, n, anext_, bnext_, 0) }          \
-    C3_SYNC(c3_younger(R, IPW, (S), NS), NR)                                                                         \
+    C3_SYNC(c3_younger(R, IPW, (S), NS, C3_HPW), NR)                                                                         \
     if ((S) == 0) halo_begin();                                                                                      \
     _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
       C3_MM(1, n)                                                                                                    \
       if (!(DBG & 4)) {   /* the step's DMA pieces, spread over the MFMA slots of this half block (slab pieces first) */ \
         _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                              \
           if (p * (NM / 2) / NP_ == n - NM / 2) {                                                                    \
-            if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS) + p - IPW);                    \
+            if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS, C3_HPW) + p - IPW);                    \
             C3_FENCE();                                                                                              \
           }                                                                                                          \
       }                                                                                                              \
@@ -403,12 +418,16 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
     // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
     const int t = wg + k * G;
     const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
-    const int oh0 = rb * C3_TH + 2 * wave;                   // fragment i: output row oh0 + (i >> 1), columns 32*(i & 1) ..
+    const int oh0 = rb * C3_TH + (FPW / 2) * wave;                   // fragment i: output row oh0 + (i >> 1), columns 32*(i & 1) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
     // and kept (spilled) across the whole MFMA phase
     int em = m, ehi = hi, el = lane;
     asm volatile("" : "+v"(em), "+v"(ehi), "+v"(el));
-    constexpr int ROWB = COUT * 2, SPR = COUT / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
+    // The transpose scratch of a wave is a quarter of the free halo buffer: 10 KB (FPW 4) or 6 KB (FPW 2).  A fragment's 32
+    // pixels x CW channels x 2 B must fit: all COUT channels in one pass, or (cout 128 on the 4-row tile) two passes of 64.
+    constexpr int JW = (32 * COUT * 2 <= C3_HALO / 4) ? NCT : NCT / 2, CW = JW * 32, NPASS = NCT / JW;
+    static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1), "transpose scratch");
+    constexpr int ROWB = CW * 2, SPR = CW / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + (C3_HALO - abuf) + wave * (C3_HALO / 4);
     bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
     // (base of image b, not of the wave's first row: rows past the image bottom must not even form an address beyond the buffer)
@@ -430,9 +449,9 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
 #pragma unroll
         for (int kh = 0; kh < 8 / MK; ++kh) {
           if (kh * MK < a.s_nks) {
-            s16x8 sxq[4][MK];
+            s16x8 sxq[FPW][MK];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < FPW; ++i) {
               const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
               const bool live = tc < C3_TW && ow < a.W && oh < a.H;
               const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.s_cs : 0) + 16 * MK * kh;
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
                 for (int j = 0; j < NCT; ++j) {
                   const s16x8 wf = *(const s16x8*)(wq + (size_t)((kh * MK + ks) * NCT + j) * 1024);
 #pragma unroll
-                  for (int i = 0; i < 4; ++i)
+                  for (int i = 0; i < FPW; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, sxq[i][ks], acc[i][j], 0, 0, 0);
                 }
               }
@@ -499,10 +518,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
         if constexpr (SC_HOIST) sc_load(1, scq[1], shq[1]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (do_add && i + 1 < 4) res_load(i + 1, rv[(i + 1) & 1]);
+      for (int i = 0; i < FPW; ++i) {
+        if (do_add && i + 1 < FPW) res_load(i + 1, rv[(i + 1) & 1]);
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) {
+        for (int jp = 0; jp < NPASS; ++jp) {
+#pragma unroll
+        for (int j = jp * JW; j < (jp + 1) * JW; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
           const int cur = SC_HOIST ? j : (i * NCT + j) & 1;
           if constexpr (!SC_HOIST && !FOLD) sc_load((j + 1) % NCT, scq[cur ^ 1], shq[cur ^ 1]);
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u)
-            *(Slot16*)(scr + em * ROWB + ((((cb >> 3) + u) ^ (em & (SPR - 1))) << 4)) =
+            *(Slot16*)(scr + em * ROWB + (((((cb - jp * CW) >> 3) + u) ^ (em & (SPR - 1))) << 4)) =
                 Slot16{pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]};
         }
         C3_FENCE();
@@ -565,11 +586,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(Conv3Args a) {
             const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
             const int tcs = 32 * (i & 1) + pr, ows = ct * C3_TW + tcs;
             if (tcs < C3_TW && ows < a.W && oh0 + (i >> 1) < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
-              *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + sl * 8) = v;
+              *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + jp * CW + sl * 8) = v;
           }
         }
         __builtin_amdgcn_wave_barrier();
         C3_FENCE();
+        }   // channel pass
       }
     };
     if (a.flags == RD_RELU_POST) epilogue(std::integral_constant<int, RD_RELU_POST>{});
@@ -629,8 +651,14 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // zero bytes for padding: the tail every packer appends to the weight image (k_conv.h RD_CONV_TAIL)
   a.zero16 = (const unsigned char*)w + conv_packed_body_bytes(c3_nsteps(ts), cin, cout, RD_BF16);
   a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;   // (without RD_SCALE_FOLDED)
-  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + C3_TH - 1) / C3_TH; a.ntiles = a.ncol * a.nrow * B;
-  const int grid = std::min(a.ntiles, conv_num_cus());
+  // 4-row tiles, two workgroups per CU (FPW 2): every cout-128 layer with folded scale and no fused output conv (measured
+  // A/B: +2.5 % end to end; W = 332 layers 70 -> 53 us, W = 1328 head convs 200 -> 179 us, full-width head convs -3 %);
+  // everything else on the 8-row tile.  RD_CONV_TH4=0 switches it off, =2 restricts it to W >= 600 (dev switches)
+  static const int th4_mode = getenv("RD_CONV_TH4") ? atoi(getenv("RD_CONV_TH4")) : 1;
+  const bool th4 = th4_mode && cout == 128 && fold && !(head && !sc) && (th4_mode != 2 || W >= 600);
+  const int th = th4 ? 4 : C3_TH;
+  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
+  const int grid = std::min(a.ntiles, conv_num_cus() * (th4 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);
 #ifdef RD_CONV3_DEV   // ablation variants (DBG bits: 2 no barrier, 4 no DMA after the prologue, 16 halo from the zero page, 32 no vmcnt wait)
@@ -639,6 +667,17 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
 #endif
+  if (th4) {
+    constexpr size_t L2 = C3Cfg<4, 2>::LDS;
+    if (sc) {
+      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a);
+      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 1, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a);
+      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
+    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
+    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 1, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 2, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
+    return check_launch("conv3x3_stream_kernel<th4>");
+  }
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
     RD_REQUIRE(fold, RD_EINVAL, "conv3 + shortcut: the weights must carry the folded scales (RD_SCALE_FOLDED)");
