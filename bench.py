@@ -288,7 +288,7 @@ def main():
                 "frac": achieved / (PEAK_BF16_TFLOPS if bf else 157.3),
                 "traffic": measured_traffic("conv3x3_stream_kernel", Bf) if bf else None,
                 "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes of "
-                                "this command (profiles/r01_pmc_traffic.json)",
+                                "this command (profiles/r02_pmc_traffic.json, tools/profile_round.sh)",
                 "algorithmic_bytes_per_launch": conv_bytes(pipe.plan, 2 if bf else 4, only_conv3=bf) * Bf / nlaunch,
                 "launches_per_step": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_launch": fl * Bf / nlaunch / 1e9,
                 "share_of_conv_flops": fl / fl_all,
