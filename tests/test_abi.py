@@ -28,16 +28,17 @@ def test_product_library_loads_and_exports_every_symbol():
     L = R.Lib(path)  # resolves every declared symbol (AttributeError otherwise)
     assert L.raw("rd_version")() >= 100
     # host-only entry points work without a GPU
-    assert L.raw("rd_conv_packed_bytes")(9, 128, 128, R.RD_BF16) == 2 * 9 * 128 * 128
-    assert L.raw("rd_conv_packed_bytes")(9, 72, 128, R.RD_BF16) == 2 * 9 * 128 * 128   # 72 -> two 64-channel chunks
-    assert L.raw("rd_conv_packed_bytes")(1, 8, 64, R.RD_F32) == 64 * 128
+    TAIL = 256                                                  # zero tail every packed buffer ends with (k_conv.h RD_CONV_TAIL)
+    assert L.raw("rd_conv_packed_bytes")(9, 128, 128, R.RD_BF16) == 2 * 9 * 128 * 128 + TAIL
+    assert L.raw("rd_conv_packed_bytes")(9, 72, 128, R.RD_BF16) == 2 * 9 * 128 * 128 + TAIL   # 72 -> two 64-channel chunks
+    assert L.raw("rd_conv_packed_bytes")(1, 8, 64, R.RD_F32) == 64 * 128 + TAIL
     # every phase of the graph transposed convs: 6 taps (3 rows x 2 adjacent columns), run as a 6-step unit
     assert [L.raw("rd_deconv_phase_taps")(3, 8, 4, 2, p) for p in range(4)] == [6, 6, 6, 6]
     assert [L.raw("rd_deconv_phase_taps")(3, 4, 2, 1, p) for p in range(2)] == [6, 6]
     assert L.raw("rd_deconv_phase_taps")(3, 8, 4, 2, 4) == R.RD_EINVAL
     d = np.array([[0] * 11 + [s] for s in (0.7, 0.9, 0.7, 0.8)], np.float32)
     assert L.wnms_order_host(d).tolist()[:2] == [1, 3]
-    assert L.raw("rd_meta_packed_bytes")(R.RD_BF16) == 36864 + 73728 + 2 * 2304 + 512 + 512
+    assert L.raw("rd_meta_packed_bytes")(R.RD_BF16) == 36864 + 73728 + 2 * 2304 + 512 + 512 + 1024   # ... + the hidden layer as an MFMA fragment
 
 
 def test_missing_extension_fails_loudly(tmp_path):
