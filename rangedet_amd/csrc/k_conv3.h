@@ -56,14 +56,22 @@ struct Conv3Args {
 // and 75 KB of LDS, so TWO workgroups share a CU (two waves per SIMD): each is its own asynchronous pipeline with its own
 // barriers, and one's barrier waits, DMA-issue stalls and epilogue run under the other's MFMAs.  The price is 6/4 instead
 // of 10/8 halo rows per output row, so it is for the MFMA-bound 128-channel layers, not for the HBM-bound 64-channel ones.
-constexpr int C3_TW = 62;                  // output columns per tile (halo = 64 columns exactly)
-constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row
-template <int NCT, int FPW = 4> struct C3Cfg {
-  static constexpr int TH = 2 * FPW;                     // output rows per tile (8 or 4)
+//
+// FC = 32-pixel fragments per tile row (2: 62 output columns, halo 64; 1: 30 output columns, halo 32).  <FPW 2, FC 1> is the
+// 8-row x 30-column tile: wave w owns rows 2w, 2w+1 like the 8 x 62 tile (10/8 halo rows), half as wide, 72 KB of LDS, two
+// workgroups per CU -- the 4-row tile's stall hiding without its 6/4 halo rows, for the HBM-bound 64-channel layers.
+constexpr int C3_TW = 62;                  // output columns per tile (halo = 64 columns exactly), FC 2
+constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row, FC 2
+template <int NCT, int FPW = 4, int FC = 2> struct C3Cfg {
+  static constexpr int RW = FPW / FC;                    // output rows per wave
+  static constexpr int TH = 4 * RW;                      // output rows per tile (8 or 4)
+  static constexpr int COLS = 32 * FC;                   // halo columns
+  static constexpr int TW = COLS - 2;                    // output columns per tile
+  static constexpr int ROWB = COLS * 64;                 // bytes of one halo row
   static constexpr int HROWS = TH + 2;                   // halo rows
-  static constexpr int HALO = HROWS * 64 * 64;           // bytes of one halo image
-  static constexpr int HPW = HROWS;                      // 1-KB halo pieces per wave and unit (4 * HROWS in all)
-  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
+  static constexpr int HALO = HROWS * ROWB;              // bytes of one halo image
+  static constexpr int HPW = HALO / 4096;                // 1-KB halo pieces per wave and unit
+  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? 8 : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
   static constexpr int IPW = NCT / 2;                    // slab DMA instructions per wave per step
   static constexpr int SLAB = NCT * 2048;
   static constexpr size_t LDS = 2 * HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
@@ -131,11 +139,13 @@ constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw
 // Halo pieces (C3_HPW = 10 per wave and unit) per step ordinal: 2 each at ordinals 0..4 of a 9-step unit; 4, 4, 2 at
 // ordinals 0..2 of a 6-step unit; the last ones are issued at least two steps before the wait that must cover them
 // (ordinal NS-2).
-// (HP = 6, the 4-row tile: 2 each at ordinals 0..2 of a 9-step unit, 3 each at ordinals 0..1 of a 6-step unit.)
-constexpr int c3_halo_last(int NS, int HP) { return HP == 10 ? (NS == 9 ? 4 : 2) : (NS == 9 ? 2 : 1); }
+// (HP = 6, the 4-row tile: 2 each at ordinals 0..2 of a 9-step unit, 3 each at ordinals 0..1 of a 6-step unit;
+//  HP = 5, the 8 x 30 tile: 1 each at ordinals 0..4 of a 9-step unit; 2, 2, 1 at ordinals 0..2 of a 6-step unit.)
+constexpr int c3_halo_last(int NS, int HP) { return HP == 6 ? (NS == 9 ? 2 : 1) : (NS == 9 ? 4 : 2); }
 constexpr int c3_halo_pieces(int s, int NS, int HP) {
   return HP == 10 ? (NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)))
-                  : (NS == 9 ? (s <= 2 ? 2 : 0) : (s <= 1 ? 3 : 0));
+       : HP == 6  ? (NS == 9 ? (s <= 2 ? 2 : 0) : (s <= 1 ? 3 : 0))
+                  : (NS == 9 ? (s <= 4 ? 1 : 0) : (s <= 1 ? 2 : (s == 2 ? 1 : 0)));
 }
 constexpr int c3_halo_first(int s, int NS, int HP) { int n = 0; for (int t = 0; t < s; ++t) n += c3_halo_pieces(t, NS, HP); return n; }
 // DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (ordinal s of its unit):
@@ -159,14 +169,16 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP) {
 // through one rank-1 MFMA per accumulator at the start of every tile (A = the shift as a bf16 high + low pair in k = 0, 1;
 // B = ones) -- 4 * NCT MFMAs of the tile's 36 * 8 * NCT..., in exchange for which the epilogue has no multiply-add left:
 // it reads the accumulators, adds the residual if any, converts and clamps.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4>
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
   static_assert(!HEAD || (NCT == 4 && TS == 0 && FPW == 4), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
-  using Cfg = C3Cfg<NCT, FPW>;
+  static_assert(FC == 2 || (FC == 1 && FPW == 2 && NCT == 2), "30-column tiles: two fragments per wave, cout 64");
+  using Cfg = C3Cfg<NCT, FPW, FC>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int C3_HALO = Cfg::HALO, C3_HPW = Cfg::HPW, C3_TH = Cfg::TH;   // (shadow the FPW 4 file-scope constants)
+  constexpr int C3_TW = Cfg::TW, C3_ROWB = Cfg::ROWB, RW = Cfg::RW;
   constexpr int NR = FPW + NCT;                  // fragment reads per k-step
   constexpr int NM = FPW * NCT;                  // MFMAs per k-step
   constexpr int NS = c3_nsteps(TS);              // steps (taps) per unit
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     else if (hk + 1 < ntl) { ++hk; hc = 0; }
   };
   auto halo_piece = [&](int buf, int j) {
-    const int q = wave * C3_HPW + j, r = q >> 2, c16 = (q & 3) * 16;
+    const int q = wave * C3_HPW + j, r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
     const int cc = c16 + l4;
     const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
     const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int c = d + m;                                  // 1 + dw + m with dw = d - 1
-    aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * (FPW / 2) * C3_ROWB;
+    aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * RW * C3_ROWB;
   }
   const int boff = RING + lane * 16;
 
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
     const int t = wg + k * G;
     const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
-    const int oh0 = rb * C3_TH + (FPW / 2) * wave;                   // fragment i: output row oh0 + (i >> 1), columns 32*(i & 1) ..
+    const int oh0 = rb * C3_TH + RW * wave;                          // fragment i: output row oh0 + i / FC, columns 32*(i % FC) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
     // and kept (spilled) across the whole MFMA phase
     int em = m, ehi = hi, el = lane;
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             s16x8 sxq[FPW][MK];
 #pragma unroll
             for (int i = 0; i < FPW; ++i) {
-              const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
+              const int tc = 32 * (i % FC) + em, ow = ct * C3_TW + tc, oh = oh0 + i / FC;
               const bool live = tc < C3_TW && ow < a.W && oh < a.H;
               const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.s_cs : 0) + 16 * MK * kh;
 #pragma unroll
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       // residuals: the loads of pixel fragment i+1 are issued before fragment i is processed (dead pixels read pixel 0)
       Slot16 rv[2][NCT][2];
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
-        const int tc = 32 * (i & 1) + em, ow = ct * C3_TW + tc, oh = oh0 + (i >> 1);
+        const int tc = 32 * (i % FC) + em, ow = ct * C3_TW + tc, oh = oh0 + i / FC;
         const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh);
         const bf16_t* rp = rimg0 + (live ? ((size_t)oh * a.Wo + (size_t)(ow >> sh)) * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bq, h0, 0, 0, 0);
             h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bq, h1, 0, 0, 0);
           }
-          const int tcs = 32 * (i & 1) + em, ows = ct * C3_TW + tcs, ohs = oh0 + (i >> 1);
+          const int tcs = 32 * (i % FC) + em, ows = ct * C3_TW + tcs, ohs = oh0 + i / FC;
           if (tcs < C3_TW && ows < a.W && ohs < a.H) {
             float* o = a.ho + (size_t)b * a.ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * a.hn + 4 * ehi;
 #pragma unroll
@@ -584,9 +596,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           for (int it = 0; it < 32 / RPI; ++it) {
             const int pr = it * RPI + el / SPR, sl = el % SPR;
             const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
-            const int tcs = 32 * (i & 1) + pr, ows = ct * C3_TW + tcs;
-            if (tcs < C3_TW && ows < a.W && oh0 + (i >> 1) < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
-              *(Slot16*)(yrow0 + (size_t)(i >> 1) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + jp * CW + sl * 8) = v;
+            const int tcs = 32 * (i % FC) + pr, ows = ct * C3_TW + tcs;
+            if (tcs < C3_TW && ows < a.W && oh0 + i / FC < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
+              *(Slot16*)(yrow0 + (size_t)(i / FC) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + jp * CW + sl * 8) = v;
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -655,10 +667,13 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // A/B: +2.5 % end to end; W = 332 layers 70 -> 53 us, W = 1328 head convs 200 -> 179 us, full-width head convs -3 %);
   // everything else on the 8-row tile.  RD_CONV_TH4=0 switches it off, =2 restricts it to W >= 600 (dev switches)
   static const int th4_mode = getenv("RD_CONV_TH4") ? atoi(getenv("RD_CONV_TH4")) : 1;
-  const bool th4 = th4_mode && cout == 128 && fold && !(head && !sc) && (th4_mode != 2 || W >= 600);
-  const int th = th4 ? 4 : C3_TH;
-  a.ncol = (W + C3_TW - 1) / C3_TW; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
-  const int grid = std::min(a.ntiles, conv_num_cus() * (th4 ? 2 : 1));
+  const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && !(head && !sc) && (th4_mode != 2 || W >= 600);
+  // 8 x 30 tiles, two workgroups per CU, for the cout-64 layers (RD_CONV_W30=0 switches it off)
+  static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 1;
+  const bool w30 = w30_mode && !th4 && cout == 64 && fold;
+  const int th = th4 ? 4 : C3_TH, tw = w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
+  a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
+  const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);
 #ifdef RD_CONV3_DEV   // ablation variants (DBG bits: 2 no barrier, 4 no DMA after the prologue, 16 halo from the zero page, 32 no vmcnt wait)
@@ -668,15 +683,31 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
 #undef C3_DBG_CASE
 #endif
   if (th4) {
-    constexpr size_t L2 = C3Cfg<4, 2>::LDS;
-    if (sc) {
-      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a);
-      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 1, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a);
-      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
-    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
-    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 1, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 2, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);
+#define C3_LAUNCH_TH4(N)                                                                                                          \
+  {                                                                                                                             \
+    constexpr size_t L2 = C3Cfg<N, 2>::LDS;                                                                                     \
+    if (sc) {                                                                                                                   \
+      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a); \
+      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a); \
+      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);                                                      \
+    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a); \
+    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a); \
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 2, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);           \
+  }
+    if (cout == 128) C3_LAUNCH_TH4(4) else C3_LAUNCH_TH4(2)
+#undef C3_LAUNCH_TH4
     return check_launch("conv3x3_stream_kernel<th4>");
+  }
+  if (w30) {
+    constexpr size_t L3 = C3Cfg<2, 2, 1>::LDS;
+    if (sc) {
+      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 0, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 1, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
+    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 0, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 1, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 2, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+    return check_launch("conv3x3_stream_kernel<w30>");
   }
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
