@@ -71,7 +71,7 @@ template <int NCT, int FPW = 4, int FC = 2> struct C3Cfg {
   static constexpr int HROWS = TH + 2;                   // halo rows
   static constexpr int HALO = HROWS * ROWB;              // bytes of one halo image
   static constexpr int HPW = HALO / 4096;                // 1-KB halo pieces per wave and unit
-  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? 8 : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
+  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? (NCT == 4 ? 4 : 8) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
   static constexpr int IPW = NCT / 2;                    // slab DMA instructions per wave per step
   static constexpr int SLAB = NCT * 2048;
   static constexpr size_t LDS = 2 * HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   static_assert(!HEAD || (NCT == 4 && TS == 0 && FPW == 4), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
-  static_assert(FC == 2 || (FC == 1 && FPW == 2 && NCT == 2), "30-column tiles: two fragments per wave, cout 64");
+  static_assert(FC == 2 || (FC == 1 && FPW == 2), "30-column tiles: two fragments per wave");
   using Cfg = C3Cfg<NCT, FPW, FC>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int C3_HALO = Cfg::HALO, C3_HPW = Cfg::HPW, C3_TH = Cfg::TH;   // (shadow the FPW 4 file-scope constants)
@@ -663,15 +663,18 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // zero bytes for padding: the tail every packer appends to the weight image (k_conv.h RD_CONV_TAIL)
   a.zero16 = (const unsigned char*)w + conv_packed_body_bytes(c3_nsteps(ts), cin, cout, RD_BF16);
   a.H = H; a.W = W; a.B = B; a.nslots = cin_slots(cin, RD_BF16); a.nchunk = (cin + 31) / 32; a.flags = flags;   // (without RD_SCALE_FOLDED)
-  // 4-row tiles, two workgroups per CU (FPW 2): every cout-128 layer with folded scale and no fused output conv (measured
-  // A/B: +2.5 % end to end; W = 332 layers 70 -> 53 us, W = 1328 head convs 200 -> 179 us, full-width head convs -3 %);
-  // everything else on the 8-row tile.  RD_CONV_TH4=0 switches it off, =2 restricts it to W >= 600 (dev switches)
+  // Two workgroups per CU (FPW 2) for every layer with folded scale and no fused output conv, on 8-row x 30-column tiles
+  // (FC 1).  Measured A/B, frames/s end to end: 4 x 62 tiles for the cout-128 layers +2.5 % over 8 x 62 everywhere (W = 332
+  // layers 70 -> 53 us, W = 1328 head convs 200 -> 179 us); 8 x 30 for the cout-64 layers +0.7 % on top (the HBM-bound
+  // layers keep their 10/8 halo rows); 8 x 30 instead of 4 x 62 for the cout-128 layers another +1.4 % (14 % fewer halo
+  // pieces per pixel, ring depth 4 instead of 3).  Dev switches: RD_CONV_TH4=0 -> cout 128 on 8 x 62, =3 -> cout 64 on
+  // 4 x 62 too; RD_CONV_W30=0 -> no 8 x 30 tiles, =1 -> only for cout 64.
   static const int th4_mode = getenv("RD_CONV_TH4") ? atoi(getenv("RD_CONV_TH4")) : 1;
   const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && !(head && !sc) && (th4_mode != 2 || W >= 600);
-  // 8 x 30 tiles, two workgroups per CU, for the cout-64 layers (RD_CONV_W30=0 switches it off)
-  static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 1;
-  const bool w30 = w30_mode && !th4 && cout == 64 && fold;
-  const int th = th4 ? 4 : C3_TH, tw = w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
+  static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 2;
+  const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
+  const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !(head && !sc)) || w30_128);
+  const int th = th4 && !w30 ? 4 : C3_TH, tw = w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
   a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
@@ -682,7 +685,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
 #endif
-  if (th4) {
+  if (th4 && !w30) {
 #define C3_LAUNCH_TH4(N)                                                                                                          \
   {                                                                                                                             \
     constexpr size_t L2 = C3Cfg<N, 2>::LDS;                                                                                     \
@@ -699,14 +702,19 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
     return check_launch("conv3x3_stream_kernel<th4>");
   }
   if (w30) {
-    constexpr size_t L3 = C3Cfg<2, 2, 1>::LDS;
-    if (sc) {
-      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 0, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
-      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 1, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
-      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
-    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 0, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
-    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 1, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<2, 0, 2, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);
+#define C3_LAUNCH_W30(N)                                                                                                          \
+  {                                                                                                                             \
+    constexpr size_t L3 = C3Cfg<N, 2, 1>::LDS;                                                                                  \
+    if (sc) {                                                                                                                   \
+      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
+      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
+      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);                                                      \
+    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
+    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
+    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 2, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);        \
+  }
+    if (cout == 128) C3_LAUNCH_W30(4) else C3_LAUNCH_W30(2)
+#undef C3_LAUNCH_W30
     return check_launch("conv3x3_stream_kernel<w30>");
   }
   if (sc) {
