@@ -171,7 +171,7 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP) {
 // it reads the accumulators, adds the residual if any, converts and clamps.
 template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
-  static_assert(!HEAD || (NCT == 4 && TS == 0 && FPW == 4), "fused output conv: cout 128, all nine taps, 8-row tiles");
+  static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
   static_assert(FC == 2 || (FC == 1 && FPW == 2), "30-column tiles: two fragments per wave");
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   halo_begin();
 #pragma unroll
   for (int j = 0; j < C3_HPW; ++j) halo_piece(0, j);
-  if constexpr (HEAD) {
+  if constexpr (HEAD && FPW == 4) {   // (FPW 2: no LDS to spare for them with two workgroups per CU -- read from L2 in the epilogue)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_s(a.hw + (wave * 4 + j) * 1024, lane * 16, HWOFF + (wave * 4 + j) * 1024);
   }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     // The transpose scratch of a wave is a quarter of the free halo buffer: 10 KB (FPW 4) or 6 KB (FPW 2).  A fragment's 32
     // pixels x CW channels x 2 B must fit: all COUT channels in one pass, or (cout 128 on the 4-row tile) two passes of 64.
     constexpr int JW = (32 * COUT * 2 <= C3_HALO / 4) ? NCT : NCT / 2, CW = JW * 32, NPASS = NCT / JW;
-    static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1), "transpose scratch");
+    static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1 || FPW == 2), "transpose scratch");
     constexpr int ROWB = CW * 2, SPR = CW / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + (C3_HALO - abuf) + wave * (C3_HALO / 4);
     bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
@@ -532,8 +532,24 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #pragma unroll
       for (int i = 0; i < FPW; ++i) {
         if (do_add && i + 1 < FPW) res_load(i + 1, rv[(i + 1) & 1]);
+        f32x16 h0, h1;                       // HEAD: the output conv's accumulators (weights hi / lo), summed over the passes
+        if constexpr (HEAD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+        }
 #pragma unroll
         for (int jp = 0; jp < NPASS; ++jp) {
+        // HEAD on two passes: this pass's eight weight fragments (k-steps 4*jp .., hi and lo) straight from global memory
+        // (16 KB, L2 resident), requested before the pass's conversion work so that their latency is hidden behind it
+        constexpr int KSP = 8 / NPASS;
+        s16x8 hwq[HEAD && NPASS == 2 ? 2 : 1][HEAD && NPASS == 2 ? KSP : 1];
+        if constexpr (HEAD && NPASS == 2) {
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks)
+              hwq[part][ks] = *(const s16x8*)(a.hw + part * 8192 + (jp * KSP + ks) * 1024 + el * 16);
+        }
 #pragma unroll
         for (int j = jp * JW; j < (jp + 1) * JW; ++j) {
           C3_FENCE();   // one (i, j) accumulator at a time: keeps the register footprint of the epilogue small
@@ -572,19 +588,20 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
         __builtin_amdgcn_wave_barrier();   // (the wave runs in lockstep on hardware; this orders the lanes under hipemu)
         if constexpr (HEAD) {
           // out[o][px] = sum_c w[o][c] * act[px][c]: A = weights (hi, lo), B = the fragment's pixels from the scratch image
-          f32x16 h0, h1;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-#pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            const s16x8 bq = *(const s16x8*)(scr + em * ROWB + (((2 * ks + ehi) ^ (em & 15)) << 4));
-            const s16x8 wh = *(const s16x8*)(smem + HWOFF + ks * 1024 + el * 16);
-            const s16x8 wl = *(const s16x8*)(smem + HWOFF + 8192 + ks * 1024 + el * 16);
+          for (int ks = 0; ks < KSP; ++ks) {
+            const s16x8 bq = *(const s16x8*)(scr + em * ROWB + (((2 * ks + ehi) ^ (em & (SPR - 1))) << 4));
+            s16x8 wh, wl;
+            if constexpr (NPASS == 2) { wh = hwq[0][ks]; wl = hwq[1][ks]; }
+            else {
+              wh = *(const s16x8*)(smem + HWOFF + ks * 1024 + el * 16);
+              wl = *(const s16x8*)(smem + HWOFF + 8192 + ks * 1024 + el * 16);
+            }
             h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bq, h0, 0, 0, 0);
             h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bq, h1, 0, 0, 0);
           }
           const int tcs = 32 * (i % FC) + em, ows = ct * C3_TW + tcs, ohs = oh0 + i / FC;
-          if (tcs < C3_TW && ows < a.W && ohs < a.H) {
+          if (jp == NPASS - 1 && tcs < C3_TW && ows < a.W && ohs < a.H) {
             float* o = a.ho + (size_t)b * a.ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * a.hn + 4 * ehi;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -670,10 +687,17 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // pieces per pixel, ring depth 4 instead of 3).  Dev switches: RD_CONV_TH4=0 -> cout 128 on 8 x 62, =3 -> cout 64 on
   // 4 x 62 too; RD_CONV_W30=0 -> no 8 x 30 tiles, =1 -> only for cout 64.
   static const int th4_mode = getenv("RD_CONV_TH4") ? atoi(getenv("RD_CONV_TH4")) : 1;
-  const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && !(head && !sc) && (th4_mode != 2 || W >= 600);
+  static const int head30 = getenv("RD_CONV_HEAD30") ? atoi(getenv("RD_CONV_HEAD30")) : 1;
+  const bool headfuse = head && !sc;
+  // (fused output conv on the two-workgroup tiles: its 16 KB of weights no longer fit in LDS and are re-read from L2 per
+  //  fragment and pass; measured per layer: W = 1328 213 -> 205 us, W = 664 109 -> 107 us, W = 2656 398 -> 405 us, so the
+  //  full-width level stays on the 8 x 62 tile.  RD_CONV_HEAD30=0 -> never, =2 -> always)
+  const bool head30_ok = head30 == 2 || (head30 == 1 && W <= 1400);
+  const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 2;
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
-  const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !(head && !sc)) || w30_128);
+  const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !headfuse) || w30_128);
+  RD_REQUIRE(!headfuse || !th4 || w30, RD_EINVAL, "conv3 + output conv: two workgroups per CU only on the 8 x 30 tiles");
   const int th = th4 && !w30 ? 4 : C3_TH, tw = w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
   a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
@@ -713,7 +737,9 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
     else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
     else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 2, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);        \
   }
-    if (cout == 128) C3_LAUNCH_W30(4) else C3_LAUNCH_W30(2)
+    constexpr size_t LH = C3Cfg<4, 2, 1>::LDS;
+    if (headfuse) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true, false, true, 2, 1>), dim3(grid), dim3(256), LH, st, a);
+    else if (cout == 128) C3_LAUNCH_W30(4) else C3_LAUNCH_W30(2)
 #undef C3_LAUNCH_W30
     return check_launch("conv3x3_stream_kernel<w30>");
   }

@@ -89,6 +89,7 @@ inline void allow_conv_lds() {
   allow_big_lds(conv3x3_stream_kernel<4, 0, 2, false, false, true, 2, 1>);
   allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true, true, 2, 1>);
   allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true, true, 2, 1>);
+  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true, false, true, 2, 1>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
   allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
   allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
