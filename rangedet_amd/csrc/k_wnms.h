@@ -92,8 +92,9 @@ struct EdgeLds {
 };
 constexpr int EDGE_LDS_BYTES = (5 * 8 + 16) * 64 * 4;
 
-// box1 = the earlier (kept candidate) box, box2 = the later one; pre1/pre2 their prepped records.
-__device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, const EdgeLds& L) {
+// The reference's sort + de-duplication of the 8 edges, literally (nms.h:98-109): returns the number of edges kept, which then
+// sit in positions 0 .. t-1 of the per-lane edge array.
+__device__ int w_sort_dedup_literal(const float* pre1, const float* pre2, const EdgeLds& L) {
   RD_NOCONTRACT
   // nms.h:210-225: p[0..3] = box2, p[4..7] = box1 ; l[z] from box2, l[z+4] from box1
 #pragma unroll
@@ -109,7 +110,6 @@ __device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, cons
     e.ang = pre1[8 + z];
     L.put(z + 4, e);
   }
-  float area1 = pre1[12], area2 = pre2[12];
   // std::sort on 8 elements == libstdc++ __insertion_sort (n <= 16), restated literally because the
   // comparator is not a strict weak order (nms.h:58-64,98)
   for (int i = 1; i < 8; ++i) {
@@ -129,10 +129,56 @@ __device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, cons
   int i, j;
   for (i = 0, j = 0; i < 8; i++)
     if (w_sgn(L.an[i * 64 + L.t] - L.an[j * 64 + L.t]) > 0) L.put(++j, L.get(i));
-  const int t = j + 1;
+  return j + 1;
+}
+
+// box1 = the earlier (kept candidate) box, box2 = the later one; pre1/pre2 their prepped records.
+__device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, const EdgeLds& L) {
+  RD_NOCONTRACT
+  float area1 = pre1[12], area2 = pre2[12];
+  // Fast path of the sort + de-duplication below.  When all 28 pairs of edge angles differ by at least EPS, w_less is the plain
+  // `<` on the angles -- a strict total order, so ANY sort returns the reference's permutation and the de-duplication loop
+  // keeps all 8 edges (every adjacent difference is > EPS).  The sorted position of an edge is then its rank, computed with
+  // straight-line code on registers (no divergent loops, no LDS traffic) and each edge is stored once, at its rank.
+  // Boxes with (nearly) parallel edges take the literal path.
+  int t;
+  {
+    float ang[8];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) { ang[z] = pre2[8 + z]; ang[z + 4] = pre1[8 + z]; }
+    int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool near = false;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) {
+        const float d = ang[i] - ang[j];
+        near |= !(fabsf(d) >= 1e-5f);                       // (NaN angles take the literal path too)
+        if (d < 0) ++rank[j]; else ++rank[i];
+      }
+    if (!near) {
+#pragma unroll
+      for (int z = 0; z < 4; ++z) {
+        int z1 = (z + 1) & 3;
+        WEdge e;
+        e.a = {pre2[2 * z], pre2[2 * z + 1]};
+        e.b = {pre2[2 * z1], pre2[2 * z1 + 1]};
+        e.ang = pre2[8 + z];
+        L.put(rank[z], e);
+        e.a = {pre1[2 * z], pre1[2 * z + 1]};
+        e.b = {pre1[2 * z1], pre1[2 * z1 + 1]};
+        e.ang = pre1[8 + z];
+        L.put(rank[z + 4], e);
+      }
+      t = 8;
+    } else {
+      t = w_sort_dedup_literal(pre1, pre2, L);
+    }
+  }
   L.q(0) = 0;
   L.q(1) = 1;
   int top = 1, bot = 0;
+  int i;
   for (i = 2; i < t; i++) {
     const WEdge li = L.get(i);
     while (top > bot && w_outside(li, L.get(L.q(top)), L.get(L.q(top - 1)))) top--;
