@@ -74,7 +74,6 @@ __device__ __forceinline__ bool w_outside(const WEdge& e0, const WEdge& e1, cons
 // (global memory).  They live in LDS instead, one column per lane: element i of lane t at [i*64 + t] (conflict-free).
 struct EdgeLds {
   float *ax, *ay, *bx, *by, *an;  // each [8][64]
-  int* dq;                        // [16][64]
   int t;
   __device__ __forceinline__ WEdge get(int i) const {
     WEdge e;
@@ -88,9 +87,8 @@ struct EdgeLds {
     bx[i * 64 + t] = e.b.x; by[i * 64 + t] = e.b.y;
     an[i * 64 + t] = e.ang;
   }
-  __device__ __forceinline__ int& q(int i) const { return dq[i * 64 + t]; }
 };
-constexpr int EDGE_LDS_BYTES = (5 * 8 + 16) * 64 * 4;
+constexpr int EDGE_LDS_BYTES = 5 * 8 * 64 * 4;
 
 // The reference's sort + de-duplication of the 8 edges, literally (nms.h:98-109): returns the number of edges kept, which then
 // sit in positions 0 .. t-1 of the per-lane edge array.
@@ -175,31 +173,34 @@ __device__ float w_overlap(const float* pre1, const float* pre2, bool is3d, cons
       t = w_sort_dedup_literal(pre1, pre2, L);
     }
   }
-  L.q(0) = 0;
-  L.q(1) = 1;
+  // the deque of edge positions (values 0..7, at most 10 entries) is a 64-bit register of 4-bit fields, not an LDS column: its
+  // reads sit at the head of every dependent chain of the sweep
+  unsigned long long dq = 0x10ull;                         // q[0] = 0, q[1] = 1
+  auto qg = [&](int k) -> int { return (int)((dq >> (4 * k)) & 15ull); };
+  auto qs = [&](int k, int v) { dq = (dq & ~(15ull << (4 * k))) | ((unsigned long long)v << (4 * k)); };
   int top = 1, bot = 0;
   int i;
   for (i = 2; i < t; i++) {
     const WEdge li = L.get(i);
-    while (top > bot && w_outside(li, L.get(L.q(top)), L.get(L.q(top - 1)))) top--;
-    while (top > bot && w_outside(li, L.get(L.q(bot)), L.get(L.q(bot + 1)))) bot++;
-    L.q(++top) = i;
+    while (top > bot && w_outside(li, L.get(qg(top)), L.get(qg(top - 1)))) top--;
+    while (top > bot && w_outside(li, L.get(qg(bot)), L.get(qg(bot + 1)))) bot++;
+    qs(++top, i);
   }
-  while (top > bot && w_outside(L.get(L.q(bot)), L.get(L.q(top)), L.get(L.q(top - 1)))) top--;
-  while (top > bot && w_outside(L.get(L.q(top)), L.get(L.q(bot)), L.get(L.q(bot + 1)))) bot++;
+  while (top > bot && w_outside(L.get(qg(bot)), L.get(qg(top)), L.get(qg(top - 1)))) top--;
+  while (top > bot && w_outside(L.get(qg(top)), L.get(qg(bot)), L.get(qg(bot + 1)))) bot++;
   {
-    const int qb = L.q(bot);
-    L.q(++top) = qb;
+    const int qb = qg(bot);
+    qs(++top, qb);
   }
   // polygon vertices + fan area (nms.h:147-166), vertices generated on the fly
   const int nv = top - bot;
   float inter = 0.f;
   if (nv >= 3) {
-    WPt p0 = w_meet(L.get(L.q(bot + 1)), L.get(L.q(bot)));
-    WPt pa = w_meet(L.get(L.q(bot + 2)), L.get(L.q(bot + 1)));
+    WPt p0 = w_meet(L.get(qg(bot + 1)), L.get(qg(bot)));
+    WPt pa = w_meet(L.get(qg(bot + 2)), L.get(qg(bot + 1)));
     float area = 0.f;
     for (int k = 2; k < nv; ++k) {
-      WPt pb = w_meet(L.get(L.q(bot + k + 1)), L.get(L.q(bot + k)));
+      WPt pb = w_meet(L.get(qg(bot + k + 1)), L.get(qg(bot + k)));
       area += w_cross3(p0, pa, pb);
       pa = pb;
     }
@@ -312,7 +313,6 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
   const int t = threadIdx.x;
   EdgeLds EL;
   EL.ax = edges; EL.ay = edges + 512; EL.bx = edges + 1024; EL.by = edges + 1536; EL.an = edges + 2048;
-  EL.dq = (int*)(edges + 2560);
   EL.t = t;
   const long ntile = (long)nrb * ncb * WN_CT;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -896,7 +896,6 @@ __global__ __launch_bounds__(64) void single_overlap_kernel(const float* __restr
   const int t = threadIdx.x;
   EdgeLds EL;
   EL.ax = edges; EL.ay = edges + 512; EL.bx = edges + 1024; EL.by = edges + 1536; EL.an = edges + 2048;
-  EL.dq = (int*)(edges + 2560);
   EL.t = t;
   const long i = (long)blockIdx.x * 64 + t;
   if (i >= n) return;
