@@ -477,9 +477,10 @@ int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const 
   for (int b0 = 0; b0 < B; b0 += nb) {
     hipLaunchKernelGGL(sort_keygen_kernel, dim3((unsigned)((N + 255) / 256), nb), dim3(256), 0, st, cls_score + (size_t)b0 * N,
                        mask ? mask + (size_t)b0 * N : nullptr, N, apply_sigmoid, s.keysA, s.idxA, stride);
-    int rc = radix_sort_pairs(s, N, st, nb, stride);
+    unsigned *rk, *ri;
+    int rc = radix_topk_pairs(s, N, k, st, nb, stride, &rk, &ri);
     if (rc != RD_OK) return rc;
-    hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((k + 255) / 256), nb), dim3(256), 0, st, s.keysA, s.idxA, k, D,
+    hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((k + 255) / 256), nb), dim3(256), 0, st, rk, ri, k, D,
                        bbox_delta + (size_t)b0 * N * D, pc + (size_t)b0 * N * 3, out_score + (size_t)b0 * k,
                        out_delta + (size_t)b0 * k * D, out_pc + (size_t)b0 * k * 3, out_idx ? out_idx + (size_t)b0 * k : nullptr,
                        stride, N);

@@ -44,6 +44,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+  for (size_t r = 0; r < h; ++r) memset((char*)p + r * pitch, v, w);
+  return hipSuccess;
+}
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
   for (size_t r = 0; r < h; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);

@@ -283,6 +283,39 @@ def test_sorted_foreground(be):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", ["all_equal", "top_ties", "half", "narrow"])
+def test_sorted_foreground_preselect_edges(be, case):
+    """The top-k pre-selection (12-bit threshold bin, ordered compaction, sort of the candidates only) against the full-sort
+    oracle on the distributions that stress it: every key in one bin, ties across the cut, k = N / 2 exactly, scores packed
+    into a few bins."""
+    rng = np.random.default_rng(11)
+    B, N, D = 2, 6000, 8
+    k = N // 2 if case == "half" else 1500
+    if case == "all_equal":
+        score = np.full((B, N), 0.7310586, np.float32)
+    elif case == "top_ties":
+        score = rng.uniform(0.0, 0.9, (B, N)).astype(np.float32)
+        score[:, rng.permutation(N)[:2000]] = 0.95           # 2000 equal best scores: the cut at k = 1500 falls inside the tie
+    elif case == "narrow":
+        score = (0.5 + rng.integers(0, 4, (B, N)) * 2.0 ** -12).astype(np.float32)   # four distinct values, one 12-bit bin
+    else:
+        score = rng.uniform(0.0, 1.0, (B, N)).astype(np.float32)
+    delta = rng.standard_normal((B, N, D)).astype(np.float32)
+    pc = rng.standard_normal((B, N, 3)).astype(np.float32)
+    L = be.lib
+    mask = np.ones((B, N), np.float32)
+    rs, rd, rp, ri = O.get_sorted_foreground(score, delta, pc, mask, k)
+    nb = L.raw("rd_sorted_foreground_workspace_bytes")(N, k) * B
+    ws = be.empty(nb)
+    o_s, o_d, o_p, o_i = be.empty(B * k * 4), be.empty(B * k * D * 4), be.empty(B * k * 12), be.empty(B * k * 4)
+    L.call("rd_sorted_foreground", be.ptr(be.up(score)), be.ptr(be.up(delta)), be.ptr(be.up(pc)), be.ptr(be.up(mask)), B, N, k, D, 0,
+           be.ptr(o_s), be.ptr(o_d), be.ptr(o_p), be.ptr(o_i), be.ptr(ws), nb, be.stream)
+    assert np.array_equal(be.down(o_i, np.int32, (B, k)), ri)
+    assert np.array_equal(be.down(o_s, np.float32, (B, k)), rs)
+    assert np.array_equal(be.down(o_d, np.float32, (B, k, D)), rd)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_decode3d_bbox(be):
     rng = np.random.default_rng(3)
     B, N = 2, 3000
