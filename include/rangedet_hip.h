@@ -172,7 +172,8 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
 size_t rd_sorted_foreground_workspace_bytes(long N, long k);
 /* cls_score (B,N) [logits when apply_sigmoid != 0], bbox_delta (B,N,D), pc (B,N,3), mask (B,N) ->
  * sorted_fg_score (B,k), sorted_fg_bbox_delta (B,k,D), sorted_fg_pc (B,k,3); optional sorted_idx (B,k) int32.
- * Order: score*mask descending, ties by flat index ascending.  Requires N >= k (get_sorted_foreground.py:65). */
+ * Order: score*mask descending, ties by flat index ascending.  Requires N >= k (get_sorted_foreground.py:65).
+ * (2k <= N: only the keys up to the k-th one's 12-bit bin are sorted -- same result, see k_sort.h.) */
 int rd_sorted_foreground(const float* cls_score, const float* bbox_delta, const float* pc, const float* mask,
                          int B, long N, long k, int D, int apply_sigmoid, float* out_score, float* out_delta,
                          float* out_pc, int* out_idx, void* ws, size_t ws_bytes, void* stream);
