@@ -809,19 +809,24 @@ struct TieSort {
     sync();
   }
 };
-constexpr int TIE_STACK_BYTES = 3 * 40 * 4;
+constexpr int TIE_STACK_BYTES = 3 * 40 * 4 + 16;   // introsort range stack + the two detection flags in front of it
 constexpr int TIE_LDS_K = 16384;   // keys + indices + range bitmap in LDS up to this K (130 KB); beyond it: global scratch
-__global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restrict__ dets, int cap,
+// 256 threads scan the scores (identity fill + "any tie / any rise"): that pass is all there is to do for most frames, and as a
+// single wave it kept the kernel resident for ~100 us (128 dependent iterations); wave 0 alone runs the replay when needed.
+__global__ __launch_bounds__(256) void wnms_tie_order_kernel(const float* __restrict__ dets, int cap,
                                                             const int* __restrict__ d_count, int* __restrict__ order,
                                                             WnmsBatch bs, long order_stride, int* __restrict__ scratch) {
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   dets += blockIdx.z * bs.dets; order += blockIdx.z * order_stride; scratch += blockIdx.z * bs.ints;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int K = d_count ? min(d_count[blockIdx.z], cap) : cap;
+  int* flags = (int*)smem;                       // [0] any tie, [1] any rise
+  if (tid < 2) flags[tid] = 0;
+  __syncthreads();
   // identity for the unused tail; strictly decreasing scores -> identity everywhere; non-increasing (sorted with ties) ->
   // only the ranges holding tied rows are replayed
   int tied = 0, rising = 0;
-  for (int i = lane; i < cap; i += 64) {
+  for (int i = tid; i < cap; i += 256) {
     order[i] = i;
     if (i + 1 < K) {
       const float a0 = dets[(size_t)i * 12 + 11], a1 = dets[(size_t)(i + 1) * 12 + 11];
@@ -829,9 +834,13 @@ __global__ __launch_bounds__(64) void wnms_tie_order_kernel(const float* __restr
       else if (!(a0 > a1)) rising = 1;
     }
   }
-  const bool any_tied = __ballot(tied) != 0ull, any_rising = __ballot(rising) != 0ull;
-  if (!any_tied && !any_rising) return;
-  int* stack = (int*)smem;                       // [3 * 40] introsort range stack, then (LDS variant) keys / indices / bitmaps
+  if (tied) flags[0] = 1;
+  if (rising) flags[1] = 1;
+  __threadfence();                               // the identity fill is in memory before wave 0 may overwrite parts of it
+  __syncthreads();
+  const bool any_tied = flags[0] != 0, any_rising = flags[1] != 0;
+  if ((!any_tied && !any_rising) || tid >= 64) return;   // (whole waves leave: the replay only uses wave-level barriers)
+  int* stack = (int*)(smem + 16);                // [3 * 40] introsort range stack, then (LDS variant) keys / indices / bitmaps
   unsigned char* lds = smem + TIE_STACK_BYTES;
   TieSort T;
   T.n = K; T.lane = lane;

@@ -550,7 +550,7 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   if (!ord && tie_order == RD_TIE_REFERENCE) {   // the reference's own order: std::sort replayed on the device
     const size_t lds = TIE_STACK_BYTES + (Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + 3 * ((size_t)Kcap / 32 + 2) * 4 : 0);
     allow_big_lds(wnms_tie_order_kernel);
-    hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(64), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
+    hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(256), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
                        w.scratch);
     ord = w.order;
     bs.order = (long)(per / 4);
