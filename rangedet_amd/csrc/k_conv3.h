@@ -692,9 +692,9 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // (fused output conv on the two-workgroup tiles: its 16 KB of weights no longer fit in LDS and are re-read from L2 per
   //  fragment and pass; measured per layer: W = 1328 213 -> 205 us, W = 664 109 -> 107 us, W = 2656 398 -> 405 us, so the
   //  full-width level stays on the 8 x 62 tile.  RD_CONV_HEAD30=0 -> never, =2 -> always)
-  const bool head30_ok = head30 == 2 || (head30 == 1 && W <= 1400);
-  const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 2;
+  const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && W <= 1400));   // (only exists on the 8 x 30 tiles)
+  const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
   const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !headfuse) || w30_128);
   RD_REQUIRE(!headfuse || !th4 || w30, RD_EINVAL, "conv3 + output conv: two workgroups per CU only on the 8 x 30 tiles");
