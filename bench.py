@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- range-image frames/s of the RangeDet inference hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without RANK/WORLD_SIZE in the environment: bench.py spawns
+                                                        its own N ranks, one per GPU; under torch.distributed.run it
+                                                        takes the launcher's ranks)
 
 One "step" = one full pass of the hot path over one batch (--batch, default 8) of synthetic 64x2650(pad 2656)x8 range
 images per rank (BASELINE config 4 runs 64 frames over 8 GPUs = 8 per GPU; frames are independent, batching only fills
@@ -146,7 +148,50 @@ def cpu_baseline(params, frames, budget_s=20.0):
                       "restatement" % len(steady)}
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_main(rank, world, port, argv):
+    """One spawned rank (python bench.py --gpus N without a launcher): the same environment torch.distributed.run would set."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    main(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no RANK / WORLD_SIZE: spawn the N ranks here, like the reference's eval driver starts one
+    module per GPU (tools/test.py:143-161); rank 0 prints the JSON line.  A failing rank fails the whole run (mp.spawn re-raises)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rank_main, args=(args.gpus, _free_port(), argv), nprocs=args.gpus, join=True)
+
+
+def dry_run(args, rank, world):
+    """RD_BENCH_DRYRUN=1: the launch / rendezvous / gather / reporting skeleton on the host alone (gloo; no GPU, no kernels):
+    every rank contributes its rank and frame list, rank 0 prints a JSON line.  Used by tests/test_dist.py."""
+    import torch
+    import torch.distributed as dist
+    from rangedet_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    shard = rdist.FrameSharding(rank, world)
+    mine = torch.tensor([rank] + shard.frames_of_step(0, args.batch), dtype=torch.int64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": [int(a[0]) for a in allr],
+                          "frames_step0": sorted(int(f) for a in allr for f in a[1:]), "max_over_ranks": float(t.item())}), flush=True)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -159,22 +204,41 @@ def main():
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
     ap.add_argument("--wnms-cap", type=int, default=8192, help="rows per frame the weighted NMS is sized for (checked every step)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    argv = list(sys.argv[1:] if argv is None else argv)
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torch.distributed.run, or our own spawn below
+    if args.gpus > 1 and not launched:
+        return self_launch(args, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if os.environ.get("RD_BENCH_DRYRUN"):
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
     from rangedet_amd import dist as rdist, lib as rdlib, synth
     from rangedet_amd.pipeline import InterleavedPipelines
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     gather = world > 1 or bool(os.environ.get("RD_BENCH_GATHER"))   # the env switch exercises the collective path on one GPU
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if gather:
         rdist.init_process_group("nccl", dev)
+    ranks_seen, rccl_version = [rank], None
+    if gather:
+        # every rank reports in through the communicator the data path uses (RCCL): proves N distinct ranks on N devices
+        me = torch.tensor([rank, local], device=dev, dtype=torch.int32)
+        seen = torch.zeros((world, 2), device=dev, dtype=torch.int32)
+        dist.all_gather_into_tensor(seen.view(-1), me)
+        ranks_seen = [int(r) for r in seen[:, 0].cpu()]
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001  (reporting only)
+            rccl_version = None
     shard = rdist.FrameSharding(rank, world)
     dt = rdlib.RD_BF16 if args.dtype == "bf16" else rdlib.RD_F32
 
@@ -325,7 +389,9 @@ def main():
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"])),
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
-                       "gathered_frames_last_step": gathered_frames},
+                       "gathered_frames_last_step": gathered_frames, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
+                       "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                   ("self (mp.spawn)" if world > 1 else "single process")},
             "roofline": roof, "meta_kernel": meta_info, "meta_dla_forward": backbone_info,
             # the whole path against both roofs: algorithmic conv-family bytes / flops of a frame + the
             # Meta-Kernel's, over the measured wall time per frame (everything included: NMS, launches, side stream)

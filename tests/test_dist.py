@@ -107,3 +107,32 @@ def test_sharding_arithmetic():
     assert record_floats() == 2401
     every = sorted(f for r in range(8) for st in range(2) for f in FrameSharding(r, 8).frames_of_step(st, 4))
     assert every == list(range(64))
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_launches_itself(launcher):
+    """`python bench.py --gpus 2` (the driver's command form) spawns its own two ranks when no launcher set RANK / WORLD_SIZE, and
+    also runs under torch.distributed.run; RD_BENCH_DRYRUN keeps it to the launch / rendezvous / gather / report skeleton (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RD_BENCH_DRYRUN"] = "1"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["ranks_seen"] == [0, 1] and d["n_gpus"] == 2 and d["frames_step0"] == list(range(16))
+
+
+def test_bench_world_mismatch_is_an_error_not_an_assert():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", RD_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
