@@ -13,8 +13,10 @@ input transform chain, the checker of rd_input_transform (csrc/k_input.h).
   GenerateFPNTarget / TransAndReshape   rangedet/core/input.py:560-624
   constants             config/rangedet/rangedet_veh_wo_aug_4_18e.py:245-282, :71
 
-PARITY UNPINNED: the reference module imports mxnet / numba / processing_cxx at module scope and none of them is in this
-image, so its classes cannot be imported to generate vectors; the chain is restated from the source, step by step.
+PARITY PINNED (round 3): bit-equal to the outputs of the reference's own transform objects (rangedet/core/input.py, with the
+parameter classes of the reference config) on the committed fixtures tests/golden/input_chain_*.npz and, through SHA-256
+digests, on two full-size 64x2650 records (tests/golden/make_ref_python_golden.py ran the reference chain in the build
+container with inert stand-ins for its unused module-scope imports; tests/test_ref_python_pins.py).
 The constants are restated here on purpose (not imported from the product): tests compare them with the product's.
 """
 import numpy as np

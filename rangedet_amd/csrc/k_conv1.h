@@ -141,7 +141,7 @@ inline bool conv1_eligible(const TapList& tl, int in_stride, int out_stride, int
   if ((in_stride != 1 && in_stride != 2) || Wq != (Win - 1) / in_stride + 1 || Wout != Wq) return false;
   if (cout != 64 && cout != 128) return false;
   const int nks = (cin + 15) / 16;   // 16-channel k-steps
-  return (nks == 1 || nks == 4 || nks == 8) && getenv("RD_CONV_V1") == nullptr;
+  return (nks == 1 || nks == 4 || nks == 8) && !dev_switches().conv_v1;
 }
 
 inline int launch_conv1(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,

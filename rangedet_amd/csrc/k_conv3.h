@@ -62,7 +62,11 @@ struct Conv3Args {
 // workgroups per CU -- the 4-row tile's stall hiding without its 6/4 halo rows, for the HBM-bound 64-channel layers.
 constexpr int C3_TW = 62;                  // output columns per tile (halo = 64 columns exactly), FC 2
 constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row, FC 2
-template <int NCT, int FPW = 4, int FC = 2> struct C3Cfg {
+// NHB = halo buffers (round 3).  2: the halo of unit u+1 is fetched while unit u is consumed.  3 (cout 64 on the 8 x 30 tiles
+// only -- the HBM-bound layers): the fetch runs TWO units ahead, so a piece has a whole unit (>= 9 steps) to arrive instead of
+// the 3 - 8 steps between its issue and the barrier of ordinal NS-2, and twice as many bytes are in flight per CU; the third
+// 20-KB buffer is paid for with a 5-deep instead of 8-deep weight ring and the (FOLD-unused) scale / shift array.
+template <int NCT, int FPW = 4, int FC = 2, int NHB = 2> struct C3Cfg {
   static constexpr int RW = FPW / FC;                    // output rows per wave
   static constexpr int TH = 4 * RW;                      // output rows per tile (8 or 4)
   static constexpr int COLS = 32 * FC;                   // halo columns
@@ -71,10 +75,11 @@ template <int NCT, int FPW = 4, int FC = 2> struct C3Cfg {
   static constexpr int HROWS = TH + 2;                   // halo rows
   static constexpr int HALO = HROWS * ROWB;              // bytes of one halo image
   static constexpr int HPW = HALO / 4096;                // 1-KB halo pieces per wave and unit
-  static constexpr int R = FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? (NCT == 4 ? 4 : 8) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
+  static_assert(NHB == 2 || (NHB == 3 && FPW == 2 && FC == 1 && NCT == 2), "three halo buffers: cout 64 on 8 x 30 tiles");
+  static constexpr int R = NHB == 3 ? 5 : FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? (NCT == 4 ? 4 : 8) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
   static constexpr int IPW = NCT / 2;                    // slab DMA instructions per wave per step
   static constexpr int SLAB = NCT * 2048;
-  static constexpr size_t LDS = 2 * HALO + (size_t)R * SLAB + 2 * NCT * 32 * sizeof(float);
+  static constexpr size_t LDS = (size_t)NHB * HALO + (size_t)R * SLAB + (NHB == 3 ? 0 : 2 * NCT * 32 * sizeof(float));
 };
 constexpr int C3_TH = C3Cfg<4, 4>::TH;     // (the FPW 4 geometry, for code that sizes things before choosing a variant)
 constexpr int C3_HALO = C3Cfg<4, 4>::HALO;
@@ -151,11 +156,12 @@ constexpr int c3_halo_first(int s, int NS, int HP) { int n = 0; for (int t = 0; 
 // DMA instructions a wave issues after "its part of slab g+2", as seen at the wait of step g (ordinal s of its unit):
 // the halo pieces of step g+2-R plus everything of steps g+3-R .. g-1.  Every step issues IPW slab instructions plus its
 // halo pieces.  At ordinal NS-2 the wait must also cover the last halo piece: the following step reads the next halo.
-constexpr int c3_younger(int R, int IPW, int s, int NS, int HP) {
+// (NHB 3: the next unit's halo was issued during the PREVIOUS unit, i.e. before every slab this count skips -- no cap.)
+constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
   int n = (R - 3) * IPW;
   for (int d = 1; d <= R - 2; ++d) n += c3_halo_pieces((((s - d) % NS) + NS) % NS, NS, HP);
   const int cap = (NS - 3 - c3_halo_last(NS, HP)) * IPW;
-  if (s == NS - 2 && n > cap) n = cap;
+  if (NHB == 2 && s == NS - 2 && n > cap) n = cap;
   return n;
 }
 // s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
@@ -169,13 +175,14 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP) {
 // through one rank-1 MFMA per accumulator at the start of every tile (A = the shift as a bf16 high + low pair in k = 0, 1;
 // B = ones) -- 4 * NCT MFMAs of the tile's 36 * 8 * NCT..., in exchange for which the epilogue has no multiply-add left:
 // it reads the accumulators, adds the residual if any, converts and clamps.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2>
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(NHB == 2 || FOLD, "three halo buffers: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
   static_assert(FC == 2 || (FC == 1 && FPW == 2), "30-column tiles: two fragments per wave");
-  using Cfg = C3Cfg<NCT, FPW, FC>;
+  using Cfg = C3Cfg<NCT, FPW, FC, NHB>;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int C3_HALO = Cfg::HALO, C3_HPW = Cfg::HPW, C3_TH = Cfg::TH;   // (shadow the FPW 4 file-scope constants)
   constexpr int C3_TW = Cfg::TW, C3_ROWB = Cfg::ROWB, RW = Cfg::RW;
@@ -185,10 +192,13 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  constexpr int RING = 2 * C3_HALO;
+  constexpr int RING = NHB * C3_HALO;
+  // byte offset of the halo buffer after / before buffer a in the cycle
+  auto hnext = [](int a_) { return NHB == 2 ? C3_HALO - a_ : (a_ == (NHB - 1) * C3_HALO ? 0 : a_ + C3_HALO); };
+  auto hprev = [](int a_) { return NHB == 2 ? C3_HALO - a_ : (a_ == 0 ? (NHB - 1) * C3_HALO : a_ - C3_HALO); };
   float* Sc = (float*)(smem + RING + R * SLAB);
   constexpr int HWOFF = RING + R * SLAB + 2 * COUT * (int)sizeof(float);   // HEAD: 16 KB of packed output-conv weights
-  if (tid < COUT) {
+  if (NHB == 2 && tid < COUT) {
     Sc[tid] = a.scale ? a.scale[tid] : 1.f;
     Sc[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
   }
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     const int cc = c16 + l4;
     const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
     const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
-    dma_v(ok ? (const void*)(sp + hlane) : (const void*)a.zero16, buf * C3_HALO + q * 1024);
+    dma_v(ok ? (const void*)(sp + hlane) : (const void*)a.zero16, buf + q * 1024);   // (buf = byte offset of the halo buffer)
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
   const int nslab_tile = a.nchunk * NS;
@@ -332,6 +342,11 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   halo_begin();
 #pragma unroll
   for (int j = 0; j < C3_HPW; ++j) halo_piece(0, j);
+  if constexpr (NHB == 3) {   // the fetch runs two units ahead: unit 1 as well
+    halo_begin();
+#pragma unroll
+    for (int j = 0; j < C3_HPW; ++j) halo_piece(C3_HALO, j);
+  }
   if constexpr (HEAD && FPW == 4) {   // (FPW 2: no LDS to spare for them with two workgroups per CU -- read from L2 in the epilogue)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_s(a.hw + (wave * 4 + j) * 1024, lane * 16, HWOFF + (wave * 4 + j) * 1024);
@@ -363,9 +378,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     const int acur_ = (aoff[dw_] + abuf + dh_ * C3_ROWB) ^ 32;                                                         \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
-    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? C3_HALO - abuf : abuf) + ndh_ * C3_ROWB;                       \
+    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? hnext(abuf) : abuf) + ndh_ * C3_ROWB;                          \
     const int bnext_ = boff + rnext_ * SLAB;                                                                         \
-    const int hbuf_ = abuf ? 0 : 1;                                                                                  \
+    const int hbuf_ = hprev(abuf);   /* NHB 2: the other buffer (unit u+1); NHB 3: unit u-1's, for unit u+2 */       \
     C3_FENCE();                                                                                                      \
     _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                                 \
       MM0(0, n)                                                                                                      \
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       if (n < NR) C3_RD(0, n, anext_, bnext_, 0)                                                                     \
     }                                                                                                                \
     if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RD(0, n, anext_, bnext_, 0) }          \
-    C3_SYNC(c3_younger(R, IPW, (S), NS, C3_HPW), NR)                                                                         \
+    C3_SYNC(c3_younger(R, IPW, (S), NS, C3_HPW, NHB), NR)                                                            \
     if ((S) == 0) halo_begin();                                                                                      \
     _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
       C3_MM(1, n)                                                                                                    \
@@ -413,13 +428,13 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       }
       C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
-      abuf = C3_HALO - abuf;
+      abuf = hnext(abuf);
     }
 #pragma unroll 1
     for (int c = 1; c < a.nchunk; ++c) {
       C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
-      abuf = C3_HALO - abuf;
+      abuf = hnext(abuf);
     }
     if (k == 0) C3_TRACE()
 
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     constexpr int JW = (32 * COUT * 2 <= C3_HALO / 4) ? NCT : NCT / 2, CW = JW * 32, NPASS = NCT / JW;
     static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1 || FPW == 2), "transpose scratch");
     constexpr int ROWB = CW * 2, SPR = CW / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
-    unsigned char* scr = smem + (C3_HALO - abuf) + wave * (C3_HALO / 4);
+    unsigned char* scr = smem + hprev(abuf) + wave * (C3_HALO / 4);   // (the buffer of the unit just consumed)
     bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
     // (base of image b, not of the wave's first row: rows past the image bottom must not even form an address beyond the buffer)
     const bf16_t* __restrict__ rimg0 = a.res + (size_t)b * a.r_bs + a.r_co;
@@ -499,10 +514,11 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       Slot16 rv[2][NCT][2];
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
         const int tc = 32 * (i % FC) + em, ow = ct * C3_TW + tc, oh = oh0 + i / FC;
-        const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh);
+        const bool live = tc < C3_TW && ow < a.W && oh < a.H && !(ow & sh) && !(DBG & 64);   // (DBG 64: every lane reads pixel 0 -- L2 hits)
         const bf16_t* rp = rimg0 + (live ? ((size_t)oh * a.Wo + (size_t)(ow >> sh)) * a.r_cs : 0) + 16 * ehi;
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
+          if (DBG & 128) { dst[j][0] = Slot16{0, 0, 0, 0}; dst[j][1] = Slot16{0, 0, 0, 0}; continue; }   // (DBG 128: no residual load)
           dst[j][0] = *(const Slot16*)(rp + j * 32);
           dst[j][1] = *(const Slot16*)(rp + j * 32 + 8);
         }
@@ -652,13 +668,24 @@ inline int conv_num_cus() {
 #endif
 }
 
+// One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB>
+inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB>;
+  static const bool once = (allow_big_lds(k), true);
+  (void)once;
+  constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  return check_launch("conv3x3_stream_kernel");
+}
+
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout) {
   if (dt != RD_BF16 || tl.n != 9 || (in_stride != 1 && in_stride != 2) || out_stride != 1) return false;
   if (Wq != (Win - 1) / in_stride + 1 || Wout != Wq) return false;   // pad 1, kernel 3
   if (cout != 64 && cout != 128) return false;
   for (int t = 0; t < 9; ++t)
     if (tl.dh[t] != t / 3 - 1 || tl.dw[t] != t % 3 - 1) return false;
-  return getenv("RD_CONV_V1") == nullptr;
+  return !dev_switches().conv_v1;
 }
 
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
@@ -686,13 +713,13 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // layers keep their 10/8 halo rows); 8 x 30 instead of 4 x 62 for the cout-128 layers another +1.4 % (14 % fewer halo
   // pieces per pixel, ring depth 4 instead of 3).  Dev switches: RD_CONV_TH4=0 -> cout 128 on 8 x 62, =3 -> cout 64 on
   // 4 x 62 too; RD_CONV_W30=0 -> no 8 x 30 tiles, =1 -> only for cout 64.
-  static const int th4_mode = getenv("RD_CONV_TH4") ? atoi(getenv("RD_CONV_TH4")) : 1;
-  static const int head30 = getenv("RD_CONV_HEAD30") ? atoi(getenv("RD_CONV_HEAD30")) : 1;
+  const DevSwitches& sw_ = dev_switches();
+  const int th4_mode = sw_.conv_th4, head30 = sw_.conv_head30, w30_mode = sw_.conv_w30;
+  const bool hb3 = sw_.conv_hb3 != 0;   // cout 64 on the 8 x 30 tiles: halo fetch two units ahead (three buffers)
   const bool headfuse = head && !sc;
   // (fused output conv on the two-workgroup tiles: its 16 KB of weights no longer fit in LDS and are re-read from L2 per
   //  fragment and pass; measured per layer: W = 1328 213 -> 205 us, W = 664 109 -> 107 us, W = 2656 398 -> 405 us, so the
   //  full-width level stays on the 8 x 62 tile.  RD_CONV_HEAD30=0 -> never, =2 -> always)
-  static const int w30_mode = getenv("RD_CONV_W30") ? atoi(getenv("RD_CONV_W30")) : 2;
   const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && W <= 1400));   // (only exists on the 8 x 30 tiles)
   const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
@@ -708,64 +735,47 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
 #define C3_DBG_CASE(D) if (cout == 128 && dbg == D) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); hipLaunchKernelGGL((conv3x3_stream_kernel<4, D>), dim3(grid), dim3(256), C3Cfg<4>::LDS, st, a); return check_launch("conv3x3_stream_kernel"); }
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
+  // cout 64 on the 8 x 30 tiles (plain 3x3, folded scales): 16 halo from the zero page, 64 residual from one L2-resident pixel,
+  // 128 no residual load, 4 no DMA after the prologue, 8 no MFMAs
+#define C3_DBG64(D)                                                                                                     \
+  if (cout == 64 && w30 && !sc && ts == 0 && dbg == D) {                                                                \
+    if (hb3) { auto k = conv3x3_stream_kernel<2, D, 0, false, false, true, 2, 1, 3>; allow_big_lds(k);                  \
+               hipLaunchKernelGGL(k, dim3(grid), dim3(256), (C3Cfg<2, 2, 1, 3>::LDS), st, a); }                         \
+    else { auto k = conv3x3_stream_kernel<2, D, 0, false, false, true, 2, 1, 2>; allow_big_lds(k);                      \
+           hipLaunchKernelGGL(k, dim3(grid), dim3(256), (C3Cfg<2, 2, 1, 2>::LDS), st, a); }                             \
+    return check_launch("conv3x3_stream_kernel<dbg>");                                                                  \
+  }
+  C3_DBG64(4) C3_DBG64(8) C3_DBG64(16) C3_DBG64(64) C3_DBG64(128)
+#undef C3_DBG64
 #endif
-  if (th4 && !w30) {
-#define C3_LAUNCH_TH4(N)                                                                                                          \
-  {                                                                                                                             \
-    constexpr size_t L2 = C3Cfg<N, 2>::LDS;                                                                                     \
-    if (sc) {                                                                                                                   \
-      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a); \
-      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, true, true, 2>), dim3(grid), dim3(256), L2, st, a); \
-      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);                                                      \
-    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a); \
-    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a); \
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 2, false, false, true, 2>), dim3(grid), dim3(256), L2, st, a);           \
-  }
-    if (cout == 128) C3_LAUNCH_TH4(4) else C3_LAUNCH_TH4(2)
-#undef C3_LAUNCH_TH4
-    return check_launch("conv3x3_stream_kernel<th4>");
-  }
-  if (w30) {
-#define C3_LAUNCH_W30(N)                                                                                                          \
-  {                                                                                                                             \
-    constexpr size_t L3 = C3Cfg<N, 2, 1>::LDS;                                                                                  \
-    if (sc) {                                                                                                                   \
-      if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
-      else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, true, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
-      else return rd::fail(RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);                                                      \
-    } else if (ts == 0) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 0, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
-    else if (ts == 1) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 1, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a); \
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, 2, false, false, true, 2, 1>), dim3(grid), dim3(256), L3, st, a);        \
-  }
-    constexpr size_t LH = C3Cfg<4, 2, 1>::LDS;
-    if (headfuse) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true, false, true, 2, 1>), dim3(grid), dim3(256), LH, st, a);
-    else if (cout == 128) C3_LAUNCH_W30(4) else C3_LAUNCH_W30(2)
-#undef C3_LAUNCH_W30
-    return check_launch("conv3x3_stream_kernel<w30>");
-  }
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
     RD_REQUIRE(fold, RD_EINVAL, "conv3 + shortcut: the weights must carry the folded scales (RD_SCALE_FOLDED)");
-#define C3_LAUNCH_SC(N, T_) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, true, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a)
-    if (cout == 128) { if (ts == 0) C3_LAUNCH_SC(4, 0); else C3_LAUNCH_SC(4, 1); }
-    else { if (ts == 0) C3_LAUNCH_SC(2, 0); else C3_LAUNCH_SC(2, 1); }
-#undef C3_LAUNCH_SC
-    return check_launch("conv3x3_stream_kernel<sc>");
   }
-  if (head) {
-    if (fold) hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true, false, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<4, 0, 0, true>), dim3(grid), dim3(256), C3Cfg<4>::LDS + 16384, st, a);
-    return check_launch("conv3x3_stream_kernel<head>");
+  // (tile shape, cout) -> instantiation; within it (tap set, shortcut).  All of these carry folded scales.
+#define C3_BODY(N, FPW_, FC_, NHB_)                                                                       \
+  {                                                                                                       \
+    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_>(grid, st, a)                 \
+                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_>(grid, st, a);                \
+    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_>(grid, st, a)                        \
+         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_>(grid, st, a)                        \
+                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_>(grid, st, a);                       \
   }
-#define C3_LAUNCH(N, T_)                                                                                                        \
-  {                                                                                                                             \
-    if (fold) hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_, false, false, true>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a); \
-    else hipLaunchKernelGGL((conv3x3_stream_kernel<N, 0, T_>), dim3(grid), dim3(256), C3Cfg<N>::LDS, st, a);                     \
+  if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) }
+  if (w30) {
+    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2>(grid, st, a);
+    if (cout == 128) C3_BODY(4, 2, 1, 2)
+    if (hb3) C3_BODY(2, 2, 1, 3)
+    C3_BODY(2, 2, 1, 2)
   }
-  if (cout == 128) { if (ts == 0) C3_LAUNCH(4, 0) else if (ts == 1) C3_LAUNCH(4, 1) else C3_LAUNCH(4, 2) }
-  else { if (ts == 0) C3_LAUNCH(2, 0) else if (ts == 1) C3_LAUNCH(2, 1) else C3_LAUNCH(2, 2) }
-#undef C3_LAUNCH
-  return check_launch("conv3x3_stream_kernel");
+  if (head && !sc) return fold ? c3_go<4, 0, true, false, true, 4, 2, 2>(grid, st, a) : c3_go<4, 0, true, false, false, 4, 2, 2>(grid, st, a);
+  if (fold) { if (cout == 128) C3_BODY(4, 4, 2, 2) else C3_BODY(2, 4, 2, 2) }
+#undef C3_BODY
+  // scale / shift applied in the epilogue (stand-alone use of the C ABI; the lowering always folds)
+#define C3_PLAIN(N) return ts == 0 ? c3_go<N, 0, false, false, false, 4, 2, 2>(grid, st, a) : ts == 1 ? c3_go<N, 1, false, false, false, 4, 2, 2>(grid, st, a) : c3_go<N, 2, false, false, false, 4, 2, 2>(grid, st, a);
+  if (cout == 128) { C3_PLAIN(4) }
+  C3_PLAIN(2)
+#undef C3_PLAIN
 }
 
 }  // namespace rd

@@ -333,7 +333,7 @@ inline int radix_sort_pairs(const SortWs& s, long N, hipStream_t st, int nb = 1,
 
 // the k smallest (key, index) pairs of keysA / idxA, sorted: in *rk / *ri (one of the two buffer pairs; positions >= k unspecified)
 inline int radix_topk_pairs(const SortWs& s, long N, long k, hipStream_t st, int nb, long ws_stride, unsigned** rk, unsigned** ri) {
-  static const bool off = getenv("RD_SORT_NO_SELECT") != nullptr;      // dev switch
+  const bool off = dev_switches().sort_no_select;      // dev switch
   *rk = s.keysA; *ri = s.idxA;
   if (off || 2 * k > N) return radix_sort_pairs(s, N, st, nb, ws_stride);
   { int rc = sort_clear(s, st, nb, ws_stride, true); if (rc != RD_OK) return rc; }

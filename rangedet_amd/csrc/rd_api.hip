@@ -43,57 +43,10 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   w.sort_ws = p;
   return w;
 }
-template <class K>
-inline void allow_big_lds(K kernel) {
-  // (a kernel with static LDS cannot take the full 160 KB as dynamic: the attribute call then fails, the launch with the
-  // size actually requested still works -- do not leave that status behind for the next check_launch)
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-    (void)hipGetLastError();
-}
-inline void allow_conv_lds() {
-  allow_big_lds(conv3x3_stream_kernel<4>);
-  allow_big_lds(conv3x3_stream_kernel<2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 2, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 2, false, false, true>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 2, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 2, false, false, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true, true, 2>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 2, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 0, false, true, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<2, 0, 1, false, true, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 2, false, false, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, false, true, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 1, false, true, true, 2, 1>);
-  allow_big_lds(conv3x3_stream_kernel<4, 0, 0, true, false, true, 2, 1>);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>);
-  allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
+inline void allow_conv_lds() {   // the generic tap kernel (the persistent 3x3 kernel does this per instantiation, k_conv3.h c3_go)
+  static const bool once = (allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>), allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>),
+                            allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>), allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>), true);
+  (void)once;
 }
 }  // namespace rd
 
@@ -310,7 +263,7 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
   RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "conv3x3_ex: x channel stride/offset");
   RD_REQUIRE(!(sc_x && residual) && !(sc_x && !sc_w_packed), RD_EINVAL, "conv3x3_ex: shortcut conv and residual are exclusive");
   RD_REQUIRE(!((flags & RD_ADD) && !residual && !sc_x), RD_EINVAL, "conv3x3_ex: RD_ADD without residual / shortcut");
-  RD_REQUIRE(getenv("RD_CONV_V1") == nullptr, RD_EINVAL, "conv3x3_ex: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
+  RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "conv3x3_ex: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
   allow_conv_lds();
   const int v = stride_w;                      // pixels per view pixel
   const int Wv = Win / v;
@@ -348,7 +301,7 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
   RD_REQUIRE(!(flags & RD_ADD), RD_EINVAL, "conv2d_head_out: no residual in a head tower");
   RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE,
              "conv2d_head_out: x channel stride/offset");
-  RD_REQUIRE(getenv("RD_CONV_V1") == nullptr, RD_EINVAL, "conv2d_head_out: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
+  RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "conv2d_head_out: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
   allow_conv_lds();
   Conv3Args h;
   memset(&h, 0, sizeof(h));
@@ -374,7 +327,7 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   if (deconv_embeds_3x3(tl)) {
     const int ts = deconv_tap_set(tl);
     if (!ts) tl = conv_taps(3, 3);   // packed as a full 3x3 window with zero weights (rd_pack_deconv_weight_host)
-    if (dtype == RD_BF16 && Wout == stride_w * Win && (cout == 64 || cout == 128) && getenv("RD_CONV_V1") == nullptr) {
+    if (dtype == RD_BF16 && Wout == stride_w * Win && (cout == 64 || cout == 128) && !dev_switches().conv_v1) {
       // phase pixels of the output seen as [H][Win][stride_w * Cstride]: channel offset phase * Cstride
       const bf16_t* r = (const bf16_t*)residual;
       return launch_conv3(x, x_cstride, x_coff, w_packed_phase, scale, shift, r, r_cstride * stride_w,
@@ -579,7 +532,7 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   // only for the later rows that are still unsuppressed (compacted list) and resumes the scan.  Results are identical
   // to the one-round form -- the skipped rows are exactly the ones whose bits nobody reads.
   const int R1 = 256, nb1 = R1 / 64;
-  static const bool one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;   // dev switch (tools/wnms_bench.py)
+  const bool one_round = dev_switches().wnms_one_round;   // dev switch (tools/wnms_bench.py)
   const bool two = Kcap >= 4 * R1 && !one_round;
   // pair tiles are strided over a fixed number of single-wave workgroups per frame: one tile each at the pipeline's typical K
   // (1 - 2 k rows: <= 2048 tiles per round), grid-strided beyond that -- so the launch size does not grow with the capacity

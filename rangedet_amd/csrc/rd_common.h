@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -35,6 +36,42 @@ inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RD_EHIP, "%s: %s", what, hipGetErrorString(e));
   return RD_OK;
+}
+
+// ---- development switches: the environment is read ONCE per process (not per launch) ---------------------------------
+// None is needed in production; each exists so that an A/B of one change can be run on one box inside one gpurun call
+// (DESIGN.md, table of development switches).
+struct DevSwitches {
+  bool conv_v1;            // RD_CONV_V1: generic tap kernel instead of the persistent 3x3 / streaming 1x1 kernels
+  int conv_th4;            // RD_CONV_TH4 (0..3, default 1), RD_CONV_W30 (0..2, default 2), RD_CONV_HEAD30 (0..2, default 1): tile shapes
+  int conv_w30, conv_head30;
+  int conv_hb3;            // RD_CONV_HB3 (default 1): cout 64 on 8 x 30 tiles fetches its halo two units ahead (three buffers)
+  bool sort_no_select;     // RD_SORT_NO_SELECT
+  bool wnms_one_round;     // RD_WNMS_ONE_ROUND
+};
+inline const DevSwitches& dev_switches() {
+  static const DevSwitches s = [] {
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    DevSwitches d;
+    d.conv_v1 = getenv("RD_CONV_V1") != nullptr;
+    d.conv_th4 = num("RD_CONV_TH4", 1);
+    d.conv_w30 = num("RD_CONV_W30", 2);
+    d.conv_head30 = num("RD_CONV_HEAD30", 1);
+    d.conv_hb3 = num("RD_CONV_HB3", 1);
+    d.sort_no_select = getenv("RD_SORT_NO_SELECT") != nullptr;
+    d.wnms_one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;
+    return d;
+  }();
+  return s;
+}
+
+// A kernel that takes more than 64 KB of dynamic LDS must say so once.  (A kernel with static LDS cannot take the full 160 KB as
+// dynamic: the attribute call then fails while the launch with the size actually requested still works -- do not leave that
+// status behind for the next check_launch.)
+template <class K>
+inline void allow_big_lds(K kernel) {
+  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    (void)hipGetLastError();
 }
 
 // ---- per-kind event profiling ------------------------------------------------------------------------
