@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
+NPIX = 64 * 2656            # padded pixels of a frame (set by main() for the configuration that runs)
+META_FLOP_PER_PX = 19.29e9 / (64 * 2656)   # 19.29 GFLOP per 64 x 2656 frame
 
 
 def is_conv3(s):
@@ -81,8 +83,8 @@ def backbone_forward_roofline(pipe, frame, Bf, esz, reps=2):
     nb = next(i for i, s in enumerate(steps) if str(s.get("name", "")).startswith("rpn_"))
     sub = copy.copy(pipe.plan)
     sub.steps = steps[:nb]
-    gb = (conv_bytes(sub, esz) + 64 * 2656 * (128 * esz + 12)) / 1e9
-    gf = (conv_flops(sub)[0] + 19.29e9) / 1e9
+    gb = (conv_bytes(sub, esz) + NPIX * (128 * esz + 12)) / 1e9
+    gf = (conv_flops(sub)[0] + META_FLOP_PER_PX * NPIX) / 1e9
     dev = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # (few repetitions on purpose: these launches are outside the pipeline replay that the `roofline` block averages, and
@@ -105,7 +107,7 @@ def backbone_forward_roofline(pipe, frame, Bf, esz, reps=2):
     torch.cuda.synchronize()
     mms, mcnt = L.prof()["meta"]
     L.call("rd_prof_enable", 0)
-    mbytes = Bf * 64 * 2656 * (128 * esz + 12)
+    mbytes = Bf * NPIX * (128 * esz + 12)
     meta_alone = {"avg_launch_ms": mms / max(mcnt, 1), "gbps": mbytes / (mms / max(mcnt, 1) * 1e-3) / 1e9 if mcnt else 0.0}
     meta_alone["frac_hbm_peak"] = meta_alone["gbps"] / PEAK_HBM_GBPS
     return {"meta_kernel_alone": meta_alone,"scope": "Meta-Kernel + DLA backbone forward: plan steps 0..%d (input layout, %d conv-family launches, the fused "
@@ -196,7 +198,12 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="arithmetic type of activations / weights (fp32 accumulation): bf16 = BASELINE configs[1]; f16 = the reference's "
+                         "own mixed-precision type (config fp16 = True); f32 = parity mode")
+    ap.add_argument("--config", default="waymo", choices=["waymo", "kitti"],
+                    help="waymo = rangedet_veh_wo_aug_4_18e on 64x2650(pad 2656)x8 (BASELINE configs[1]/[2], the metric's workload); "
+                         "kitti = BASELINE configs[4]: 64x2048x5 range images, vehicle + pedestrian heads (named in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (pipelines on separate streams)")
@@ -240,26 +247,45 @@ def main(argv=None):
         except Exception:      # noqa: BLE001  (reporting only)
             rccl_version = None
     shard = rdist.FrameSharding(rank, world)
-    dt = rdlib.RD_BF16 if args.dtype == "bf16" else rdlib.RD_F32
+    dt = {"bf16": rdlib.RD_BF16, "f16": rdlib.RD_F16, "f32": rdlib.RD_F32}[args.dtype]
 
-    params = synth.make_weights(seed=18)
+    global NPIX
+    kitti = args.config == "kitti"
     Bf = args.batch
+    if kitti:
+        # KITTI range images (datasets/create_range_image_in_kitti.py:121,126): 64 x 2048, channels range, x, y, z, intensity
+        from rangedet_amd.config.rangedet_veh_wo_aug_4_18e import KITTI_INPUT_CHANNELS
+        Hk, Wk = 64, 2048
+        NPIX = Hk * Wk
+        params = synth.make_weights(seed=18, width=Wk, in_ch=KITTI_INPUT_CHANNELS, num_classes=2)
+        pkw = dict(variant="kitti", feat_size=(Hk, Wk), pad_field=(Hk, Wk), pre_nms_top_n={'veh': 50000, 'ped': 5000})
+    else:
+        params = synth.make_weights(seed=18)
+        pkw = {}
     multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=args.wnms_cap, batch=Bf,
-                                 tie_order=args.tie_order)
+                                 tie_order=args.tie_order, **pkw)
     pipe = multi.pipes[0]   # (per-kernel profiling replay and the roofline figures use one pipeline on the default stream)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
     # (synthetic raw records through the device transform chain, rd_input_transform)
-    frames = [synth.make_batch(shard.frames_of_step(i, Bf), lib=pipe.lib, alloc=pipe.alloc) for i in range(args.frames)]
+    if kitti:
+        frames = [synth.make_batch(shard.frames_of_step(i, Bf), W=Wk, pad_W=Wk, H=Hk, lib=pipe.lib, alloc=pipe.alloc) for i in range(args.frames)]
+        for f in frames:   # the Waymo-style synthetic record's channels in KITTI order: range, x, y, z, intensity
+            f['input_data'] = f['input_data'][:, [0, 3, 4, 5, 1]].contiguous()
+    else:
+        frames = [synth.make_batch(shard.frames_of_step(i, Bf), lib=pipe.lib, alloc=pipe.alloc) for i in range(args.frames)]
     L = pipe.lib
     A = pipe.alloc
     gathers = [rdist.DetectionGather(p.bpost, shard, A, L) for p in multi.pipes] if gather else None
     # every step's results go to the host like the reference's loop materialises every frame (tools/test.py:151-153):
     # per pipeline, pinned host buffers for the (B, 200, 8) boxes, the keep counts and the candidate counts, filled by async
     # copies on the batch's post-processing stream
-    host = [dict(d8=torch.empty((Bf, rdist.MAX_DET, 8), dtype=torch.float32).pin_memory(),
-                 nkeep=torch.empty((Bf,), dtype=torch.int32).pin_memory(),
-                 count=torch.empty((Bf,), dtype=torch.int32).pin_memory(), done=None, step=-1,
-                 stage=A.alloc(Bf * rdist.MAX_DET * 32)) for _ in multi.pipes]
+    classes = pipe.class_names                      # one class (waymo config) or vehicle + pedestrian (kitti)
+    host = [{c: dict(d8=torch.empty((Bf, rdist.MAX_DET, 8), dtype=torch.float32).pin_memory(),
+                     nkeep=torch.empty((Bf,), dtype=torch.int32).pin_memory(),
+                     count=torch.empty((Bf,), dtype=torch.int32).pin_memory(),
+                     stage=A.alloc(Bf * rdist.MAX_DET * 32)) for c in classes} for _ in multi.pipes]
+    for h in host:
+        h.update(done=None, step=-1)
     max_cand = [0]
 
     def harvest(j):
@@ -269,10 +295,11 @@ def main(argv=None):
         if h["done"] is None:
             return None
         h["done"].synchronize()
-        kmax = int(h["count"].max())
-        if kmax > multi.pipes[j].bpost.cap:
-            raise RuntimeError("step %d: %d candidates above min_score exceed --wnms-cap %d" % (h["step"], kmax, multi.pipes[j].bpost.cap))
-        max_cand[0] = max(max_cand[0], kmax)
+        for c in classes:
+            kmax = int(h[c]["count"].max())
+            if kmax > multi.pipes[j].bposts[c].cap:
+                raise RuntimeError("step %d: %d %s candidates above min_score exceed --wnms-cap %d" % (h["step"], kmax, c, multi.pipes[j].bposts[c].cap))
+            max_cand[0] = max(max_cand[0], kmax)
         h["done"] = None
         return h
 
@@ -283,14 +310,16 @@ def main(argv=None):
         harvest(j)                                         # the batch that last used this pipeline (two steps ago)
         j2, _ = multi.enqueue(frames[i % len(frames)])
         assert j2 == j
-        pj, bp, h = multi.pipes[j], multi.pipes[j].bpost, host[j]
+        pj, h = multi.pipes[j], host[j]
         with torch.cuda.stream(pj._post_stream):
-            nd = min(rdist.MAX_DET, bp.cap)
-            L.call("rd_copy_rows", A.ptr(bp.out8), bp.cap * 32, A.ptr(h["stage"]), rdist.MAX_DET * 32, 0, nd * 32, Bf,
-                   pj._post_stream.cuda_stream)          # first 200 rows of every frame -> one contiguous block
-            h["d8"].copy_(A.view_f32(h["stage"], (Bf, rdist.MAX_DET, 8)), non_blocking=True)
-            h["nkeep"].copy_(A.view_i32(bp.nkeep, (Bf,)), non_blocking=True)
-            h["count"].copy_(A.view_i32(bp.count, (Bf,)), non_blocking=True)
+            for c in classes:
+                bp, hc = pj.bposts[c], h[c]
+                nd = min(rdist.MAX_DET, bp.cap)
+                L.call("rd_copy_rows", A.ptr(bp.out8), bp.cap * 32, A.ptr(hc["stage"]), rdist.MAX_DET * 32, 0, nd * 32, Bf,
+                       pj._post_stream.cuda_stream)          # first 200 rows of every frame -> one contiguous block
+                hc["d8"].copy_(A.view_f32(hc["stage"], (Bf, rdist.MAX_DET, 8)), non_blocking=True)
+                hc["nkeep"].copy_(A.view_i32(bp.nkeep, (Bf,)), non_blocking=True)
+                hc["count"].copy_(A.view_i32(bp.count, (Bf,)), non_blocking=True)
             if gather:
                 # the ONE collective of the path, enqueued behind this batch's post-processing on its side stream: the next
                 # batch's forward overlaps it, nothing on a launch stream waits for it
@@ -323,7 +352,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last = (args.warmup + args.steps - 1) % len(multi.pipes)
-    res = multi.pipes[last].post[0].collect()
+    res = multi.pipes[last].collect()[0]
     gathered_frames = len(gathers[last].unpack((args.warmup + args.steps - 1))) if gather else None
 
     # ---- per-kernel timing with HIP events on the launch stream, over a replay of the same steps ------------------
@@ -338,7 +367,7 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
         prof = L.prof()
         L.call("rd_prof_enable", 0)
-        bf = dt == rdlib.RD_BF16
+        bf = dt in rdlib.H16
         # dominant kernel: bf16 = the persistent 3x3 stride-1 kernel (own profiling kind); f32 = the generic tap kernel
         fl, nlaunch = conv_flops(pipe.plan, only_conv3=bf)
         ms, cnt = prof["conv3" if bf else "conv"]
@@ -359,12 +388,12 @@ def main(argv=None):
                 "all_conv_family": {"launches_per_step": n_all, "gflop_per_frame": fl_all / 1e9,
                                     "tflops": fl_all * Bf * nprof / (ms_all * 1e-3) / 1e12 if ms_all else 0.0}}
         mms, mcnt = prof["meta"]
-        esz = 2 if dt == rdlib.RD_BF16 else 4
-        mbytes = Bf * 64 * 2656 * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)
+        esz = 2 if dt in rdlib.H16 else 4
+        mbytes = Bf * NPIX * ((64 + 64) * esz + 3 * 4)  # compulsory: data in + out, coords fp32 (262 B/px bf16)
         meta_info = {"kernel": "meta_kernel (fused Meta-Kernel unit)", "bound": "hbm",
                      "achieved": mbytes / (mms / max(mcnt, 1) * 1e-3) / 1e9 if mcnt else 0.0, "peak": PEAK_HBM_GBPS,
                      "unit": "GB/s", "avg_launch_ms": mms / max(mcnt, 1), "bytes_per_launch": mbytes,
-                     "tflops": Bf * 19.29e9 / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
+                     "tflops": Bf * META_FLOP_PER_PX * NPIX / (mms / max(mcnt, 1) * 1e-3) / 1e12 if mcnt else 0.0}
         meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
         meta_info["traffic"] = measured_traffic("meta_kernel", Bf) if dt == rdlib.RD_BF16 else None
         backbone_info = backbone_forward_roofline(pipe, frames[0], Bf, esz)
@@ -373,7 +402,7 @@ def main(argv=None):
         alone = backbone_info.pop("meta_kernel_alone")
         meta_info.update({"in_pipeline_avg_launch_ms": meta_info["avg_launch_ms"], "in_pipeline_gbps": meta_info["achieved"],
                           "avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["gbps"], "frac": alone["frac_hbm_peak"],
-                          "tflops": Bf * 19.29e9 / (alone["avg_launch_ms"] * 1e-3) / 1e12,
+                          "tflops": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12,
                           "note": "achieved / avg_launch_ms: serial replay of the kernel alone (HIP events); in_pipeline_*: the "
                                   "same launch inside the timed pipeline, where the previous batch's NMS kernels share the GPU"})
 
@@ -383,10 +412,15 @@ def main(argv=None):
             "value": args.steps * world * Bf / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "rangedet_veh_wo_aug_4_18e: DLA backbone + Meta-Kernel + heads + top-50000 + 3D decode "
+            "config": {"workload": ("KITTI-shaped (BASELINE configs[4]): DLA backbone + Meta-Kernel + vehicle and pedestrian heads + per-class "
+                                    "top-k (50000 / 5000) + 3D decode + weighted NMS per class on 64x2048 x 5ch synthetic range images, "
+                                    "%d frames per step per GPU, random-init weights (seed 18)" % Bf) if kitti else
+                                   "rangedet_veh_wo_aug_4_18e: DLA backbone + Meta-Kernel + heads + top-50000 + 3D decode "
                                    "+ weighted NMS on 64x2650 (pad 2656) x 8ch synthetic range images, %d frames per step per GPU, " % Bf + ""
                                    "random-init weights (seed 18)", "frames_per_step": world * Bf, "frames_per_gpu_per_step": Bf, "batches_in_flight_per_gpu": len(multi.pipes), "parallelism": "frame-parallel dp%d" % world,
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"])),
+                       "per_class": {c: {"candidates": int(r["num_candidates"]), "kept": int(len(r["keep_inds"]))}
+                                     for c, r in res.get("per_class", {}).items()} or None,
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
@@ -400,11 +434,11 @@ def main(argv=None):
                                                    "gflop_per_frame": gf, "tflops": gf / sec / 1e3,
                                                    "frac_mfma_peak": gf / sec / 1e3 / PEAK_BF16_TFLOPS})(
                 elapsed / (args.steps * world * Bf) * world,
-                (conv_bytes(pipe.plan, 2 if dt == rdlib.RD_BF16 else 4) + 64 * 2656 * 262) / 1e9,
-                (conv_flops(pipe.plan)[0] + 19.29e9) / 1e9),
+                (conv_bytes(pipe.plan, 2 if dt in rdlib.H16 else 4) + NPIX * 262) / 1e9,
+                (conv_flops(pipe.plan)[0] + META_FLOP_PER_PX * NPIX) / 1e9),
             "kernel_ms_per_frame": {k: v[0] / max(1, min(args.steps, 20)) / Bf for k, v in prof.items()},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not kitti:
             from oracle import input_ref   # (the checker's numpy transform: only this leg may touch oracle/)
             out["cpu_baseline"] = cpu_baseline(params, [input_ref.make_frame(i) for i in range(3)])
         line = json.dumps(out)

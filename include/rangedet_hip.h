@@ -34,7 +34,7 @@
  *     device memory and never keeps a pointer past the call.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are re-entrant.
  *   - activations inside the library are channels-last: [B][H][W][Cstride] with the used channels at
- *     [coff, coff+C); element type RD_F32 (float) or RD_BF16 (raw uint16 bfloat16).
+ *     [coff, coff+C); element type RD_F32 (float), RD_BF16 (raw uint16 bfloat16) or RD_F16 (raw uint16 IEEE half).
  *     rd_nchw_to_nhwc / rd_nhwc_to_nchw convert at the reference's NCHW float32 boundary.
  */
 #ifndef RANGEDET_HIP_H_
@@ -54,12 +54,14 @@ extern "C" {
 
 #define RD_F32 0
 #define RD_BF16 1
+#define RD_F16 2  /* IEEE binary16: the reference's own mixed-precision type (config fp16 = True, dla_backbone.py:136-137 to_fp16,
+                   * builder.py:257-261 to_fp32); every 16-bit layout is shared with RD_BF16 */
 
 /* epilogue flags of the conv family */
 #define RD_RELU_PRE 1  /* ReLU directly after the BN affine (before the residual add)        */
 #define RD_ADD 2       /* add `residual`                                                     */
 #define RD_RELU_POST 4 /* ReLU after the residual add                                        */
-#define RD_SCALE_FOLDED 8 /* bf16 3x3 family only: the packer folded the BatchNorm scale into the weights (fold_scale argument of
+#define RD_SCALE_FOLDED 8 /* 16-bit 3x3 family only: the packer folded the BatchNorm scale into the weights (fold_scale argument of
                            * the packers); `scale` must be NULL.  The shift then enters the accumulators through one extra MFMA
                            * per accumulator and the epilogue has no multiply-add (what the production lowering uses) */
 
@@ -109,7 +111,7 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
                      const float* shift, const void* residual, int r_cstride, int r_coff, void* y,
                      int y_cstride, int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw,
                      int stride_w, int flags, int dtype, void* stream);
-/* Second conv of a BasicBlock in its extended forms (dla_backbone.py:18-56; bf16, persistent kernel):
+/* Second conv of a BasicBlock in its extended forms (dla_backbone.py:18-56; dtype RD_BF16 or RD_F16, persistent kernel):
  *   stride_w 2  (`conv2` of the first unit of a down-sampling stage, dla_backbone.py:139-143): computed on the pixel-pair view
  *               of x -- [H][Win][cs] with Win even read as [H][Win/2][2*cs] -- as a stride-1 conv with six taps, so only the
  *               stored pixels are computed; weights packed by rd_pack_conv3x3_ex_host(stride_w = 2, x_cstride);
@@ -120,24 +122,26 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
  * Otherwise the contract of rd_conv2d_bn_act (3x3, pad 1).  sc_x: [B][H][Win][sc_cstride], channels [sc_coff, sc_coff+sc_cin). */
 size_t rd_conv3x3_ex_packed_bytes(int cin, int cout, int stride_w, int x_cstride);
 int rd_pack_conv3x3_ex_host(const float* w_oihw_host, const float* fold_scale_host, int cout, int cin, int stride_w,
-                            int x_cstride, void* packed_host);
+                            int x_cstride, int dtype, void* packed_host);
 size_t rd_conv1x1_sc_packed_bytes(int cin, int cout);
-int rd_pack_conv1x1_sc_host(const float* w_oi_host, const float* fold_scale_host, int cout, int cin, void* packed_host);
+int rd_pack_conv1x1_sc_host(const float* w_oi_host, const float* fold_scale_host, int cout, int cin, int dtype,
+                            void* packed_host);
 int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale, const float* shift,
                          const void* residual, int r_cstride, int r_coff, const void* sc_x, int sc_cstride, int sc_coff,
                          int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
-                         int cout, int stride_w, int flags, void* stream);
-/* Last conv of a head tower (3x3, cout 128, BN + ReLU, bf16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
+                         int cout, int stride_w, int flags, int dtype, void* stream);
+/* Last conv of a head tower (3x3, cout 128, BN + ReLU, RD_BF16 or RD_F16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
  * rpn_{cls,reg}_conv_3 + BN + ReLU, then rpn_cls_logit / rpn_reg_delta with bias): the 128-channel result is consumed in
  * the epilogue and never written.  out[b*out_batch_stride + (n_off + h*W + w)*nout + o], float32, like rd_head_out; nout <= 8.
  * head_w_packed: rd_pack_head_weight_host(w (nout, 128) row-major float32) -> rd_head_packed_bytes() bytes (bf16 hi + lo
  * pairs, so the fp32 weights keep their precision).  Same numbers as rd_conv2d_bn_act followed by rd_head_out up to fp32
  * summation order. */
 size_t rd_head_packed_bytes(void);
-int rd_pack_head_weight_host(const float* w, int nout, int cin, void* out_host);
+int rd_pack_head_weight_host(const float* w, int nout, int cin, int dtype, void* out_host);
 int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
                               const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
-                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, void* stream);
+                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, int dtype,
+                              void* stream);
 
 /* Transposed conv, kernel (3,kw), stride (1,stride_w), pad (1,pad_w); one call per output phase. */
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase,

@@ -37,7 +37,7 @@ class Cfg:
     num_reg_delta = 8
     class_names = ('veh',)
     pre_nms_top_n = {'veh': 50000}
-    min_score = {'veh': 0.5}
+    min_score = {'veh': 0.5, 'ped': 0.4, 'cyc': 0.3}     # config:332 (TestParam.min_score)
     thr_lo, thr_hi, is_3d_iou = 0.1, 0.5, False
 
 
@@ -170,9 +170,9 @@ def forward(inputs, P, cfg=Cfg, num_fgs=None, stages=False):
     return out
 
 
-def postprocess(fg_cls_score, decoded_bbox, cfg=Cfg, order=None):
-    """tools/test.py:184-224 for one frame: score filter, 10->11 dim, wnms_4c, 12->8 dim."""
-    cn = cfg.class_names[0]
+def postprocess(fg_cls_score, decoded_bbox, cfg=Cfg, order=None, cls=None):
+    """tools/test.py:184-224 for one frame: score filter, 10->11 dim, wnms_4c, 12->8 dim (cls: the class whose min_score applies)."""
+    cn = cls or cfg.class_names[0]
     dets = cpu_ops.score_filter_to_dets(fg_cls_score, decoded_bbox, cfg.min_score[cn])
     if dets.shape[0] == 0:
         return dets, np.zeros((0, 12), np.float32), [], np.zeros((0, 8))

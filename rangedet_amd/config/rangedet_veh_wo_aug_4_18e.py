@@ -25,6 +25,10 @@ _VARIANTS = {
 KITTI_INPUT_CHANNELS = 5
 
 
+def variant_classes(variant):
+    return _VARIANTS[variant]["class_names"]
+
+
 def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(64, 2656), fp16=True, batch_image=1,
                pre_nms_top_n=None, wnms=True, sampling_rate=4, end_epoch=18, name=None):
     _wnms = bool(wnms)

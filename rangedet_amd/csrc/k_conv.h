@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
     const int n = p >> 3, sp = p & 7;
     const int s = sp ^ ((n >> 1) & 7);
     const int mm = n & 31;
-    if constexpr (DT == RD_BF16) {
+    if constexpr (DT != RD_F32) {
       // bf16 weights are packed in MFMA-fragment order (k_conv3.h pack_taps_frag): [32-ch chunk][tap][ks][Cout/32][lane]
       const int ncb = a.cout >> 5, cb = chalf * 2 + (n >> 5);
       goff[j] = (((s >> 2) * a.ntaps * 2 + ((s >> 1) & 1)) * ncb + cb) * 1024 + ((s & 1) * 32 + mm) * 16;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   int fch = 0, ftap = 0;                                   // (64-ch chunk, tap) of the next slab to fetch
   auto w_fill = [&](int step) {
     const unsigned char* src;
-    if constexpr (DT == RD_BF16) {
+    if constexpr (DT != RD_F32) {
       src = (const unsigned char*)a.w + (size_t)((2 * fch * a.ntaps + ftap) * 2 * (a.cout >> 5)) * 1024;
       if (++ftap == a.ntaps) { ftap = 0; ++fch; }
     } else {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
     }
     auto kstep = [&](int ks) {
       const int kx = ks << 5;
-      if constexpr (DT == RD_BF16) {
+      if constexpr (DT != RD_F32) {
         s16x8 av[2], bv[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = H16<DT>::mfma(bv[j], av[i], acc[i][j]);
       } else {
         f32x4 av[2], bv[2];
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void conv_taps_kernel(ConvArgs a) {
   const T* __restrict__ res = (const T*)a.res + (size_t)b * a.r_bs + (size_t)oh * a.Wout * a.r_cs + a.r_co + chalf * 64;
   const bool relu_pre = a.flags & RD_RELU_PRE, do_add = a.flags & RD_ADD, relu_post = a.flags & RD_RELU_POST;
   constexpr int SPT = 16 / E::CH;                 // 16-byte slots per 16 channels (2 for bf16, 4 for f32)
-  constexpr int NB = (DT == RD_BF16) ? 2 : 1;     // tiles whose residual loads are batched ahead of the math
+  constexpr int NB = (DT != RD_F32) ? 2 : 1;     // tiles whose residual loads are batched ahead of the math
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int q = q0 + mt * 32 + m;
@@ -382,7 +382,7 @@ inline void pack_taps(int ntaps, int cin, int cout, int dt, void* out, F get) {
           int ci = c * kc + k;
           float v = ci < cin ? get(co, ci, t) : 0.f;
           size_t idx = (((size_t)c * ntaps + t) * cout + co) * kc + k;
-          if (dt == RD_BF16) ((bf16_t*)out)[idx] = f32_to_bf16(v);
+          if (is_h16(dt)) ((bf16_t*)out)[idx] = h16_from_f32(dt, v);
           else ((float*)out)[idx] = v;
         }
 }
@@ -411,13 +411,13 @@ inline int launch_conv1(const void* x, int x_cs, int x_co, const void* w, const 
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st, int ts, const struct Conv3Args* head);
+                        int cout, int flags, int sw, hipStream_t st, int ts, const struct Conv3Args* head, int dt);
 
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,
                        int B, int H, int Win, int Wq, int Wout, int cin, int cout, int in_stride,
                        int out_stride, int out_off, int flags, int dt, hipStream_t st) {
-  RD_REQUIRE(dt == RD_F32 || dt == RD_BF16, RD_EINVAL, "conv: dtype %d", dt);
+  RD_REQUIRE(dt == RD_F32 || is_h16(dt), RD_EINVAL, "conv: dtype %d", dt);
   RD_REQUIRE(cout == 64 || cout == 128, RD_ESHAPE, "conv: cout %d not in {64,128}", cout);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "conv: %d taps unsupported", tl.n);
   RD_REQUIRE(B > 0 && H > 0 && Win > 0 && Wq > 0 && cin > 0, RD_ESHAPE, "conv: empty shape");
@@ -446,7 +446,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
   if (conv1_eligible(tl, in_stride, out_stride, cin, cout, dt, Win, Wq, Wout) && x_co + 16 * ((cin + 15) / 16) <= x_cs)
     return launch_conv1(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, Wout, cin, cout, flags, in_stride, st);
   if (conv3_eligible(tl, in_stride, out_stride, cout, dt, Win, Wq, Wout))
-    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st, 0, nullptr);
+    return launch_conv3(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, Win, cin, cout, flags, in_stride, st, 0, nullptr, dt);
   // Workgroup = 4 rows x 64 px x 64 output channels (Cout = 128 runs as two channel-half workgroups per pixel tile),
   // 4 waves, 3-deep weight ring, two workgroups per CU when the halo allows.
   constexpr int RO = 4;
@@ -470,7 +470,7 @@ inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, con
 #define RD_LAUNCH_CONV(DT_)                                                                            \
   if (deep) hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 8>), grid, dim3(256), lds, st, a);             \
   else hipLaunchKernelGGL((conv_taps_kernel<DT_, 4, 3>), grid, dim3(256), lds, st, a);
-  if (dt == RD_BF16) { RD_LAUNCH_CONV(RD_BF16) } else { RD_LAUNCH_CONV(RD_F32) }
+  if (dt == RD_BF16) { RD_LAUNCH_CONV(RD_BF16) } else if (dt == RD_F16) { RD_LAUNCH_CONV(RD_F16) } else { RD_LAUNCH_CONV(RD_F32) }
 #undef RD_LAUNCH_CONV
   return check_launch("conv_taps_kernel");
 }

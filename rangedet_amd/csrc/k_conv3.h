@@ -87,7 +87,7 @@ constexpr int C3_HALO = C3Cfg<4, 4>::HALO;
 // packed bf16 conv-family weights: [32-ch chunk][tap][ks (2)][Cout/32][64 lanes][8 bf16], lane (mm, hi) of a fragment
 // holds W[co = 32*cb + conv_row_perm(mm)][ci = 32*chunk + 16*ks + 8*hi + j][tap].   get(co, ci, tap) -> float
 template <class F>
-inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
+inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get, int dt = RD_BF16) {
   const int nchunk = (cin + 31) / 32, ncb = cout / 32;
   bf16_t* o = (bf16_t*)out;
   for (int c = 0; c < nchunk; ++c)
@@ -98,14 +98,14 @@ inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get) {
             const int co = cb * 32 + conv_row_perm(lane & 31);
             for (int j = 0; j < 8; ++j) {
               const int ci = c * 32 + ks * 16 + (lane >> 5) * 8 + j;
-              *o++ = f32_to_bf16(ci < cin ? get(co, ci, t) : 0.f);
+              *o++ = h16_from_f32(dt, ci < cin ? get(co, ci, t) : 0.f);
             }
           }
 }
 
 // packed 1x1 output-conv weights of the HEAD variant: [hi | lo][ks 0..7][64 lanes][8 bf16]; lane (mm, hi) of k-step ks holds
 // w[mm][16*ks + 8*hi + j] (rows mm >= nout and channels >= cin are zero), hi = bf16(w), lo = bf16(w - hi).
-inline void pack_head_frag(const float* w, int nout, int cin, void* out) {
+inline void pack_head_frag(const float* w, int nout, int cin, void* out, int dt = RD_BF16) {
   bf16_t* o = (bf16_t*)out;
   for (int part = 0; part < 2; ++part)
     for (int ks = 0; ks < 8; ++ks)
@@ -113,15 +113,15 @@ inline void pack_head_frag(const float* w, int nout, int cin, void* out) {
         for (int j = 0; j < 8; ++j) {
           const int mm = lane & 31, c = 16 * ks + 8 * (lane >> 5) + j;
           const float v = (mm < nout && c < cin) ? w[(size_t)mm * cin + c] : 0.f;
-          const bf16_t h = f32_to_bf16(v);
-          *o++ = part == 0 ? h : f32_to_bf16(v - bf16_to_f32(h));
+          const bf16_t h = h16_from_f32(dt, v);
+          *o++ = part == 0 ? h : h16_from_f32(dt, v - h16_to_f32(dt, h));
         }
 }
 
 // packed 1x1 projection-shortcut weights of the SC variant: [ks][Cout/32][64 lanes][8 bf16], lane (mm, hi) of fragment
 // (ks, cb) holds scale[co] * w[co = 32*cb + conv_row_perm(mm)][ci = 16*ks + 8*hi + j]  (w: (cout, cin) row-major).
 inline size_t sc_frag_bytes(int cin, int cout) { return (size_t)((cin + 15) / 16) * (cout / 32) * 1024; }
-inline void pack_sc_frag(const float* w, const float* scale, int cin, int cout, void* out) {
+inline void pack_sc_frag(const float* w, const float* scale, int cin, int cout, void* out, int dt = RD_BF16) {
   bf16_t* o = (bf16_t*)out;
   const int nks = (cin + 15) / 16;
   for (int ks = 0; ks < nks; ++ks)
@@ -130,7 +130,7 @@ inline void pack_sc_frag(const float* w, const float* scale, int cin, int cout, 
         const int co = cb * 32 + conv_row_perm(lane & 31);
         for (int j = 0; j < 8; ++j) {
           const int ci = ks * 16 + (lane >> 5) * 8 + j;
-          *o++ = f32_to_bf16(ci < cin ? (scale ? scale[co] : 1.f) * w[(size_t)co * cin + ci] : 0.f);
+          *o++ = h16_from_f32(dt, ci < cin ? (scale ? scale[co] : 1.f) * w[(size_t)co * cin + ci] : 0.f);
         }
       }
 }
@@ -175,7 +175,10 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
 // through one rank-1 MFMA per accumulator at the start of every tile (A = the shift as a bf16 high + low pair in k = 0, 1;
 // B = ones) -- 4 * NCT MFMAs of the tile's 36 * 8 * NCT..., in exchange for which the epilogue has no multiply-add left:
 // it reads the accumulators, adds the residual if any, converts and clamps.
-template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2>
+// DT = RD_BF16 or RD_F16: the element type of activations and weights (same layouts; the MFMA instruction and the conversions
+// of the epilogue differ, rd_common.h H16<DT>).
+template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2,
+          int DT = RD_BF16>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
   static_assert(NHB == 2 || FOLD, "three halo buffers: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #pragma unroll
     for (int j = 0; j < NCT; ++j) {
       const float t = a.shift ? a.shift[32 * j + conv_row_perm(m)] : 0.f;
-      const bf16_t th = f32_to_bf16(t);
-      const bf16_t tl = f32_to_bf16(t - bf16_to_f32(th));
+      const bf16_t th = H16<DT>::from_f32(t);
+      const bf16_t tl = H16<DT>::from_f32(t - H16<DT>::to_f32(th));
       bzw[j] = hi ? 0u : ((unsigned)th | ((unsigned)tl << 16));
     }
   }
@@ -315,16 +318,16 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #define C3_MM(BUF, N)                                                                                     \
   {                                                                                                       \
     if (!(DBG & 8))                                                                                       \
-      acc[(N) / NCT][(N) % NCT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
-                                                                          acc[(N) / NCT][(N) % NCT], 0, 0, 0);    \
+      acc[(N) / NCT][(N) % NCT] = H16<DT>::mfma(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
+                                                                          acc[(N) / NCT][(N) % NCT]);    \
     C3_FENCE();                                                                                           \
   }
   // first k-step of a tile: C = 0 as an inline constant instead of zeroing 16 * 4 * NCT accumulator registers per tile
 #define C3_MMZ(BUF, N)                                                                                    \
   {                                                                                                       \
     if (!(DBG & 8))                                                                                       \
-      acc[(N) / NCT][(N) % NCT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
-                                                                          f32x16{}, 0, 0, 0);             \
+      acc[(N) / NCT][(N) % NCT] = H16<DT>::mfma(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
+                                                                          f32x16{});             \
     C3_FENCE();                                                                                           \
   }
   // workgroup barrier that retires the counted DMA and all LDS reads except the NR youngest (the fragments of the next
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   for (int k = 0; k < ntl; ++k) {
     {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
       if constexpr (FOLD) {
-        const unsigned one2 = hi ? 0u : 0x3F803F80u;            // B: k = 0, 1 -> 1.0 (bf16), the rest 0
+        const unsigned one2 = hi ? 0u : H16<DT>::ONE * 0x10001u;   // B: k = 0, 1 -> 1.0, the rest 0
         unsigned ob[4] = {one2, 0u, 0u, 0u};
         s16x8 ones;
         memcpy(&ones, ob, 16);
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           unsigned ab[4] = {bzw[n % NCT], 0u, 0u, 0u};
           s16x8 bz;
           memcpy(&bz, ab, 16);
-          acc[n / NCT][n % NCT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bz, ones, f32x16{}, 0, 0, 0);
+          acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
         }
         C3_FENCE();
         C3_STEP(0)
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
                   const s16x8 wf = *(const s16x8*)(wq + (size_t)((kh * MK + ks) * NCT + j) * 1024);
 #pragma unroll
                   for (int i = 0; i < FPW; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, sxq[i][ks], acc[i][j], 0, 0, 0);
+                    acc[i][j] = H16<DT>::mfma(wf, sxq[i][ks], acc[i][j]);
                 }
               }
           }
@@ -586,11 +589,11 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
                 v = av * s2 + t2;                                      // v_pk_fma_f32
               }
               if (relu_f32) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
-              if (do_add) {   // bf16 -> f32 is a 16-bit shift of the packed pair
+              if (do_add) {
                 const unsigned w2 = rv[i & 1][j][r >> 3][(r >> 1) & 3];
-                v += f32x2{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)};
+                v += H16<DT>::unpk(w2);
               }
-              unsigned p2 = f32x2_to_bf16x2(v[0], v[1]);
+              unsigned p2 = H16<DT>::pk(v[0], v[1]);
               if (relu_i16) p2 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
               pk[2 * g4 + h2] = p2;
             }
@@ -613,8 +616,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
               wh = *(const s16x8*)(smem + HWOFF + ks * 1024 + el * 16);
               wl = *(const s16x8*)(smem + HWOFF + 8192 + ks * 1024 + el * 16);
             }
-            h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bq, h0, 0, 0, 0);
-            h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bq, h1, 0, 0, 0);
+            h0 = H16<DT>::mfma(wl, bq, h0);
+            h1 = H16<DT>::mfma(wh, bq, h1);
           }
           const int tcs = 32 * (i % FC) + em, ows = ct * C3_TW + tcs, ohs = oh0 + i / FC;
           if (jp == NPASS - 1 && tcs < C3_TW && ows < a.W && ohs < a.H) {
@@ -669,9 +672,9 @@ inline int conv_num_cus() {
 }
 
 // One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
-template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB>
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
-  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB>;
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT>;
   static const bool once = (allow_big_lds(k), true);
   (void)once;
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
@@ -679,8 +682,20 @@ inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
   return check_launch("conv3x3_stream_kernel");
 }
 
+// The CPU emulator build (tests/emu, test infrastructure) instantiates the fp16 persistent kernel for the PRODUCTION launch forms
+// only -- folded scales on the 8 x 30 tiles, fused output conv -- to keep its compile time in minutes; other fp16 forms run on the
+// generic tap kernel there.  The GPU library has every form in both 16-bit types.
+inline bool conv3_has_form(int dt, bool fold) {
+#ifdef HIPEMU
+  return dt == RD_BF16 || fold;
+#else
+  (void)dt; (void)fold;
+  return true;
+#endif
+}
+
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout) {
-  if (dt != RD_BF16 || tl.n != 9 || (in_stride != 1 && in_stride != 2) || out_stride != 1) return false;
+  if (!is_h16(dt) || !conv3_has_form(dt, false) || tl.n != 9 || (in_stride != 1 && in_stride != 2) || out_stride != 1) return false;
   if (Wq != (Win - 1) / in_stride + 1 || Wout != Wq) return false;   // pad 1, kernel 3
   if (cout != 64 && cout != 128) return false;
   for (int t = 0; t < 9; ++t)
@@ -688,9 +703,22 @@ inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int
   return !dev_switches().conv_v1;
 }
 
+template <int DT>
+inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                           const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head) {
+                        int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, int dt) {
+  RD_REQUIRE(is_h16(dt), RD_EINVAL, "conv3: dtype %d (the persistent 3x3 kernel takes RD_BF16 or RD_F16)", dt);
+  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head);
+  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head);
+}
+
+template <int DT>
+inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                           const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
   if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
@@ -747,7 +775,22 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   }
   C3_DBG64(4) C3_DBG64(8) C3_DBG64(16) C3_DBG64(64) C3_DBG64(128)
 #undef C3_DBG64
+#define C3_DBG128(D)                                                                                                    \
+  if (cout == 128 && w30 && !sc && !headfuse && ts == 0 && dbg == D) {                                                  \
+    auto k = conv3x3_stream_kernel<4, D, 0, false, false, true, 2, 1, 2>; allow_big_lds(k);                             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), (C3Cfg<4, 2, 1, 2>::LDS), st, a);                                      \
+    return check_launch("conv3x3_stream_kernel<dbg>");                                                                  \
+  }
+  C3_DBG128(4) C3_DBG128(8) C3_DBG128(16) C3_DBG128(2) C3_DBG128(32)
+#undef C3_DBG128
 #endif
+#ifdef HIPEMU
+  constexpr bool kAllForms = DT == RD_BF16;
+#else
+  constexpr bool kAllForms = true;
+#endif
+  RD_REQUIRE(kAllForms || (fold && w30 && (cout == 128 || hb3)) || (headfuse && fold), RD_ESHAPE,
+             "conv3: this fp16 launch form is not instantiated in the emulator build (conv3_has_form)");
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
     RD_REQUIRE(fold, RD_EINVAL, "conv3 + shortcut: the weights must carry the folded scales (RD_SCALE_FOLDED)");
@@ -755,27 +798,31 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
   // (tile shape, cout) -> instantiation; within it (tap set, shortcut).  All of these carry folded scales.
 #define C3_BODY(N, FPW_, FC_, NHB_)                                                                       \
   {                                                                                                       \
-    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_>(grid, st, a)                 \
-                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_>(grid, st, a);                \
-    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_>(grid, st, a)                        \
-         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_>(grid, st, a)                        \
-                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_>(grid, st, a);                       \
+    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a)                 \
+                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a);                \
+    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                        \
+         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                        \
+                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a);                       \
   }
-  if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) }
+  if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
   if (w30) {
-    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2>(grid, st, a);
+    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT>(grid, st, a);
     if (cout == 128) C3_BODY(4, 2, 1, 2)
     if (hb3) C3_BODY(2, 2, 1, 3)
-    C3_BODY(2, 2, 1, 2)
+    if constexpr (kAllForms) C3_BODY(2, 2, 1, 2)
   }
-  if (head && !sc) return fold ? c3_go<4, 0, true, false, true, 4, 2, 2>(grid, st, a) : c3_go<4, 0, true, false, false, 4, 2, 2>(grid, st, a);
+  if (head && !sc && fold) return c3_go<4, 0, true, false, true, 4, 2, 2, DT>(grid, st, a);
+  if constexpr (kAllForms) {
+  if (head && !sc) return c3_go<4, 0, true, false, false, 4, 2, 2, DT>(grid, st, a);
   if (fold) { if (cout == 128) C3_BODY(4, 4, 2, 2) else C3_BODY(2, 4, 2, 2) }
 #undef C3_BODY
   // scale / shift applied in the epilogue (stand-alone use of the C ABI; the lowering always folds)
-#define C3_PLAIN(N) return ts == 0 ? c3_go<N, 0, false, false, false, 4, 2, 2>(grid, st, a) : ts == 1 ? c3_go<N, 1, false, false, false, 4, 2, 2>(grid, st, a) : c3_go<N, 2, false, false, false, 4, 2, 2>(grid, st, a);
+#define C3_PLAIN(N) return ts == 0 ? c3_go<N, 0, false, false, false, 4, 2, 2, DT>(grid, st, a) : ts == 1 ? c3_go<N, 1, false, false, false, 4, 2, 2, DT>(grid, st, a) : c3_go<N, 2, false, false, false, 4, 2, 2, DT>(grid, st, a);
   if (cout == 128) { C3_PLAIN(4) }
   C3_PLAIN(2)
 #undef C3_PLAIN
+  }
+  return rd::fail(RD_ESHAPE, "conv3: launch form not available");
 }
 
 }  // namespace rd

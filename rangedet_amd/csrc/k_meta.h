@@ -25,8 +25,9 @@ struct MetaLayout {  // byte offsets inside the packed parameter block
 };
 __host__ __device__ inline MetaLayout meta_layout(int dt) {
   MetaLayout L;
-  const size_t w1s = dt == RD_BF16 ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
-  const size_t a2 = dt == RD_BF16 ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
+  const bool h = dt != RD_F32;   // RD_BF16 / RD_F16: 16-bit weights in MFMA-fragment order
+  const size_t w1s = h ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
+  const size_t a2 = h ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
   L.w1s = 0;
   L.a2 = w1s;
   L.wbytes = w1s + a2;
@@ -35,7 +36,7 @@ __host__ __device__ inline MetaLayout meta_layout(int dt) {
   L.w0p = L.t1 + 9 * 64 * 4;
   L.s2t2 = L.w0p + 2 * 16 * 4 * 4;
   L.w0f = L.s2t2 + 128 * 4;                          // bf16: A operand of the hidden-layer MFMA (64 lanes x 8 bf16)
-  L.total = L.w0f + (dt == RD_BF16 ? 1024 : 0);
+  L.total = L.w0f + (h ? 1024 : 0);
   return L;
 }
 inline int meta_perm(int blk, int m) {  // MFMA row m of 32-block blk -> channel
@@ -46,8 +47,9 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
   const MetaLayout L = meta_layout(dt);
   unsigned char* base = (unsigned char*)out;
   memset(base, 0, L.total);
+  const bool h16 = dt != RD_F32;
   auto put = [&](size_t byte_off, size_t idx, float v) {
-    if (dt == RD_BF16) ((bf16_t*)(base + byte_off))[idx] = f32_to_bf16(v);
+    if (h16) ((bf16_t*)(base + byte_off))[idx] = h16_from_f32(dt, v);
     else ((float*)(base + byte_off))[idx] = v;
   };
   for (int k = 0; k < 9; ++k)
@@ -56,7 +58,7 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
         const int m = lane & 31, hi = lane >> 5;
         const int ch = meta_perm(mt, m);
         const float s = s1[ch * 9 + k];
-        if (dt == RD_BF16) {
+        if (h16) {
           for (int ks = 0; ks < 2; ++ks)
             for (int e = 0; e < 8; ++e) {
               // hidden unit seen by B-operand element (ks, hi, e): the bf16 kernel computes the hidden layer with an
@@ -80,7 +82,7 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
           for (int r = 0; r < 16; ++r) {
             const int c = 32 * mt + 16 * hi + r;
             const float v = agg[(size_t)o * 576 + c * 9 + k];
-            if (dt == RD_BF16)
+            if (h16)
               put(L.a2, (((((size_t)k * 2 + ot) * 2 + mt) * 2 + (r >> 3)) * 64 + lane) * 8 + (r & 7), v);
             else
               put(L.a2, (((((size_t)k * 2 + ot) * 2 + mt) * 4 + (r >> 2)) * 64 + lane) * 4 + (r & 3), v);
@@ -94,7 +96,7 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
       ft1[k * 64 + c] = t1[c * 9 + k];
     }
   float* fw0 = (float*)(base + L.w0p);
-  if (dt == RD_BF16) {
+  if (h16) {
     // A operand of the ONE v_mfma_f32_32x32x16_bf16 that computes the hidden layer, row m = hidden unit m.  Weights and
     // relative coordinates are split into bf16 high + low parts (v = vh + vl, vh = bf16(v), vl = bf16(v - vh)) and the
     // 16 K slots carry the three significant partial products -- (Wh + Wl)(xh + xl) + b up to the Wl*xl term (2^-18):
@@ -106,8 +108,8 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
       const int m = lane & 31, hi = lane >> 5;
       float v[4] = {w0[m * 3], w0[m * 3 + 1], w0[m * 3 + 2], b0[m]};
       for (int e = 0; e < 4; ++e) {
-        const bf16_t h = f32_to_bf16(v[e]);
-        const bf16_t l = f32_to_bf16(v[e] - bf16_to_f32(h));
+        const bf16_t h = h16_from_f32(dt, v[e]);
+        const bf16_t l = h16_from_f32(dt, v[e] - h16_to_f32(dt, h));
         fa[lane * 8 + e] = hi ? l : h;                               // k 0..3 : high parts | k 8..11: low parts
         fa[lane * 8 + 4 + e] = (hi || e == 3) ? (bf16_t)0 : h;      // k 4..7 : high weights against the low coordinates
       }
@@ -139,21 +141,19 @@ struct MetaArgs {
 
 template <int DT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
+  static_assert(DT == RD_F32, "the 16-bit types run meta16_kernel (its packed W0 / W1 layouts differ); this is the fp32 parity kernel");
   using E = Elem<DT>;
   using T = typename E::T;
-  static_assert(DT == RD_F32, "bf16 runs meta_bf16_kernel (its packed W0 / W1 layouts differ); this is the fp32 parity kernel");
-  constexpr bool BF = false;   // (the bf16 branches below document the shared structure; they are not instantiated)
-  constexpr int PXB = BF ? 128 : 256;  // bytes per pixel (64 channels)
+  constexpr int PXB = 256;             // bytes per pixel (64 channels)
   constexpr int SPP = PXB / 16;        // 16-byte slots per pixel
   constexpr int HC = 34;               // halo columns
   HIP_DYNAMIC_SHARED(unsigned char, smem);
-  // LDS carve: [weights (bf16 only)] [consts] [halo]
-  constexpr size_t W1S_B = BF ? 9 * 2 * 2 * 64 * 16 : 9 * 2 * 4 * 64 * 16;
-  constexpr size_t A2_B = BF ? 9 * 2 * 2 * 2 * 64 * 16 : 9 * 2 * 2 * 4 * 64 * 16;
+  // LDS carve: [consts] [halo]; the weights (220 KiB) stream from L2
+  constexpr size_t W1S_B = 9 * 2 * 4 * 64 * 16;
+  constexpr size_t A2_B = 9 * 2 * 2 * 4 * 64 * 16;
   constexpr size_t WB = W1S_B + A2_B;
   constexpr size_t CONST_B = 9 * 64 * 4 * 2 + 512 + 512;
-  unsigned char* lw = smem;                       // bf16: weights live here
-  unsigned char* lc = smem + (BF ? WB : 0);       // consts
+  unsigned char* lc = smem;                       // consts
   unsigned char* halo = lc + CONST_B;
   const float* cb1 = (const float*)lc;            // [9][64]
   const float* ct1 = cb1 + 9 * 64;                // [9][64]
@@ -163,11 +163,8 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
   const int px = lane & 31, hi = lane >> 5;
   const int NT = WAVES * 64;
 
-  // one-time fill of weights (bf16) and constants
-  if (BF)
-    for (size_t i = tid; i < WB / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)a.packed)[i];
   for (size_t i = tid; i < CONST_B / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + WB))[i];
-  const unsigned char* w1s = BF ? lw : a.packed;
+  const unsigned char* w1s = a.packed;
   const unsigned char* a2w = w1s + W1S_B;
 
   const T* data = (const T*)a.data;
@@ -187,8 +184,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
       Slot16 v = {0u, 0u, 0u, 0u};
       if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
         v = *(const Slot16*)(data + (((size_t)b * a.H + ih) * a.W + iw) * a.d_cs + a.d_co + s * E::CH);
-      const int swz = BF ? ((pl >> 1) & 7) : (pl & 15);
-      *(Slot16*)(halo + pl * PXB + ((s ^ swz) << 4)) = v;
+      *(Slot16*)(halo + pl * PXB + ((s ^ (pl & 15)) << 4)) = v;
     }
     __syncthreads();
 
@@ -231,50 +227,27 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) d1[mt][4 * g + e] = bq[e];
         }
-      if constexpr (BF) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          s16x8 bfrag;
+      for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bfrag[e] = (short)f32_to_bf16(hv[8 * ks + e]);
+        for (int mt = 0; mt < 2; ++mt) {
+          const f32x4 af = *(const f32x4*)(w1s + ((((size_t)k * 2 + mt) * 4 + q4) * 64 + lane) * 16);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const s16x8 af = *(const s16x8*)(w1s + ((((size_t)k * 2 + mt) * 2 + ks) * 64 + lane) * 16);
-            d1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, d1[mt], 0, 0, 0);
-          }
+          for (int e = 0; e < 4; ++e)
+            d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], hv[4 * q4 + e], d1[mt], 0, 0, 0);
         }
-      } else {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 af = *(const f32x4*)(w1s + ((((size_t)k * 2 + mt) * 4 + q4) * 64 + lane) * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], hv[4 * q4 + e], d1[mt], 0, 0, 0);
-          }
-      }
       // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
       const int pl = (wv + 1 + dh) * HC + (px + 1 + dw);
       const unsigned char* hp = halo + pl * PXB;
-      const int swz = BF ? ((pl >> 1) & 7) : (pl & 15);
+      const int swz = pl & 15;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         float av[16];
-        if constexpr (BF) {
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const s16x8 dv = *(const s16x8*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f32x4 dv = *(const f32x4*)(hp + (((8 * mt + 4 * hi + s4) ^ swz) << 4));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[8 * s2 + e] = bf16_to_f32((bf16_t)dv[e]);
-          }
-        } else {
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const f32x4 dv = *(const f32x4*)(hp + (((8 * mt + 4 * hi + s4) ^ swz) << 4));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) av[4 * s4 + e] = dv[e];
-          }
+          for (int e = 0; e < 4; ++e) av[4 * s4 + e] = dv[e];
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -283,29 +256,15 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
           for (int e = 0; e < 4; ++e) av[4 * g + e] = fmaxf(av[4 * g + e] * d1[mt][4 * g + e] + tq[e], 0.f);
         }
         // MFMA #2: acc2[o][px] += A[o][(ch,k)] . a[ch]
-        if constexpr (BF) {
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            s16x8 bfrag;
+        for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bfrag[e] = (short)f32_to_bf16(av[8 * s2 + e]);
+          for (int ot = 0; ot < 2; ++ot) {
+            const f32x4 af = *(const f32x4*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 4 + r4) * 64 + lane) * 16);
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-              const s16x8 af = *(const s16x8*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 2 + s2) * 64 + lane) * 16);
-              acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+              acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], av[4 * r4 + e], acc2[ot], 0, 0, 0);
           }
-        } else {
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-              const f32x4 af = *(const f32x4*)(a2w + (((((size_t)k * 2 + ot) * 2 + mt) * 4 + r4) * 64 + lane) * 16);
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], av[4 * r4 + e], acc2[ot], 0, 0, 0);
-            }
-        }
       }
     }
     // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
@@ -337,8 +296,10 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 //   * point coordinates come from an LDS halo (one coalesced fetch per tile instead of 27 global loads per pixel);
 //   * the next tile's data / coordinate halo is fetched into registers while the current tile is computed.
 // LDS: weights 108 KiB + constants 5.5 KiB + data halo 42.5 KiB + coordinate halo 4 KiB = 160 KiB, one workgroup per CU.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
+// DT = RD_BF16 or RD_F16 (same structure; the high / low split of MFMA #0 then carries 2^-18 resp. 2^-24 relative error).
+template <int WAVES, int DT = RD_BF16>
+__global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
+  using HT = H16<DT>;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   constexpr int PXB = 128, SPP = 8, HC = 34, HR = WAVES + 2, NT = WAVES * 64;
@@ -415,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
   };
 
   // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
-  const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(RD_BF16).w0f + lane * 16);
+  const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(DT).w0f + lane * 16);
   // per-lane LDS addresses that do not depend on the tile: everything a tap adds to them is a compile-time constant
   const unsigned char* w1l = lw + lane * 16;                 // + ((k*2 + mt)*2 + ks) * 1024
   const unsigned char* a2l = lw + W1S_B + lane * 16;         // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
@@ -452,14 +413,15 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
       // MFMA #0: pre[j][px] = W0[j][0..2] . rel + b0[j], one bf16 MFMA on high / low split operands (~fp32 accurate)
       f32x16 pre;
       {
-        const unsigned hxy = f32x2_to_bf16x2(r0, r1), hz1 = f32x2_to_bf16x2(r2, 1.0f);
-        const float l0 = r0 - __uint_as_float(hxy << 16), l1 = r1 - __uint_as_float(hxy & 0xffff0000u);
-        const float l2 = r2 - __uint_as_float(hz1 << 16);
-        const unsigned lxy = f32x2_to_bf16x2(l0, l1), lz0 = f32x2_to_bf16x2(l2, 0.f);
+        const unsigned hxy = HT::pk(r0, r1), hz1 = HT::pk(r2, 1.0f);
+        const f32x2 uxy = HT::unpk(hxy), uz1 = HT::unpk(hz1);
+        const float l0 = r0 - uxy[0], l1 = r1 - uxy[1];
+        const float l2 = r2 - uz1[0];
+        const unsigned lxy = HT::pk(l0, l1), lz0 = HT::pk(l2, 0.f);
         unsigned pk0[4] = {hxy, hz1, hi ? 0u : lxy, hi ? 0u : lz0};
         s16x8 b0frag;
         memcpy(&b0frag, pk0, 16);
-        pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0frag, b0frag, f32x16{}, 0, 0, 0);
+        pre = HT::mfma(w0frag, b0frag, f32x16{});
       }
       // hidden vector as the two B fragments of MFMA #1 (ReLU on the packed pairs: negative bf16 = negative int16)
       s16x8 hfrag[2];
@@ -468,7 +430,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
         unsigned pk[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const unsigned v = f32x2_to_bf16x2(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
+          const unsigned v = HT::pk(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
           pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
         }
         memcpy(&hfrag[ks], pk, 16);
@@ -488,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const s16x8 af = *(const s16x8*)(w1l + ((k * 2 + mt) * 2 + ks) * 1024);
-          d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hfrag[ks], d1, 0, 0, 0);
+          d1 = HT::mfma(af, hfrag[ks], d1);
         }
         // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
 #pragma unroll
@@ -499,11 +461,11 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
           unsigned pk[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x2 x2 = {__uint_as_float(dv[e] << 16), __uint_as_float(dv[e] & 0xffff0000u)};
+            const f32x2 x2 = HT::unpk(dv[e]);
             const f32x2 w2 = {d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]};
             const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
             const f32x2 v2 = x2 * w2 + b2;
-            const unsigned v = f32x2_to_bf16x2(v2[0], v2[1]);
+            const unsigned v = HT::pk(v2[0], v2[1]);
             pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
           }
           s16x8 bfrag;
@@ -512,7 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
 #pragma unroll
           for (int ot = 0; ot < 2; ++ot) {
             const s16x8 af = *(const s16x8*)(a2l + (((k * 2 + ot) * 2 + mt) * 2 + s2) * 1024);
-            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc2[ot], 0, 0, 0);
+            acc2[ot] = HT::mfma(af, bfrag, acc2[ot]);
           }
         }
       }
@@ -526,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_bf16_kernel(MetaArgs a) {
         unsigned pk[8];
 #pragma unroll
         for (int r = 0; r < 16; r += 2)
-          pk[r >> 1] = f32x2_to_bf16x2(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
+          pk[r >> 1] = HT::pk(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
                                        fmaxf(acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1], 0.f));
         *(Slot16*)(yp + ob) = Slot16{pk[0], pk[1], pk[2], pk[3]};
         *(Slot16*)(yp + ob + 8) = Slot16{pk[4], pk[5], pk[6], pk[7]};

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const void* __restrict__ 
 // LDS image into the MFMA B-operand layout (lane (px, hi) <- 16-byte channel group 2*ks + hi of its pixel).  The A
 // operand is the weight matrix padded to 32 rows, held in registers as a bf16 hi + lo pair per k-step (w = hi + lo to
 // ~2^-17, so fp32 weights keep their precision); D[co][px] leaves lane (px, hi) with co = 4*hi + r in registers r = 0..3.
-template <int NOUT>
+template <int NOUT, int DT = RD_BF16>
 __global__ __launch_bounds__(256) void head_out_mfma_kernel(const bf16_t* __restrict__ x, int cs, int coff,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ out, long out_bs, long n_off, long HW,
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void head_out_mfma_kernel(const bf16_t* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = (m < NOUT && ks < nks) ? w[m * cin + ks * 16 + hi * 8 + j] : 0.f;
-      h[j] = f32_to_bf16(v);
-      l[j] = f32_to_bf16(v - bf16_to_f32(h[j]));
+      h[j] = H16<DT>::from_f32(v);
+      l[j] = H16<DT>::from_f32(v - H16<DT>::to_f32(h[j]));
     }
     memcpy(&wh[ks], h, 16);
     memcpy(&wl[ks], l, 16);
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void head_out_mfma_kernel(const bf16_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const s16x8 b = *(const s16x8*)(img + m * 256 + (((2 * ks + hi) ^ (m & 15)) << 4));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], b, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], b, acc, 0, 0, 0);
+      acc = H16<DT>::mfma(wl[ks], b, acc);
+      acc = H16<DT>::mfma(wh[ks], b, acc);
     }
     __builtin_amdgcn_wave_barrier();
     const long p = tile * 32 + m;

@@ -45,6 +45,7 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
 }
 inline void allow_conv_lds() {   // the generic tap kernel (the persistent 3x3 kernel does this per instantiation, k_conv3.h c3_go)
   static const bool once = (allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>), allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>),
+                            allow_big_lds(conv_taps_kernel<RD_F16, 4, 3>), allow_big_lds(conv_taps_kernel<RD_F16, 4, 8>),
                             allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>), allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>), true);
   (void)once;
 }
@@ -67,11 +68,12 @@ int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int
   ProfScope ps(RD_PROF_LAYOUT, st);
   {  // few channels, slot-aligned destination: pixel-per-thread variant with 16-byte stores
     const int ch = ch_per_slot(dst_dtype), ctot = C + zero_pad;
-    if ((dst_dtype == RD_BF16 || dst_dtype == RD_F32) && ctot % ch == 0 && ctot / ch <= 2 && dst_cstride % ch == 0 && dst_coff % ch == 0) {
+    if ((is_h16(dst_dtype) || dst_dtype == RD_F32) && ctot % ch == 0 && ctot / ch <= 2 && dst_cstride % ch == 0 && dst_coff % ch == 0) {
       const long npix = (long)B * HW;
       const int g2 = (int)std::min<long>((npix + 255) / 256, 8192);
 #define RD_PX(DT, NS) hipLaunchKernelGGL((nchw_to_nhwc_px_kernel<DT, NS>), dim3(g2), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, npix)
       if (dst_dtype == RD_BF16) { if (ctot / ch == 1) RD_PX(RD_BF16, 1); else RD_PX(RD_BF16, 2); }
+      else if (dst_dtype == RD_F16) { if (ctot / ch == 1) RD_PX(RD_F16, 1); else RD_PX(RD_F16, 2); }
       else { if (ctot / ch == 1) RD_PX(RD_F32, 1); else RD_PX(RD_F32, 2); }
 #undef RD_PX
       return check_launch("nchw_to_nhwc");
@@ -79,6 +81,8 @@ int rd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int
   }
   if (dst_dtype == RD_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_BF16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
+  else if (dst_dtype == RD_F16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_F16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
   else if (dst_dtype == RD_F32)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<RD_F32>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, dst_cstride, dst_coff, zero_pad, total);
   else
@@ -107,6 +111,8 @@ int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int
   ProfScope ps(RD_PROF_LAYOUT, st);
   if (src_dtype == RD_BF16)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<RD_BF16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, src_cstride, src_coff, total);
+  else if (src_dtype == RD_F16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<RD_F16>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, src_cstride, src_coff, total);
   else if (src_dtype == RD_F32)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<RD_F32>, dim3(grid), dim3(256), 0, st, src, dst, C, HW, src_cstride, src_coff, total);
   else
@@ -118,12 +124,12 @@ int rd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int
 size_t rd_conv_packed_bytes(int ntaps, int cin, int cout, int dtype) { return conv_packed_bytes(ntaps, cin, cout, dtype); }
 int rd_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_conv: null pointer");
-  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_conv: dtype");
+  RD_REQUIRE(dtype == RD_F32 || is_h16(dtype), RD_EINVAL, "pack_conv: dtype");
   RD_REQUIRE(kh * kw >= 1 && kh * kw <= 9 && (kh & 1) && (kw & 1), RD_ESHAPE, "pack_conv: kernel (%d,%d)", kh, kw);
   TapList tl = conv_taps(kh, kw);
   auto get = [&](int co, int ci, int t) { return w[(((size_t)co * cin + ci) * kh + tl.kh[t]) * kw + tl.kw[t]]; };
   memset(out, 0, conv_packed_bytes(tl.n, cin, cout, dtype));     // padding of partial chunks and the zero tail
-  if (dtype == RD_BF16) pack_taps_frag(tl.n, cin, cout, out, get);
+  if (is_h16(dtype)) pack_taps_frag(tl.n, cin, cout, out, get, dtype);
   else pack_taps(tl.n, cin, cout, dtype, out, get);
   return RD_OK;
 }
@@ -176,7 +182,7 @@ int rd_pack_deconv_weight_host(const float* w, int cin, int cout, int kh, int kw
 int rd_pack_deconv_weight_folded_host(const float* w, const float* fold_scale, int cin, int cout, int kh, int kw, int stride_w,
                                       int pad_w, int phase, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_deconv: null pointer");
-  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_deconv: dtype");
+  RD_REQUIRE(dtype == RD_F32 || is_h16(dtype), RD_EINVAL, "pack_deconv: dtype");
   RD_REQUIRE(stride_w >= 1 && phase >= 0 && phase < stride_w, RD_EINVAL, "pack_deconv: phase");
   TapList tl = deconv_taps_sorted(kh, kw, stride_w, pad_w, phase);
   RD_REQUIRE(tl.n >= 1 && tl.n <= 9, RD_ESHAPE, "pack_deconv: %d taps", tl.n);
@@ -193,7 +199,7 @@ int rd_pack_deconv_weight_folded_host(const float* w, const float* fold_scale, i
   };
   const int nt = emb ? 9 : tl.n;
   memset(out, 0, conv_packed_bytes(nt, cin, cout, dtype));
-  if (dtype == RD_BF16) pack_taps_frag(nt, cin, cout, out, get);
+  if (is_h16(dtype)) pack_taps_frag(nt, cin, cout, out, get, dtype);
   else pack_taps(nt, cin, cout, dtype, out, get);
   return RD_OK;
 }
@@ -224,8 +230,10 @@ static int ex_view_cin(int cin, int x_cstride, int stride_w) { return stride_w =
 size_t rd_conv3x3_ex_packed_bytes(int cin, int cout, int stride_w, int x_cstride) {
   return conv_packed_bytes(stride_w == 2 ? 6 : 9, ex_view_cin(cin, x_cstride, stride_w), cout, RD_BF16);
 }
-int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, int cin, int stride_w, int x_cstride, void* out) {
+int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, int cin, int stride_w, int x_cstride, int dtype,
+                            void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_conv3x3_ex: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_conv3x3_ex: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE(stride_w == 1 || stride_w == 2, RD_ESHAPE, "pack_conv3x3_ex: stride_w %d", stride_w);
   RD_REQUIRE(cout == 64 || cout == 128, RD_ESHAPE, "pack_conv3x3_ex: cout %d", cout);
   RD_REQUIRE(stride_w == 1 || (x_cstride >= cin && x_cstride % 8 == 0), RD_ESHAPE, "pack_conv3x3_ex: x_cstride %d for cin %d", x_cstride, cin);
@@ -234,29 +242,31 @@ int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, i
   };
   memset(out, 0, rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride));
   if (stride_w == 1) {
-    pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); });
+    pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); }, dtype);
   } else {
     pack_taps_frag(6, x_cstride + cin, cout, out, [&](int co, int c2, int s) -> float {
       const int dh = s / 2 - 1, dw2 = s % 2 - 1;
       if (c2 < cin) return dw2 == 0 ? wv(co, c2, dh, 0) : 0.f;                               // even pixel
       if (c2 >= x_cstride && c2 - x_cstride < cin) return wv(co, c2 - x_cstride, dh, dw2 == -1 ? -1 : 1);   // odd pixel
       return 0.f;
-    });
+    }, dtype);
   }
   return RD_OK;
 }
 size_t rd_conv1x1_sc_packed_bytes(int cin, int cout) { return sc_frag_bytes(cin, cout); }
-int rd_pack_conv1x1_sc_host(const float* w, const float* fold_scale, int cout, int cin, void* out) {
+int rd_pack_conv1x1_sc_host(const float* w, const float* fold_scale, int cout, int cin, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_conv1x1_sc: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_conv1x1_sc: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE((cout == 64 || cout == 128) && cin >= 1 && cin <= 128, RD_ESHAPE, "pack_conv1x1_sc: cout %d, cin %d (1..128)", cout, cin);
-  pack_sc_frag(w, fold_scale, cin, cout, out);
+  pack_sc_frag(w, fold_scale, cin, cout, out, dtype);
   return RD_OK;
 }
 int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale, const float* shift,
                          const void* residual, int r_cstride, int r_coff, const void* sc_x, int sc_cstride, int sc_coff,
                          int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
-                         int cout, int stride_w, int flags, void* stream) {
+                         int cout, int stride_w, int flags, int dtype, void* stream) {
   RD_REQUIRE(x && w_packed && y, RD_EINVAL, "conv3x3_ex: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "conv3x3_ex: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE(B > 0 && H > 0 && Win > 0 && cin > 0 && (cout == 64 || cout == 128), RD_ESHAPE, "conv3x3_ex: shape / cout %d", cout);
   RD_REQUIRE(stride_w == 1 || (stride_w == 2 && Win % 2 == 0), RD_ESHAPE, "conv3x3_ex: stride_w %d with Win %d (stride 2 needs an even width)", stride_w, Win);
   RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "conv3x3_ex: y channels exceed stride");
@@ -282,21 +292,24 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
   RD_REQUIRE(!(fl & RD_SCALE_FOLDED) || !scale, RD_EINVAL, "conv3x3_ex: folded weights take no scale array");
   return launch_conv3(x, x_cstride * v, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride, y_coff, B, H,
                       Wv, ex_view_cin(cin, x_cstride, stride_w), cout, fl, 1, (hipStream_t)stream, stride_w == 2 ? 1 : 0,
-                      sc_x ? &e : nullptr);
+                      sc_x ? &e : nullptr, dtype);
 }
 
 // ---- last tower conv + the tower's 1x1 output conv in one launch (bf16) ---------------------------------------------
 size_t rd_head_packed_bytes(void) { return 16384; }
-int rd_pack_head_weight_host(const float* w, int nout, int cin, void* out_host) {
+int rd_pack_head_weight_host(const float* w, int nout, int cin, int dtype, void* out_host) {
   RD_REQUIRE(w && out_host, RD_EINVAL, "pack_head_weight: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_head_weight: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE(nout >= 1 && nout <= 8 && cin >= 1 && cin <= 128, RD_ESHAPE, "pack_head_weight: nout %d (1..8), cin %d (1..128)", nout, cin);
-  pack_head_frag(w, nout, cin, out_host);
+  pack_head_frag(w, nout, cin, out_host, dtype);
   return RD_OK;
 }
 int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
                               const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
-                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, void* stream) {
+                              const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, int dtype,
+                              void* stream) {
   RD_REQUIRE(x && w_packed && head_w_packed && head_bias && out, RD_EINVAL, "conv2d_head_out: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "conv2d_head_out: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && nout >= 1 && nout <= 8, RD_ESHAPE, "conv2d_head_out: shape / nout %d (1..8)", nout);
   RD_REQUIRE(!(flags & RD_ADD), RD_EINVAL, "conv2d_head_out: no residual in a head tower");
   RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE,
@@ -307,7 +320,7 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
   memset(&h, 0, sizeof(h));
   h.hw = (const unsigned char*)head_w_packed; h.hb = head_bias; h.ho = out; h.ho_bs = out_batch_stride; h.ho_off = n_off; h.hn = nout;
   return launch_conv3(x, x_cstride, x_coff, w_packed, scale, shift, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
-                      (hipStream_t)stream, 0, &h);
+                      (hipStream_t)stream, 0, &h, dtype);
 }
 
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase, const float* scale,
@@ -327,12 +340,13 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   if (deconv_embeds_3x3(tl)) {
     const int ts = deconv_tap_set(tl);
     if (!ts) tl = conv_taps(3, 3);   // packed as a full 3x3 window with zero weights (rd_pack_deconv_weight_host)
-    if (dtype == RD_BF16 && Wout == stride_w * Win && (cout == 64 || cout == 128) && !dev_switches().conv_v1) {
+    if (is_h16(dtype) && Wout == stride_w * Win && (cout == 64 || cout == 128) && !dev_switches().conv_v1 &&
+        conv3_has_form(dtype, (flags & RD_SCALE_FOLDED) != 0)) {
       // phase pixels of the output seen as [H][Win][stride_w * Cstride]: channel offset phase * Cstride
       const bf16_t* r = (const bf16_t*)residual;
       return launch_conv3(x, x_cstride, x_coff, w_packed_phase, scale, shift, r, r_cstride * stride_w,
                           r_coff + phase * r_cstride, y, y_cstride * stride_w, y_coff + phase * y_cstride, B, H, Win, cin,
-                          cout, flags, 1, (hipStream_t)stream, ts, nullptr);
+                          cout, flags, 1, (hipStream_t)stream, ts, nullptr, dtype);
     }
   }
   RD_REQUIRE(!(flags & RD_SCALE_FOLDED), RD_ESHAPE, "deconv2d: RD_SCALE_FOLDED needs the persistent 3x3 kernel (bf16, cout 64/128, "
@@ -347,20 +361,22 @@ int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const 
   RD_REQUIRE(x && w && bias && out, RD_EINVAL, "head_out: null pointer");
   RD_REQUIRE(cin % 8 == 0 && cin <= 128 && cin > 0, RD_ESHAPE, "head_out: cin %d (multiple of 8, <= 128)", cin);
   RD_REQUIRE(nout == 1 || nout == 7 || nout == 8, RD_ESHAPE, "head_out: nout %d not in {1,7,8}", nout);
-  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "head_out: dtype");
+  RD_REQUIRE(dtype == RD_F32 || is_h16(dtype), RD_EINVAL, "head_out: dtype");
   hipStream_t st = (hipStream_t)stream;
   const long HW = (long)H * W;
   dim3 grid((unsigned)std::min<long>((HW + 31) / 32, 4096), B);
   ProfScope ps(RD_PROF_HEAD_OUT, st);
-  if (dtype == RD_BF16 && nout > 1 && cin % 16 == 0 && x_cstride % 8 == 0 && x_coff % 8 == 0) {   // matrix-core streaming variant
+  if (is_h16(dtype) && nout > 1 && cin % 16 == 0 && x_cstride % 8 == 0 && x_coff % 8 == 0) {   // matrix-core streaming variant
     dim3 g2((unsigned)std::min<long>((HW + 127) / 128, 2048), B);
-#define RD_HOM(NO) hipLaunchKernelGGL((head_out_mfma_kernel<NO>), g2, dim3(256), 0, st, (const bf16_t*)x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
-    if (nout == 7) RD_HOM(7); else RD_HOM(8);
+#define RD_HOM(NO, DT_) hipLaunchKernelGGL((head_out_mfma_kernel<NO, DT_>), g2, dim3(256), 0, st, (const bf16_t*)x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
+    if (dtype == RD_F16) { if (nout == 7) RD_HOM(7, RD_F16); else RD_HOM(8, RD_F16); }
+    else { if (nout == 7) RD_HOM(7, RD_BF16); else RD_HOM(8, RD_BF16); }
 #undef RD_HOM
     return check_launch("head_out");
   }
 #define RD_HO(DT, NO) hipLaunchKernelGGL((head_out_kernel<DT, NO>), grid, dim3(256), 0, st, x, x_cstride, x_coff, w, bias, out, out_batch_stride, n_off, HW, cin)
   if (dtype == RD_BF16) { if (nout == 1) RD_HO(RD_BF16, 1); else if (nout == 7) RD_HO(RD_BF16, 7); else RD_HO(RD_BF16, 8); }
+  else if (dtype == RD_F16) { if (nout == 1) RD_HO(RD_F16, 1); else if (nout == 7) RD_HO(RD_F16, 7); else RD_HO(RD_F16, 8); }
   else { if (nout == 1) RD_HO(RD_F32, 1); else if (nout == 7) RD_HO(RD_F32, 7); else RD_HO(RD_F32, 8); }
 #undef RD_HO
   return check_launch("head_out");
@@ -371,7 +387,7 @@ size_t rd_meta_packed_bytes(int dtype) { return meta_layout(dtype).total; }
 int rd_pack_meta_host(const float* w0, const float* b0, const float* w1, const float* b1, const float* s1,
                       const float* t1, const float* agg, const float* s2, const float* t2, int dtype, void* out) {
   RD_REQUIRE(w0 && b0 && w1 && b1 && s1 && t1 && agg && s2 && t2 && out, RD_EINVAL, "pack_meta: null pointer");
-  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "pack_meta: dtype");
+  RD_REQUIRE(dtype == RD_F32 || is_h16(dtype), RD_EINVAL, "pack_meta: dtype");
   pack_meta(w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype, out);
   return RD_OK;
 }
@@ -379,7 +395,7 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
                        void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream) {
   RD_REQUIRE(data && coord_nchw && packed && y, RD_EINVAL, "meta_kernel: null pointer");
   RD_REQUIRE(B > 0 && H > 0 && W > 0, RD_ESHAPE, "meta_kernel: empty shape");
-  RD_REQUIRE(dtype == RD_F32 || dtype == RD_BF16, RD_EINVAL, "meta_kernel: dtype");
+  RD_REQUIRE(dtype == RD_F32 || is_h16(dtype), RD_EINVAL, "meta_kernel: dtype");
   const int ch = ch_per_slot(dtype);
   RD_REQUIRE(d_cstride % ch == 0 && d_coff % ch == 0 && y_cstride % ch == 0 && y_coff % ch == 0, RD_ESHAPE,
              "meta_kernel: channel strides/offsets must be 16-byte multiples");
@@ -394,10 +410,14 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t consts = 9 * 64 * 4 * 2 + 1024;
   ProfScope ps(RD_PROF_META, st);
-  if (dtype == RD_BF16) {
-    const size_t lds = meta_layout(RD_BF16).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
-    allow_big_lds(meta_bf16_kernel<WAVES>);
-    hipLaunchKernelGGL((meta_bf16_kernel<WAVES>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
+  if (is_h16(dtype)) {
+    const size_t lds = meta_layout(dtype).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
+    static const bool once = (allow_big_lds(meta16_kernel<WAVES, RD_BF16>), allow_big_lds(meta16_kernel<WAVES, RD_F16>), true);
+    (void)once;
+    if (dtype == RD_F16)
+      hipLaunchKernelGGL((meta16_kernel<WAVES, RD_F16>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
+    else
+      hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
   } else {
     const size_t lds = consts + (size_t)(WAVES + 2) * 34 * 256;
     allow_big_lds(meta_kernel<RD_F32, WAVES>);

@@ -161,6 +161,53 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return f;
 }
 
+// ---- fp16 (round 3: the reference's own arithmetic type, config fp16 = True) -------------------------------------------
+typedef unsigned short f16_t;   // raw IEEE binary16 bits
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ f16_t f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }  // RNE
+__host__ __device__ __forceinline__ float f16_to_f32(f16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__host__ __device__ __forceinline__ unsigned f32x2_to_f16x2(float a, float b) {   // one v_cvt_pk_f16_f32 on gfx950
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+#else
+  return (unsigned)f32_to_f16(a) | ((unsigned)f32_to_f16(b) << 16);
+#endif
+}
+
+// The two 16-bit activation / weight types share every layout (2 bytes, 8 channels per 16-byte slot, the same packed MFMA
+// fragment orders); a kernel templated on DT differs only in these conversions and in the MFMA instruction.
+typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+template <int DT> struct H16;
+template <> struct H16<RD_BF16> {
+  static constexpr unsigned short ONE = 0x3F80;
+  __host__ __device__ static __forceinline__ unsigned short from_f32(float v) { return f32_to_bf16(v); }
+  __host__ __device__ static __forceinline__ float to_f32(unsigned short h) { return bf16_to_f32(h); }
+  __host__ __device__ static __forceinline__ unsigned pk(float a, float b) { return f32x2_to_bf16x2(a, b); }
+  __host__ __device__ static __forceinline__ f32x2_t_ unpk(unsigned u) {   // bf16 -> f32 is a 16-bit shift of the packed pair
+    unsigned lo = u << 16, hi = u & 0xffff0000u;
+    return f32x2_t_{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
+  }
+  __device__ static __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct H16<RD_F16> {
+  static constexpr unsigned short ONE = 0x3C00;
+  __host__ __device__ static __forceinline__ unsigned short from_f32(float v) { return f32_to_f16(v); }
+  __host__ __device__ static __forceinline__ float to_f32(unsigned short h) { return f16_to_f32(h); }
+  __host__ __device__ static __forceinline__ unsigned pk(float a, float b) { return f32x2_to_f16x2(a, b); }
+  __host__ __device__ static __forceinline__ f32x2_t_ unpk(unsigned u) {
+    return f32x2_t_{f16_to_f32((unsigned short)(u & 0xffffu)), f16_to_f32((unsigned short)(u >> 16))};
+  }
+  __device__ static __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+inline bool is_h16(int dt) { return dt == RD_BF16 || dt == RD_F16; }
+inline unsigned short h16_from_f32(int dt, float v) { return dt == RD_F16 ? f32_to_f16(v) : f32_to_bf16(v); }
+inline float h16_to_f32(int dt, unsigned short h) { return dt == RD_F16 ? f16_to_f32(h) : bf16_to_f32(h); }
+
 template <int DT> struct Elem;
 template <> struct Elem<RD_F32> {
   typedef float T;
@@ -174,8 +221,14 @@ template <> struct Elem<RD_BF16> {
   __host__ __device__ static bf16_t from_f32(float v) { return f32_to_bf16(v); }
   __host__ __device__ static float to_f32(bf16_t v) { return bf16_to_f32(v); }
 };
-inline int elem_size(int dt) { return dt == RD_BF16 ? 2 : 4; }
-inline int ch_per_slot(int dt) { return dt == RD_BF16 ? 8 : 4; }
+template <> struct Elem<RD_F16> {
+  typedef f16_t T;
+  static constexpr int CH = 8;
+  __host__ __device__ static f16_t from_f32(float v) { return f32_to_f16(v); }
+  __host__ __device__ static float to_f32(f16_t v) { return f16_to_f32(v); }
+};
+inline int elem_size(int dt) { return dt == RD_F32 ? 4 : 2; }
+inline int ch_per_slot(int dt) { return dt == RD_F32 ? 4 : 8; }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 typedef unsigned Slot16 __attribute__((ext_vector_type(4)));  // one 16-byte LDS/global granule (register-resident)

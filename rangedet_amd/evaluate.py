@@ -71,19 +71,21 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
         return big[K].run(to_inputs([rec]))
 
     def finish(j, chunk, recs, inputs):
+        # one wait (for this pipeline's own post-processing event) and one host copy per batch
+        try:
+            frames = multi.pipes[j].collect()
+        except rdlib.RangeDetError as e:
+            if e.code != rdlib.RD_EWORKSPACE or not wnms:
+                raise
+            frames = [rerun(r) for r in recs]                  # a frame above the WNMS capacity: this batch again, frame by frame, sized for the worst case
         for b, i in enumerate(chunk):
-            rec = roidb[i]
-            try:
-                fr = multi.pipes[j].post[b].collect()
-            except rdlib.RangeDetError as e:
-                if e.code != rdlib.RD_EWORKSPACE or not wnms:
-                    raise
-                fr = rerun(recs[b])
+            rec, fr = roidb[i], frames[b]
             rid = rec.get('rec_id', i)
-            det = fr['det_xyzlwhyaws']
-            if det.shape[0] == 0:
+            per = fr.get('per_class') or {pipe0.class_names[0]: fr}
+            det = {mapping[c]: r['det_xyzlwhyaws'] for c, r in per.items() if r['det_xyzlwhyaws'].shape[0]}
+            if not det:
                 continue                                       # tools/test.py:204-205, 222-223
-            output_dict[rid] = {'det_xyzlwhyaws': {cls: det}, 'meta_info': meta_info(rec, rid)}
+            output_dict[rid] = {'det_xyzlwhyaws': det, 'meta_info': meta_info(rec, rid)}
             annotation_dict[rid] = rec.get('gt_bbox_imu')
 
     pending = []                                               # (pipeline index, record indices, records, inputs kept alive)

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
-RD_F32, RD_BF16 = 0, 1
+RD_F32, RD_BF16, RD_F16 = 0, 1, 2
+H16 = (RD_BF16, RD_F16)     # the two 16-bit element types (same layouts)
 RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED = 1, 2, 4, 8
 RD_WNMS_MAX_K = 65536
 RD_TIE_STABLE, RD_TIE_REFERENCE = 0, 1
@@ -38,19 +39,19 @@ SIGNATURES = {
     "rd_conv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_ex_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "rd_pack_conv3x3_ex_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_pack_conv3x3_ex_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv1x1_sc_packed_bytes": (c_size_t, [c_int, c_int]),
-    "rd_pack_conv1x1_sc_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rd_pack_conv1x1_sc_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_bn_act_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                      c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_void_p]),
+                                     c_int, c_int, c_void_p]),
     "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
-    "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                          c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p]),
     "rd_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p]),
     "rd_meta_packed_bytes": (c_size_t, [c_int]),
@@ -149,22 +150,22 @@ class Lib:
         self.call("rd_pack_conv_weight_host", w.ctypes.data, cout, cin, kh, kw, dtype, out.ctypes.data)
         return out
 
-    def pack_conv3x3_ex(self, w_oihw, stride_w, x_cstride, fold_scale=None):
+    def pack_conv3x3_ex(self, w_oihw, stride_w, x_cstride, fold_scale=None, dtype=RD_BF16):
         w = np.ascontiguousarray(w_oihw, dtype=np.float32)
         cout, cin = w.shape[:2]
         assert w.shape[2:] == (3, 3)
         fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
         out = np.zeros(self.cdll.rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride), dtype=np.uint8)
         self.call("rd_pack_conv3x3_ex_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, stride_w,
-                  x_cstride, out.ctypes.data)
+                  x_cstride, dtype, out.ctypes.data)
         return out
 
-    def pack_conv1x1_sc(self, w_oi, fold_scale=None):
+    def pack_conv1x1_sc(self, w_oi, fold_scale=None, dtype=RD_BF16):
         w = np.ascontiguousarray(w_oi, dtype=np.float32).reshape(w_oi.shape[0], -1)
         cout, cin = w.shape
         fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
         out = np.zeros(self.cdll.rd_conv1x1_sc_packed_bytes(cin, cout), dtype=np.uint8)
-        self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, out.ctypes.data)
+        self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, dtype, out.ctypes.data)
         return out
 
     def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype, fold_scale=None):
@@ -179,10 +180,10 @@ class Lib:
                   stride_w, pad_w, phase, dtype, out.ctypes.data)
         return out
 
-    def pack_head_weight(self, w):
+    def pack_head_weight(self, w, dtype=RD_BF16):
         w = np.ascontiguousarray(w, dtype=np.float32)
         out = np.zeros(self.cdll.rd_head_packed_bytes(), dtype=np.uint8)
-        self.call("rd_pack_head_weight_host", w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data)
+        self.call("rd_pack_head_weight_host", w.ctypes.data, w.shape[0], w.shape[1], dtype, out.ctypes.data)
         return out
 
     def pack_meta(self, w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype):

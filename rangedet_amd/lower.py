@@ -20,7 +20,7 @@ Anything that does not match raises NotImplementedError at lowering time -- ther
 import os
 from dataclasses import dataclass, field
 
-from .lib import RD_ADD, RD_BF16, RD_F32, RD_RELU_POST, RD_RELU_PRE
+from .lib import H16, RD_ADD, RD_BF16, RD_F16, RD_F32, RD_RELU_POST, RD_RELU_PRE
 
 
 @dataclass
@@ -66,10 +66,11 @@ def _is(s, op, **attrs):
 class Lowering:
     def __init__(self, group, input_shapes, dtype, batch):
         """input_shapes: var name -> shape WITHOUT the batch dim, e.g. input_data: (8,64,2656)."""
-        assert dtype in (RD_F32, RD_BF16)
+        assert dtype in (RD_F32, RD_BF16, RD_F16)
         self.dtype = dtype
-        self.esz = 2 if dtype == RD_BF16 else 4
-        self.gran = 16 if dtype == RD_BF16 else 8  # channel granule = one MFMA k-step
+        self.h16 = dtype in H16                    # 16-bit activations / weights: the persistent-kernel fusions apply
+        self.esz = 2 if self.h16 else 4
+        self.gran = 16 if self.h16 else 8          # channel granule = one MFMA k-step
         self.B = batch
         self.shapes = dict(input_shapes)
         self.plan = Plan(dtype=dtype, batch=batch)
@@ -86,7 +87,7 @@ class Lowering:
         """bf16: the last conv of a head tower whose ONLY consumer is one 1x1 output conv (rpn_cls_logit / rpn_reg_delta of a
         single-class head) runs as rd_conv2d_bn_act_head_out: the output conv is applied in the 3x3 kernel's epilogue and the
         128-channel tower output is never written to HBM nor read back.  (Two classes read the tensor twice: left alone.)"""
-        if self.dtype != RD_BF16 or os.environ.get("RD_NO_FUSE_HEAD"):
+        if not self.h16 or os.environ.get("RD_NO_FUSE_HEAD"):
             return
         steps = self.plan.steps
         uses = {}
@@ -211,9 +212,9 @@ class Lowering:
         out = self._out(cout, x.H, Wout, dest)
         # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
         # and, unless RD_NO_FOLD is set, every bf16 3x3 conv with the BatchNorm scale folded into its weights (RD_SCALE_FOLDED)
-        fold = self.dtype == RD_BF16 and k == (3, 3) and not os.environ.get("RD_NO_FOLD")
+        fold = self.h16 and k == (3, 3) and not os.environ.get("RD_NO_FOLD")
         s2view = sw == 2 and x.W % 2 == 0 and not os.environ.get("RD_NO_S2_VIEW")
-        ex = self.dtype == RD_BF16 and k == (3, 3) and (sc is not None or s2view or (fold and sw == 1))
+        ex = self.h16 and k == (3, 3) and (sc is not None or s2view or (fold and sw == 1))
         kw_fold = dict(fold=bool(ex and (fold or sc is not None)), s2view=bool(ex and s2view))
         kw = {}
         if sc is not None:
@@ -227,7 +228,7 @@ class Lowering:
     def _fusable_projection(self, main_conv, sc):
         """sc = BN(Convolution 1x1, no bias) with the main 3x3 conv's stride, at most 128 input channels, and (stride 2) an even
         input width: the shortcut the persistent 3x3 kernel can accumulate in its epilogue (bf16 only)."""
-        if self.dtype != RD_BF16 or os.environ.get("RD_NO_FUSE_SC"):
+        if not self.h16 or os.environ.get("RD_NO_FUSE_SC"):
             return None
         if not (sc.op == "BatchNorm" and sc.inputs[0].op == "Convolution"):
             return None
@@ -276,7 +277,7 @@ class Lowering:
                     raise ValueError("agg add shape mismatch at %s" % add.name)
                 self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
                           cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD,
-                          fold=self.dtype == RD_BF16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD"))
+                          fold=self.h16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD"))
                 return out
         raise NotImplementedError("elemwise_add %s is not skip + relu(BN(Deconvolution))" % add.name)
 

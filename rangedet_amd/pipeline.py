@@ -10,75 +10,12 @@ from .lower import lower
 from .runtime import Executor, TorchAllocator
 
 
-def input_shapes(H, W, strides=(1, 2, 4)):
-    shapes = {'input_data': (8, H, W), 'coord_s1': (3, H, W)}
+def input_shapes(H, W, strides=(1, 2, 4), channels=8):
+    shapes = {'input_data': (channels, H, W), 'coord_s1': (3, H, W)}
     for s in strides:
         shapes['pc_vehicle_frame_s%d' % s] = (H * W // s, 3)
         shapes['range_image_mask_s%d' % s] = (H * W // s,)
     return shapes
-
-
-class PostProcessor:
-    """tools/test.py:200-224 on the device for one frame: (k,) scores + (k,10) boxes -> (M,12) rows, keep, (M,8)."""
-
-    def __init__(self, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096, hash_scale=100, tie_order="reference"):
-        self.k, self.cap = k, min(cap, k, rdlib.RD_WNMS_MAX_K)
-        self.hash_scale, self.tie_order = int(hash_scale), tie_order
-        self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
-        self.L, self.A = lib, alloc
-        A, L = alloc, lib
-        self.dets = A.alloc(k * 12 * 4)
-        self.count = A.alloc(16, zero=True)
-        self.ws_f_bytes = L.raw("rd_score_filter_workspace_bytes")(k)
-        self.ws_f = A.alloc(self.ws_f_bytes)
-        self.ws_w_bytes = L.raw("rd_wnms_workspace_bytes")(self.cap)
-        self.ws_w = A.alloc(self.ws_w_bytes)
-        self.out = A.alloc(self.cap * 12 * 4)
-        self.keep = A.alloc(self.cap * 4)
-        self.nkeep = A.alloc(16, zero=True)
-        self.out8 = A.alloc(self.cap * 8 * 4)
-        # tie_order "stable": the rows reaching WNMS are already in (score desc, index asc) order -- get_sorted_foreground
-        # sorts and the score filter is a stable compaction -- so the processing order is the identity.  "reference"
-        # (default): the library replays the reference's std::sort (nms.h:786-792) so tied scores are processed in its order
-        self.identity = A.upload(np.arange(self.cap, dtype=np.int32))
-
-    def enqueue_filter(self, score_ptr, box_ptr, stream=None):
-        """Score filter + 10->11 dim conversion only: after this the score / box buffers may be overwritten."""
-        L, A = self.L, self.A
-        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
-        L.call("rd_score_filter_dets", score_ptr, box_ptr, self.k, self.min_score, A.ptr(self.dets), A.ptr(self.count),
-               A.ptr(self.ws_f), self.ws_f_bytes, st)
-
-    def enqueue_nms(self, order_ptr=None, stream=None):
-        L, A = self.L, self.A
-        st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
-        if order_ptr is None and self.tie_order == "stable":
-            order_ptr = A.ptr(self.identity)
-        L.call("rd_wnms_4c", A.ptr(self.dets), self.cap, A.ptr(self.count), order_ptr, rdlib.RD_TIE_REFERENCE, self.thr_lo,
-               self.thr_hi, self.is3d, self.hash_scale, A.ptr(self.out), A.ptr(self.keep), A.ptr(self.nkeep), A.ptr(self.ws_w),
-               self.ws_w_bytes, st)
-        L.call("rd_dets12_to_8", A.ptr(self.out), self.cap, A.ptr(self.nkeep), A.ptr(self.out8), st)
-
-    def enqueue(self, score_ptr, box_ptr, order_ptr=None, stream=None):
-        """Enqueue on `stream` (a side stream from alloc.new_stream(), or None = the current stream).  Returns the event
-        recorded right after the score filter, i.e. the point from which the score / box buffers may be overwritten."""
-        A = self.A
-        self.enqueue_filter(score_ptr, box_ptr, stream)
-        ev = A.record_event(stream) if hasattr(A, "record_event") else None
-        self.enqueue_nms(order_ptr, stream)
-        return ev
-
-    def collect(self):
-        A = self.A
-        A.sync()
-        K = int(A.to_numpy(A.view_i32(self.count, (1,)))[0])
-        M = int(A.to_numpy(A.view_i32(self.nkeep, (1,)))[0])
-        if K > self.cap:
-            raise rdlib.RangeDetError(rdlib.RD_EWORKSPACE, "%d detections above min_score exceed the WNMS capacity %d" % (K, self.cap))
-        rows = A.to_numpy(A.view_f32(self.out, (self.cap, 12)))[:M].copy()
-        keep = A.to_numpy(A.view_i32(self.keep, (self.cap,)))[:M].copy()
-        d8 = A.to_numpy(A.view_f32(self.out8, (self.cap, 8)))[:M].copy()
-        return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
 
 
 class BatchPostProcessor:
@@ -102,7 +39,11 @@ class BatchPostProcessor:
         self.keep = A.alloc(B * self.cap * 4)
         self.nkeep = A.alloc(max(16, 4 * B), zero=True)
         self.out8 = A.alloc(B * self.cap * 8 * 4)
-        self.identity = A.upload(np.arange(self.cap, dtype=np.int32))   # see PostProcessor: rows arrive sorted
+        # tie_order "stable": the rows reaching WNMS are already in (score desc, index asc) order -- get_sorted_foreground
+        # sorts and the score filter is a stable compaction -- so the processing order is the identity.  "reference"
+        # (default): the library replays the reference's std::sort (nms.h:786-792) so tied scores are processed in its order
+        self.identity = A.upload(np.arange(self.cap, dtype=np.int32))
+        self._host = None          # one host copy of the batch's results per sync (collect_all)
 
     def enqueue_filter(self, score_ptr, score_bs, box_ptr, box_bs, stream=None):
         L, A = self.L, self.A
@@ -120,17 +61,28 @@ class BatchPostProcessor:
         L.call("rd_dets12_to_8_batched", A.ptr(self.out), self.cap * 12, self.cap, A.ptr(self.nkeep), A.ptr(self.out8),
                self.cap * 8, self.B, st)
 
-    def collect(self, b=0):
+    def collect_all(self, done=None):
+        """Results of all B frames with ONE wait and ONE host copy of each array: `done` = an event recorded behind this
+        batch's post-processing on its stream (only that event is waited for, so other batches in flight keep running);
+        None = device-wide sync."""
         A = self.A
-        A.sync()
-        K = int(A.to_numpy(A.view_i32(self.count, (self.B,)))[b])
-        M = int(A.to_numpy(A.view_i32(self.nkeep, (self.B,)))[b])
-        if K > self.cap:
-            raise rdlib.RangeDetError(rdlib.RD_EWORKSPACE, "%d detections above min_score exceed the WNMS capacity %d" % (K, self.cap))
-        rows = A.to_numpy(A.view_f32(self.out, (self.B, self.cap, 12)))[b, :M].copy()
-        keep = A.to_numpy(A.view_i32(self.keep, (self.B, self.cap)))[b, :M].copy()
-        d8 = A.to_numpy(A.view_f32(self.out8, (self.B, self.cap, 8)))[b, :M].copy()
-        return dict(num_candidates=K, wnms_rows=rows, keep_inds=keep, det_xyzlwhyaws=d8)
+        if done is not None and hasattr(done, "synchronize"):
+            done.synchronize()
+        else:
+            A.sync()
+        count = np.array(A.to_numpy(A.view_i32(self.count, (self.B,))))
+        nkeep = np.array(A.to_numpy(A.view_i32(self.nkeep, (self.B,))))
+        if int(count.max()) > self.cap:
+            raise rdlib.RangeDetError(rdlib.RD_EWORKSPACE, "%d detections above min_score exceed the WNMS capacity %d" % (int(count.max()), self.cap))
+        m = int(nkeep.max()) if self.B else 0
+        rows = np.array(A.to_numpy(A.view_f32(self.out, (self.B, self.cap, 12))[:, :m]))
+        keep = np.array(A.to_numpy(A.view_i32(self.keep, (self.B, self.cap))[:, :m]))
+        d8 = np.array(A.to_numpy(A.view_f32(self.out8, (self.B, self.cap, 8))[:, :m]))
+        return [dict(num_candidates=int(count[b]), wnms_rows=rows[b, :nkeep[b]].copy(), keep_inds=keep[b, :nkeep[b]].copy(),
+                     det_xyzlwhyaws=d8[b, :nkeep[b]].copy()) for b in range(self.B)]
+
+    def collect(self, b=0):
+        return self.collect_all()[b]
 
 
 class Nms3dPostProcessor:
@@ -159,9 +111,19 @@ class Nms3dPostProcessor:
                mk * 12, A.ptr(self.count), A.ptr(self.ws), self.ws_bytes, self.B, st)
         L.call("rd_dets12_to_8_batched", A.ptr(self.dets), mk * 12, mk, A.ptr(self.count), A.ptr(self.out8), mk * 8, self.B, st)
 
+    def collect_all(self, done=None):
+        if done is not None and hasattr(done, "synchronize"):
+            done.synchronize()
+        else:
+            self.A.sync()
+        return [self._collect(b) for b in range(self.B)]
+
     def collect(self, b=0):
+        self.A.sync()
+        return self._collect(b)
+
+    def _collect(self, b):
         A = self.A
-        A.sync()
         K = int(A.to_numpy(A.view_i32(self.count, (self.B,)))[b])
         rows = A.to_numpy(A.view_f32(self.dets, (self.B, self.mk, 12)))[b, :K].copy()
         d8 = A.to_numpy(A.view_f32(self.out8, (self.B, self.mk, 8)))[b, :K].copy()
@@ -199,31 +161,44 @@ class RangeDetPipeline:
         tie_order: "reference" = rows with equal scores are processed in the order the reference's std::sort leaves them
         (nms.h:786-792, replayed on the device); "stable" = in index order (no extra kernel).  hash_scale: the BBoxHash cell
         size tools/test.py:216 passes (100).  wnms_cap: rows per frame the weighted NMS is sized for; collect() raises when a
-        frame had more candidates above min_score (the device never truncates silently: the true count comes back)."""
+        frame had more candidates above min_score (the device never truncates silently: the true count comes back).
+        variant "kitti" (BASELINE config 5): 5 input channels, vehicle + pedestrian heads -- one post-processor per class, each
+        with its class's top-k and min_score (builder.py:467-478 slices the classes; the reference's driver itself asserts one
+        class, tools/test.py:182, so the per-class loop is this harness's: det_xyzlwhyaws keyed by class as tools/test.py:224).
+        pre_nms_top_n: an int (first class) or {class: k}."""
+        topn = pre_nms_top_n if isinstance(pre_nms_top_n, dict) else {cfgmod.variant_classes(variant)[0]: pre_nms_top_n}
         self.cfg = cfgmod.get_config(False, variant=variant, feat_size=feat_size, pad_field=pad_field,
-                                     batch_image=batch, pre_nms_top_n={variant: pre_nms_top_n}, wnms=wnms)
+                                     batch_image=batch, pre_nms_top_n=topn, wnms=wnms)
         self.wnms = bool(wnms)
         General, RpnParam, ModelParam, TestParam = self.cfg[0], self.cfg[2], self.cfg[6], self.cfg[8]
         self.lib = lib or rdlib.get_lib()
         self.alloc = alloc or TorchAllocator()
-        self.plan = lower(ModelParam.test_symbol, input_shapes(*pad_field), dtype, batch)
+        self.class_names = tuple(General.class_names)
+        nch = cfgmod.KITTI_INPUT_CHANNELS if variant == "kitti" else 8
+        self.plan = lower(ModelParam.test_symbol, input_shapes(*pad_field, channels=nch), dtype, batch)
         self.exe = Executor(self.plan, params, self.lib, self.alloc)
-        cname = General.class_names[0]
-        self.k = pre_nms_top_n
+        self.ks = {c: RpnParam.all_proposal.rpn_pre_nms_top_n[c] for c in self.class_names}
         self.batch = batch
         self._post_stream = None
         self._filter_done = None
-        if self.wnms:
-            self.bpost = BatchPostProcessor(batch, self.k, TestParam.min_score[cname], TestParam.nms.thr_lo, TestParam.nms.thr_hi,
-                                            TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap, hash_scale=hash_scale,
-                                            tie_order=tie_order)
-        else:
-            self.bpost = Nms3dPostProcessor(batch, self.k, RpnParam.all_proposal.rpn_post_nms_top_n[cname],
-                                            TestParam.min_score[cname], self.lib, self.alloc)
+        self._post_done = None
+        assert self.wnms or len(self.class_names) == 1, "the NMS3D branch is single-class (tools/test.py:182)"
+        self.bposts = {}
+        for c in self.class_names:
+            if self.wnms:
+                self.bposts[c] = BatchPostProcessor(batch, self.ks[c], TestParam.min_score[c], TestParam.nms.thr_lo,
+                                                    TestParam.nms.thr_hi, TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap,
+                                                    hash_scale=hash_scale, tie_order=tie_order)
+            else:
+                self.bposts[c] = Nms3dPostProcessor(batch, self.ks[c], RpnParam.all_proposal.rpn_post_nms_top_n[c],
+                                                    TestParam.min_score[c], self.lib, self.alloc)
+        # (first class: what single-class callers -- bench.py, evaluate, the gather -- use)
+        self.k = self.ks[self.class_names[0]]
+        self.bpost = self.bposts[self.class_names[0]]
         self.post = [_FrameView(self.bpost, b) for b in range(batch)]
 
     def forward(self, inputs):
-        """Graph outputs only: [rec_id, fg_cls_score (B,k), decoded_bbox (B,k,10), zeros, gt_bbox_imu, gt_class]."""
+        """Graph outputs only: [rec_id, then per class (fg_cls_score (B,k), decoded_bbox (B,k,10), zeros), gt_bbox_imu, gt_class]."""
         return self.exe.forward(inputs)
 
     def enqueue(self, inputs):
@@ -236,26 +211,43 @@ class RangeDetPipeline:
         if side and self._filter_done is not None:
             A.wait_event(self._filter_done)          # previous frame's filter has consumed the score / box buffers
         outs = self.exe.forward(inputs)
-        sc, bx = outs[1], outs[2]
         if side:
             A.wait_event(A.record_event(), self._post_stream)
-        # one batched score filter (it is what reads the graph's score / box buffers: the next batch's forward only has
-        # to wait for these three short kernels), then one batched weighted NMS for all frames
+        # one batched score filter per class (it is what reads the graph's score / box buffers: the next batch's forward only
+        # has to wait for these short kernels), then one batched weighted NMS per class for all frames
         ptr = lambda t: self.alloc.ptr(t) if hasattr(t, "data_ptr") else t.ctypes.data
         if not self.wnms:   # outs = [rec_id, score (B,k), bbox_after_nms (B,mk,10), keep_inds (B,mk) int32, ...]
+            sc, bx = outs[1], outs[2]
             self.bpost.enqueue(ptr(sc), self.k, ptr(bx), ptr(outs[3]), outs[3], stream=self._post_stream)
             self._filter_done = A.record_event(self._post_stream) if side else None
+            self._post_done = self._filter_done
             return outs
-        sc_bs = (ptr(sc[1]) - ptr(sc[0])) // 4 if self.batch > 1 else 0
-        bx_bs = (ptr(bx[1]) - ptr(bx[0])) // 4 if self.batch > 1 else 0
-        self.bpost.enqueue_filter(ptr(sc[0]), sc_bs, ptr(bx[0]), bx_bs, stream=self._post_stream)
+        for ci, c in enumerate(self.class_names):
+            sc, bx = outs[1 + 3 * ci], outs[2 + 3 * ci]
+            sc_bs = (ptr(sc[1]) - ptr(sc[0])) // 4 if self.batch > 1 else 0
+            bx_bs = (ptr(bx[1]) - ptr(bx[0])) // 4 if self.batch > 1 else 0
+            self.bposts[c].enqueue_filter(ptr(sc[0]), sc_bs, ptr(bx[0]), bx_bs, stream=self._post_stream)
         self._filter_done = A.record_event(self._post_stream) if side else None
-        self.bpost.enqueue_nms(stream=self._post_stream)
+        for c in self.class_names:
+            self.bposts[c].enqueue_nms(stream=self._post_stream)
+        self._post_done = A.record_event(self._post_stream) if side else None
         return outs
+
+    def collect(self):
+        """Per frame: the first class's result dict (num_candidates, wnms_rows, keep_inds, det_xyzlwhyaws); with several classes
+        the same per class under `per_class` -- waits only for this pipeline's own post-processing event."""
+        per = {c: self.bposts[c].collect_all(self._post_done) for c in self.class_names}
+        res = []
+        for b in range(self.batch):
+            r = dict(per[self.class_names[0]][b])
+            if len(self.class_names) > 1:
+                r["per_class"] = {c: per[c][b] for c in self.class_names}
+            res.append(r)
+        return res
 
     def run(self, inputs):
         outs = self.enqueue(inputs)
-        res = [p.collect() for p in self.post]
+        res = self.collect()
         r0 = dict(res[0]) if self.batch == 1 else dict(frames=res)
         r0["fg_cls_score"], r0["decoded_bbox"] = outs[1], outs[2]
         return r0
@@ -287,5 +279,5 @@ class InterleavedPipelines:
             return j, self.pipes[j].enqueue(inputs)
 
     def collect(self, j):
-        """Synchronise and read back the detections of the batch last enqueued on pipeline j (list, one dict per frame)."""
-        return [p.collect() for p in self.pipes[j].post]
+        """Wait for pipeline j's last batch (its own post-processing event only) and read back its detections: one dict per frame."""
+        return self.pipes[j].collect()

@@ -159,15 +159,15 @@ class Executor:
                             wq[:, pc] = wsc[:, lc]
                     wsc = wq
                 ss, ts = bn_affine(P, sc["bn"], sc["eps"])
-                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s))
-                b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss))
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
+                b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload((t.astype(np.float64) + ts).astype(np.float32))
             elif st.get("ex") and st.get("fold"):   # scale folded into the weights, the shift enters through the accumulators
-                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s))
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload(t)
                 b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
             elif st.get("ex"):
-                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs))
+                b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, dtype=dt))
                 b["scale"], b["shift"] = A.upload(s), A.upload(t)
             else:
                 b["w"] = A.upload(L.pack_conv_weight(w, dt))
@@ -192,7 +192,7 @@ class Executor:
             h = st["head"]
             r0, r1 = h["rows"]
             hw = np.asarray(P[h["name"] + "_weight"], np.float32).reshape(-1, st["cout"])[r0:r1]
-            b["head_w"] = A.upload(L.pack_head_weight(hw))
+            b["head_w"] = A.upload(L.pack_head_weight(hw, dtype=dt))
             b["head_bias"] = A.upload(np.asarray(P[h["name"] + "_bias"], np.float32)[r0:r1])
         elif k == "head_out":
             r0, r1 = st["rows"]
@@ -236,7 +236,7 @@ class Executor:
                 L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]),
                        A.ptr(b["scale"]) if b["scale"] is not None else None, A.ptr(b["shift"]), B,
                        x.H, x.W, b["cin"], b["flags"], A.ptr(b["head_w"]), A.ptr(b["head_bias"]), self.p(h["out"]),
-                       h["N"] * h["nout"], h["n_off"], h["nout"], st_)
+                       h["N"] * h["nout"], h["n_off"], h["nout"], dt, st_)
             elif k == "conv" and b.get("ex"):
                 x, o, r, sx = b["x"], b["out"], b["res"], b.get("sc_x")
                 cin = len(b["cmap"]) if b.get("cmap") else b["cin"]
@@ -245,7 +245,7 @@ class Executor:
                        self.p(sx) if sx else None, sx.cs if sx else 0, sx.co if sx else 0,
                        (len(b["sc"]["cmap"]) if b["sc"].get("cmap") else b["sc"]["cin"]) if sx else 0,
                        A.ptr(b["sc_w"]) if sx else None, self.p(o), o.cs, o.co, B, x.H, x.W, cin, b["cout"], b["stride_w"],
-                       b["flags"], st_)
+                       b["flags"], dt, st_)
             elif k == "conv":
                 x, o, r = b["x"], b["out"], b["res"]
                 L.call("rd_conv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["scale"]), A.ptr(b["shift"]),

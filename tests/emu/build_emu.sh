@@ -1,7 +1,7 @@
 #!/bin/bash
 # hipemu -- TEST INFRASTRUCTURE ONLY: compile the product's pure-HIP sources for the host CPU against the
-# tests/emu shim (see tests/emu/hip/hip_runtime.h).  The product never loads this library.
+# tests/emu shim (EMU_FLAGS=-g for a debuggable build: the debug info of the unrolled kernels doubles the compile time) (see tests/emu/hip/hip_runtime.h).  The product never loads this library.
 set -e
 cd "$(dirname "$0")/../.."
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
-$CXX -x c++ -std=c++17 -O2 -g -fPIC -shared ${EMU_FLAGS} -Itests/emu -Iinclude rangedet_amd/csrc/rd_api.hip -o tests/emu/librangedet_emu.so
+$CXX -x c++ -std=c++17 -O2 -fPIC -shared ${EMU_FLAGS} -Itests/emu -Iinclude rangedet_amd/csrc/rd_api.hip -o tests/emu/librangedet_emu.so

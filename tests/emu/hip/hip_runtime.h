@@ -328,6 +328,12 @@ inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_s16x8 a, hip
   for (int i = 0; i < 8; ++i) { fa[i] = hipemu::bf16_bits_to_f32((unsigned short)a[i]); fb[i] = hipemu::bf16_bits_to_f32((unsigned short)b[i]); }
   return hipemu::mfma32<8>(fa, fb, c);
 }
+typedef _Float16 hipemu_h16x8 __attribute__((ext_vector_type(8)));
+inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_h16x8 a, hipemu_h16x8 b, hipemu_f32x16 c, int, int, int) {
+  float fa[8], fb[8];
+  for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+  return hipemu::mfma32<8>(fa, fb, c);
+}
 inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
   return hipemu::mfma32<1>(&a, &b, c);
 }

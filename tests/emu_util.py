@@ -38,22 +38,39 @@ def bf16_round(a):
     return bf16_bits_to_f32(f32_to_bf16_bits(a))
 
 
+def f32_to_f16_bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def f16_bits_to_f32(b):
+    return np.ascontiguousarray(b).view(np.float16).astype(np.float32)
+
+
+def h16_round(a, dtype):
+    """Round float32 values to the library's 16-bit element type `dtype` (RD_BF16 / RD_F16), back as float32; RD_F32 unchanged."""
+    if dtype == rdlib.RD_BF16:
+        return bf16_round(a)
+    if dtype == rdlib.RD_F16:
+        return f16_bits_to_f32(f32_to_f16_bits(a))
+    return np.asarray(a, dtype=np.float32)
+
+
 def to_nhwc(x_nchw, dtype, cstride=None, coff=0):
     """(B,C,H,W) float32 -> channels-last buffer (B,H,W,cstride) of the library dtype (zeros elsewhere)."""
     B, C, H, W = x_nchw.shape
     cs = cstride or C
     buf = np.zeros((B, H, W, cs), dtype=np.float32)
     buf[..., coff:coff + C] = np.transpose(x_nchw, (0, 2, 3, 1))
-    return f32_to_bf16_bits(buf) if dtype == rdlib.RD_BF16 else buf
+    return f32_to_bf16_bits(buf) if dtype == rdlib.RD_BF16 else f32_to_f16_bits(buf) if dtype == rdlib.RD_F16 else buf
 
 
 def from_nhwc(buf, dtype, C, coff=0):
-    a = bf16_bits_to_f32(buf) if dtype == rdlib.RD_BF16 else buf
+    a = bf16_bits_to_f32(buf) if dtype == rdlib.RD_BF16 else f16_bits_to_f32(buf) if dtype == rdlib.RD_F16 else buf
     return np.transpose(a[..., coff:coff + C], (0, 3, 1, 2)).copy()
 
 
 def empty_nhwc(B, H, W, cs, dtype):
-    return np.zeros((B, H, W, cs), dtype=np.uint16 if dtype == rdlib.RD_BF16 else np.float32)
+    return np.zeros((B, H, W, cs), dtype=np.uint16 if dtype in rdlib.H16 else np.float32)
 
 
 class NumpyAllocator:

@@ -481,6 +481,47 @@ def test_kitti_full_size_bf16_properties(be):
 
 
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+def test_kitti_pipeline_two_class_fp16(be):
+    """BASELINE config 5 through the PRODUCT harness at its full size, in the reference's own arithmetic type:
+    RangeDetPipeline(variant="kitti", dtype=RD_F16), 64 x 2048 x 5 input, batch 2 -- per class (vehicle top-50000 / min_score 0.5,
+    pedestrian top-5000 / 0.4, builder.py:467-478) the device's score filter + weighted NMS + 12->8 equal the oracle's harness
+    restatement (tools/test.py:184-224) on the pipeline's own stage outputs: survivor indices bit-exact."""
+    from rangedet_amd.pipeline import RangeDetPipeline
+    H, W = 64, 2048
+    P = synth.make_weights(seed=5, width=W, in_ch=cfgmod.KITTI_INPUT_CHANNELS, num_classes=2)
+    fr = IR.make_batch([2, 3], W=W, pad_W=W, H=H)
+    fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])
+    pipe = RangeDetPipeline(P, dtype=R.RD_F16, variant="kitti", feat_size=(H, W), pad_field=(H, W), batch=2,
+                            pre_nms_top_n={'veh': 50000, 'ped': 5000}, wnms_cap=8192)
+    assert pipe.class_names == ('veh', 'ped') and pipe.ks == {'veh': 50000, 'ped': 5000}
+    outs = pipe.enqueue(fr)
+    frames = pipe.collect()
+    assert len(frames) == 2
+    seen = 0
+    for ci, c in enumerate(pipe.class_names):
+        sc = np.array(be.alloc.to_numpy(outs[1 + 3 * ci]))
+        bx = np.array(be.alloc.to_numpy(outs[2 + 3 * ci]))
+        assert sc.shape == (2, pipe.ks[c]) and np.all(np.diff(sc, axis=1) <= 0)
+        for b in range(2):
+            got = frames[b]["per_class"][c]
+            dets, rows, keep, d8 = G.postprocess(sc[b], bx[b], cls=c)
+            assert got["num_candidates"] == dets.shape[0]
+            assert got["keep_inds"].tolist() == list(keep), (c, b)
+            if len(keep):
+                # merged rows: a kept box's voter set depends on IoUs whose clip compares edge angles from atan2f with |da| < 1e-5
+                # (nms.h:120-123); device atan2f and glibc's differ by an ulp (DESIGN.md section 4), which at ~7000 candidates
+                # flips about one vote in a few thousand rows -- the survivors (above) are identical, a flipped row is not
+                rowerr = np.abs(got["wnms_rows"] - rows).max(axis=1)
+                assert (rowerr < 1e-5).mean() >= 0.995, (c, b, int((rowerr >= 1e-5).sum()), len(rowerr))
+                ok = rowerr < 1e-5
+                assert np.abs(got["det_xyzlwhyaws"][ok] - d8[ok]).max() < 1e-4
+            seen += dets.shape[0]
+    assert seen > 100, "the synthetic weights must produce candidates in at least one class"
+    # the first class's result is also what single-class callers read
+    assert frames[0]["keep_inds"].tolist() == frames[0]["per_class"]["veh"]["keep_inds"].tolist()
+
+
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_pipeline_postprocess_matches_oracle(be):
     """forward + score filter + WNMS + 12->8 on the device == tools/test.py:184-224 restated on the same stage inputs."""
     from rangedet_amd.pipeline import RangeDetPipeline
@@ -592,15 +633,18 @@ def _reduced_symbol(cfg, H, W):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-def test_e2e_bf16_tolerance(be):
-    """bf16 run (BASELINE config 2) of the lowered plan -- persistent 3x3 kernel incl. the stride-2 pixel-pair view and the
+@pytest.mark.parametrize("dt", [R.RD_BF16, R.RD_F16], ids=["bf16", "f16"])
+def test_e2e_bf16_tolerance(be, dt):
+    """16-bit runs of the lowered plan: bf16 (BASELINE config 2) and fp16 (the reference's own mixed-precision type, config:35;
+    rounding unit 2^-12 instead of 2^-9, the same error model).
+    bf16 run of the lowered plan -- persistent 3x3 kernel incl. the stride-2 pixel-pair view and the
     fused projection shortcuts, fused Meta-Kernel, fused tower outputs -- against the fp32 oracle with the tolerance derived
     from bf16 rounding depth (BF16_REL_RMS, scaled to this graph's depth).  emu: depth-reduced graph, hip: full depth."""
     emu = be.name == "emu"
     H, Wr, W, k = (8, 62, 64, 300) if emu else (16, 250, 256, 2000)
     cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
     sym, Cfg = _reduced_symbol(cfg, H, W) if emu else (cfg[6].test_symbol, G.Cfg)
-    plan = lower(sym, small_shapes(H, W), R.RD_BF16, 1)
+    plan = lower(sym, small_shapes(H, W), dt, 1)
     assert sum(1 for s in plan.steps if s.get("sc")) == 9 and sum(1 for s in plan.steps if s.get("head")) == 6
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
     fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
@@ -610,13 +654,13 @@ def test_e2e_bf16_tolerance(be):
     sfg = [s for s in plan.steps if s["kind"] == "sorted_fg"][0]
     logit, delta = ex.read_flat(sfg["score"]), ex.read_flat(sfg["delta"])
     depth = 19 if emu else 53
-    model = 2.0 ** -9 * np.sqrt(2 * depth / 3.0)
+    model = (2.0 ** -9 if dt == R.RD_BF16 else 2.0 ** -12) * np.sqrt(2 * depth / 3.0)
     for name, got, want in (("logit", logit, ref["logit"]), ("delta", delta, ref["delta"])):
         err = got - want
         axes = (0, 1) if want.ndim == 3 else None
         spread = want.std(axis=axes)
         rms, mx = np.sqrt((err ** 2).mean(axis=axes)) / spread, np.abs(err).max(axis=axes) / spread
-        print("bf16 vs fp32 oracle (%s), %s: rms/std %s max/std %s (model rms %.4f)" % (be.name, name, np.round(rms, 4), np.round(mx, 4), model))
+        print(("bf16" if dt == R.RD_BF16 else "fp16") + " vs fp32 oracle (%s), %s: rms/std %s max/std %s (model rms %.4f)" % (be.name, name, np.round(rms, 4), np.round(mx, 4), model))
         assert np.all(rms < 2.5 * model) and np.all(mx < 6 * 2.5 * model)
 
 

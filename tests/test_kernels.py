@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import BOTH, HIP_ONLY
-from emu_util import bf16_round, empty_nhwc, from_nhwc, to_nhwc, bf16_bits_to_f32
+from emu_util import bf16_round, empty_nhwc, from_nhwc, h16_round, to_nhwc, bf16_bits_to_f32
 from oracle import cpu_ops as O
 from oracle import graph_ref as G
 from oracle import input_ref as IR
@@ -17,17 +17,23 @@ from rangedet_amd import lib as R
 from rangedet_amd import synth
 from rangedet_amd.runtime import bn_affine
 
-F32, BF16 = R.RD_F32, R.RD_BF16
+F32, BF16, F16 = R.RD_F32, R.RD_BF16, R.RD_F16
+H16 = R.H16
 
 
 def _gran(dt):
-    return 16 if dt == BF16 else 8
+    return 16 if dt in H16 else 8
+
+
+def _ulp(dt):
+    """Half-ulp rounding of the 16-bit types, with margin: bf16 2^-9 -> 2^-8, fp16 2^-12 -> 2^-11."""
+    return 2 ** -8 if dt == BF16 else 2 ** -11
 
 
 def _tol(dt, ref):
-    # f32: accumulation-order noise only.  bf16: inputs are pre-rounded to bf16 so the only error is the output rounding
-    # (half a bf16 ulp = 2^-9 relative) plus fp32 accumulation.
-    return 2e-5 * max(1.0, float(np.abs(ref).max())) if dt == F32 else 2 ** -8 * max(1.0, float(np.abs(ref).max()))
+    # f32: accumulation-order noise only.  16-bit: inputs are pre-rounded to the type so the only error is the output rounding
+    # (half an ulp: 2^-9 relative for bf16, 2^-12 for fp16) plus fp32 accumulation.
+    return 2e-5 * max(1.0, float(np.abs(ref).max())) if dt == F32 else _ulp(dt) * max(1.0, float(np.abs(ref).max())) + (2e-5 if dt == F16 else 0)
 
 
 def run_conv(be, dt, B, H, W, cin, cout, k, stride, flags, cs_in=None, seed=0):
@@ -38,8 +44,7 @@ def run_conv(be, dt, B, H, W, cin, cout, k, stride, flags, cs_in=None, seed=0):
     sh = rng.standard_normal(cout).astype(np.float32)
     Wout = (W + 2 * (k // 2) - k) // stride + 1
     res = rng.standard_normal((B, cout, H, Wout)).astype(np.float32)
-    if dt == BF16:
-        x, w, res = bf16_round(x), bf16_round(w), bf16_round(res)
+    x, w, res = h16_round(x, dt), h16_round(w, dt), h16_round(res, dt)
     g = _gran(dt)
     cs = cs_in or -(-cin // g) * g
     L = be.lib
@@ -56,7 +61,7 @@ def run_conv(be, dt, B, H, W, cin, cout, k, stride, flags, cs_in=None, seed=0):
         ref = ref + res
     if flags & R.RD_RELU_POST:
         ref = np.maximum(ref, 0)
-    raw = be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, Wout, cout))
+    raw = be.down(y, np.uint16 if dt in H16 else np.float32, (B, H, Wout, cout))
     got = from_nhwc(raw, dt, cout)
     assert np.abs(got - ref).max() <= _tol(dt, ref), (np.abs(got - ref).max(), _tol(dt, ref))
 
@@ -83,6 +88,10 @@ CONV_CASES = [
     (BF16, 1, 3, 40, 8, 64, 1, 1, 0),      # 8 input channels (one 16-channel k-step)
     (BF16, 1, 4, 33, 128, 128, 1, 1, 6),   # residual + relu, single-buffered variant
     (BF16, 2, 3, 50, 64, 64, 1, 2, 4),
+    # fp16 (RD_F16): the same kernels on v_mfma_f32_32x32x16_f16 -- persistent 3x3 (plain epilogue), stride 2, 72-channel input,
+    # generic tap kernel for the 1x1 shapes
+    (F16, 2, 9, 70, 64, 128, 3, 1, 6), (F16, 1, 6, 127, 128, 64, 3, 1, 5), (F16, 1, 4, 131, 128, 128, 3, 2, 4),
+    (F16, 1, 2, 20, 72, 128, 3, 1, 4), (F16, 2, 5, 77, 64, 128, 1, 2, 0), (F16, 1, 4, 33, 128, 128, 1, 1, 6),
 ]
 
 
@@ -94,14 +103,15 @@ def test_conv2d_bn_act(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-@pytest.mark.parametrize("case", [(2, 9, 70, 128, 8), (1, 4, 130, 128, 1), (1, 8, 62, 72, 7)])
+@pytest.mark.parametrize("case", [(2, 9, 70, 128, 8), (1, 4, 130, 128, 1), (1, 8, 62, 72, 7), (2, 9, 70, 128, 8, F16), (1, 8, 62, 72, 1, F16)])
 def test_conv_fused_with_head_out(be, case):
     """rd_conv2d_bn_act_head_out == rd_conv2d_bn_act (bf16, ReLU) followed by rd_head_out on its output: the same bf16
     activations feed the same hi + lo weight MFMAs, so only the fp32 summation order differs."""
-    B, H, W, cin, nout = case
+    B, H, W, cin, nout = case[:5]
+    BF16 = case[5] if len(case) > 5 else R.RD_BF16        # (the element type under test; the body below reads "BF16")
     rng = np.random.default_rng(5)
-    x = bf16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32))
-    w = bf16_round((rng.standard_normal((128, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    x = h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), BF16)
+    w = h16_round((rng.standard_normal((128, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), BF16)
     sc, sh = rng.uniform(0.5, 1.5, 128).astype(np.float32), rng.standard_normal(128).astype(np.float32)
     hw = (rng.standard_normal((nout, 128)) / np.sqrt(128)).astype(np.float32)
     hb = rng.standard_normal(nout).astype(np.float32)
@@ -109,39 +119,47 @@ def test_conv_fused_with_head_out(be, case):
     L = be.lib
     xin = be.up(to_nhwc(x, BF16, cstride=cs))
     wp, dsc, dsh = be.up(L.pack_conv_weight(w, BF16)), be.up(sc), be.up(sh)
-    dhw, dhb, dhp = be.up(hw), be.up(hb), be.up(L.pack_head_weight(hw))
+    dhw, dhb, dhp = be.up(hw), be.up(hb), be.up(L.pack_head_weight(hw, dtype=BF16))
     N, off = H * W + 37, 21                                          # a level's slice of a longer flat tensor
     y = be.empty(B * H * W * 128 * 2)
     o1, o2 = be.empty(B * N * nout * 4), be.empty(B * N * nout * 4)
     L.call("rd_conv2d_bn_act", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), None, 0, 0, be.ptr(y), 128, 0, B, H, W,
            cin, 128, 3, 3, 1, R.RD_RELU_POST, BF16, be.stream)
     L.call("rd_head_out", be.ptr(y), 128, 0, be.ptr(dhw), be.ptr(dhb), be.ptr(o1), N * nout, off, B, H, W, 128, nout, BF16, be.stream)
-    L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), B, H, W, cin, R.RD_RELU_POST,
-           be.ptr(dhp), be.ptr(dhb), be.ptr(o2), N * nout, off, nout, be.stream)
     a = be.down(o1, np.float32, (B, N, nout))
-    b = be.down(o2, np.float32, (B, N, nout))
     assert np.abs(a[:, off:off + H * W]).max() > 0.5
-    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
-    assert (b[:, :off] == 0).all() and (b[:, off + H * W:] == 0).all()   # nothing outside the level's slice is touched
+    # (the emulator build instantiates the fp16 persistent kernel for the production = folded-scale forms only, k_conv3.h
+    #  conv3_has_form: the un-folded fused launch is checked on the GPU, and in bf16 everywhere)
+    unfolded = not (BF16 == R.RD_F16 and be.name == "emu")
+    if unfolded:
+        L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wp), be.ptr(dsc), be.ptr(dsh), B, H, W, cin, R.RD_RELU_POST,
+               be.ptr(dhp), be.ptr(dhb), be.ptr(o2), N * nout, off, nout, BF16, be.stream)
+        b = be.down(o2, np.float32, (B, N, nout))
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
+        assert (b[:, :off] == 0).all() and (b[:, off + H * W:] == 0).all()   # nothing outside the level's slice is touched
     ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy() * sc[None, :, None, None] + sh[None, :, None, None]
-    act = bf16_round(np.maximum(ref, 0).astype(np.float32))
+    act = h16_round(np.maximum(ref, 0).astype(np.float32), BF16)
     want = np.einsum('oc,bchw->bhwo', hw, act).reshape(B, H * W, nout) + hb
-    assert np.abs(b[:, off:off + H * W] - want).max() < 2 ** -7 * max(1.0, np.abs(want).max())
+    if unfolded:
+        assert np.abs(b[:, off:off + H * W] - want).max() < 2 * _ulp(BF16) * max(1.0, np.abs(want).max())
     # the production form: scale folded into the 3x3 weights (RD_SCALE_FOLDED), shift through the accumulators
     o3 = be.empty(B * N * nout * 4)
-    wpf = be.up(L.pack_conv3x3_ex(w, 1, cs, fold_scale=sc))
+    wpf = be.up(L.pack_conv3x3_ex(w, 1, cs, fold_scale=sc, dtype=BF16))
     L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wpf), None, be.ptr(dsh), B, H, W, cin,
-           R.RD_RELU_POST | R.RD_SCALE_FOLDED, be.ptr(dhp), be.ptr(dhb), be.ptr(o3), N * nout, off, nout, be.stream)
+           R.RD_RELU_POST | R.RD_SCALE_FOLDED, be.ptr(dhp), be.ptr(dhb), be.ptr(o3), N * nout, off, nout, BF16, be.stream)
     c = be.down(o3, np.float32, (B, N, nout))
-    assert np.abs(c[:, off:off + H * W] - want).max() < 1.5 * 2 ** -7 * max(1.0, np.abs(want).max())
+    assert np.abs(c[:, off:off + H * W] - want).max() < 3 * _ulp(BF16) * max(1.0, np.abs(want).max())
+    assert (c[:, :off] == 0).all() and (c[:, off + H * W:] == 0).all()
     buf = be.ptr(be.empty(1 << 16))
-    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 9, be.stream) == R.RD_ESHAPE
-    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 6, buf, buf, buf, 100, 0, 8, be.stream) == R.RD_EINVAL
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 9, BF16, be.stream) == R.RD_ESHAPE
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 6, buf, buf, buf, 100, 0, 8, BF16, be.stream) == R.RD_EINVAL
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 8, F32, be.stream) == R.RD_EINVAL
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 10, 128, 64, (3, 8), 4, 2), (BF16, 1, 2, 20, 128, 128, (3, 8), 4, 2),
-                                  (F32, 2, 2, 13, 64, 64, (3, 4), 2, 1), (BF16, 1, 3, 24, 128, 64, (3, 4), 2, 1)])
+                                  (F32, 2, 2, 13, 64, 64, (3, 4), 2, 1), (BF16, 1, 3, 24, 128, 64, (3, 4), 2, 1),
+                                  (F16, 1, 2, 20, 128, 128, (3, 8), 4, 2), (F16, 1, 3, 24, 128, 64, (3, 4), 2, 1)])
 def test_deconv2d_bn_act(be, case):
     dt, B, H, W, cin, cout, k, s, pw = case
     rng = np.random.default_rng(1)
@@ -151,8 +169,7 @@ def test_deconv2d_bn_act(be, case):
     sh = rng.standard_normal(cout).astype(np.float32)
     Wout = (W - 1) * s - 2 * pw + k[1]
     res = rng.standard_normal((B, cout, H, Wout)).astype(np.float32)
-    if dt == BF16:
-        x, w, res = bf16_round(x), bf16_round(w), bf16_round(res)
+    x, w, res = h16_round(x, dt), h16_round(w, dt), h16_round(res, dt)
     L = be.lib
     xin, rin = be.up(to_nhwc(x, dt)), be.up(to_nhwc(res, dt))
     y = be.empty(B * H * Wout * cout * 4)
@@ -163,9 +180,9 @@ def test_deconv2d_bn_act(be, case):
                be.ptr(y), cout, 0, B, H, W, cin, cout, k[0], k[1], s, pw, ph, R.RD_RELU_PRE | R.RD_ADD, dt, be.stream)
     ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, s), padding=(1, pw)).numpy()
     ref = np.maximum(ref * sc[None, :, None, None] + sh[None, :, None, None], 0) + res
-    got = from_nhwc(be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, Wout, cout)), dt, cout)
+    got = from_nhwc(be.down(y, np.uint16 if dt in H16 else np.float32, (B, H, Wout, cout)), dt, cout)
     assert np.abs(got - ref).max() <= _tol(dt, ref)
-    if dt == BF16:   # the production form: BatchNorm scale folded into the weights, shift through the accumulators
+    if dt in H16:   # the production form: BatchNorm scale folded into the weights, shift through the accumulators
         y2 = be.empty(B * H * Wout * cout * 4)
         for ph in range(s):
             wp = be.up(L.pack_deconv_weight(w, s, pw, ph, dt, fold_scale=sc))
@@ -176,7 +193,7 @@ def test_deconv2d_bn_act(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-@pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40)])
+@pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40)])
 def test_meta_kernel_unit(be, case):
     """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97."""
     dt, B, H, W = case
@@ -184,8 +201,7 @@ def test_meta_kernel_unit(be, case):
     P = synth.make_weights(seed=18, width=W)
     data = rng.standard_normal((B, 64, H, W)).astype(np.float32)
     coord = rng.standard_normal((B, 3, H, W)).astype(np.float32)
-    if dt == BF16:
-        data = bf16_round(data)
+    data = h16_round(data, dt)
     name = 'res1_unit2'
     ref = G.meta_kernel_unit(G.T(data), G.T(coord), P, name).numpy()
     s1, t1 = bn_affine(P, name + "point_wise_mlp_bn1", G.EPS)
@@ -197,29 +213,29 @@ def test_meta_kernel_unit(be, case):
     x, c, pkd = be.up(to_nhwc(data, dt)), be.up(coord), be.up(pk)
     y = be.empty(B * H * W * 64 * 4)
     L.call("rd_meta_kernel_fwd", be.ptr(x), 64, 0, be.ptr(c), be.ptr(pkd), be.ptr(y), 64, 0, B, H, W, dt, be.stream)
-    got = from_nhwc(be.down(y, np.uint16 if dt == BF16 else np.float32, (B, H, W, 64)), dt, 64)
-    # bf16 error model: the hidden vector, the 576 products and both weight sets are rounded to bf16 (2^-9 relative, rms
+    got = from_nhwc(be.down(y, np.uint16 if dt in H16 else np.float32, (B, H, W, 64)), dt, 64)
+    # fp16: the same model with 2^-12 in place of 2^-9.  bf16 error model: the hidden vector, the 576 products and both weight sets are rounded to bf16 (2^-9 relative, rms
     # 2^-9/sqrt(3) each): four independent roundings per term of the 576-term sum -> relative rms error 2^-9*sqrt(4/3) of the
     # pre-activation spread; the output is rounded once more (2^-9 of its magnitude).  Allow 6 sigma over the 1e5 outputs.
     if dt == F32:
         tol = 1e-4
     else:
-        rel = 2.0 ** -9 * np.sqrt(4.0 / 3.0)
+        u = 2.0 ** -9 if dt == BF16 else 2.0 ** -12
+        rel = u * np.sqrt(4.0 / 3.0)
         err = got - ref
-        print("meta bf16: rms err / std %.5f (model %.5f), max err / std %.4f" % (err.std() / ref.std(), rel, np.abs(err).max() / ref.std()))
+        print("meta 16-bit: rms err / std %.5f (model %.5f), max err / std %.4f" % (err.std() / ref.std(), rel, np.abs(err).max() / ref.std()))
         assert err.std() < 2.0 * rel * ref.std()
-        tol = 6 * 2.0 * rel * float(ref.std()) + 2.0 ** -9 * float(np.abs(ref).max())
+        tol = 6 * 2.0 * rel * float(ref.std()) + u * float(np.abs(ref).max()) + 1e-4
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
 def test_head_out_and_layout(be, dt):
     rng = np.random.default_rng(2)
     B, H, W, C = 2, 3, 37, 128
     x = rng.standard_normal((B, C, H, W)).astype(np.float32)
-    if dt == BF16:
-        x = bf16_round(x)
+    x = h16_round(x, dt)
     L = be.lib
     src = be.up(x)
     xin = be.empty(B * H * W * C * 4)
@@ -229,14 +245,14 @@ def test_head_out_and_layout(be, dt):
     assert np.array_equal(be.down(back, np.float32, (B, C, H, W)), x)
     # few channels into a wider zero-padded buffer (the 8-channel range image next to the 64 agg channels: lower.py concat)
     x8 = x[:, :8].copy()
-    cs, co, pad = 80, 16, 8 if dt == BF16 else 0
-    esz = 2 if dt == BF16 else 4
+    cs, co, pad = 80, 16, 8 if dt in H16 else 0
+    esz = 2 if dt in H16 else 4
     wide = be.up(np.full(B * H * W * cs * esz, 0x5A, np.uint8))
     L.call("rd_nchw_to_nhwc", be.ptr(be.up(x8)), be.ptr(wide), B, 8, H, W, cs, co, pad, dt, be.stream)
-    got = be.down(wide, np.uint16 if dt == BF16 else np.float32, (B, H, W, cs))
+    got = be.down(wide, np.uint16 if dt in H16 else np.float32, (B, H, W, cs))
     ref8 = np.transpose(x8, (0, 2, 3, 1))
-    if dt == BF16:
-        assert np.array_equal(got[..., co:co + 8], (ref8.view(np.uint32) >> 16).astype(np.uint16))
+    if dt in H16:
+        assert np.array_equal(got[..., co:co + 8], to_nhwc(x8, dt))
         assert not got[..., co + 8:co + 16].any() and (got[..., :co] == 0x5A5A).all() and (got[..., co + 16:] == 0x5A5A).all()
     else:
         assert np.array_equal(got[..., co:co + 8], ref8)
@@ -397,12 +413,13 @@ def test_wnms_two_rounds_vs_oracle(be, is3d):
     assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
 
 
-def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0, fold=False):
+def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0, fold=False, dt=R.RD_BF16):
     """rd_conv3x3_bn_act_ex (bf16) vs torch fp32: conv2 of a BasicBlock with stride (1,stride), optional residual, optional fused
     1x1 projection shortcut of a second input (scales folded into both weight sets by the packers)."""
+    if dt == R.RD_F16 and be.name == "emu" and not sc_cin and not fold:
+        pytest.skip("emulator build: fp16 persistent kernel in its production (folded-scale) forms only; this form runs on the GPU tier")
     rng = np.random.default_rng(seed)
-    dt = BF16
-    x = bf16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    x = h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), dt)
     w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
     sc2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     sh2 = rng.standard_normal(cout).astype(np.float32)
@@ -416,34 +433,34 @@ def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_
     res_ptr = (None, 0, 0)
     flags = R.RD_RELU_POST
     if sc_cin:
-        x0 = bf16_round(rng.standard_normal((B, sc_cin, H, W)).astype(np.float32))
+        x0 = h16_round(rng.standard_normal((B, sc_cin, H, W)).astype(np.float32), dt)
         wsc = (rng.standard_normal((cout, sc_cin)) / np.sqrt(sc_cin)).astype(np.float32)
         scs, shs = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
         s_cs = sc_cs or -(-sc_cin // 16) * 16
         ref = ref * sc2[None, :, None, None] + (sh2 + shs)[None, :, None, None]
         ref = ref + (F.conv2d(torch.from_numpy(x0), torch.from_numpy(wsc[:, :, None, None]), stride=(1, stride)).numpy() *
                      scs[None, :, None, None])
-        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2))
-        args_sc = (be.ptr(be.up(to_nhwc(x0, dt, cstride=s_cs))), s_cs, 0, sc_cin, be.ptr(be.up(L.pack_conv1x1_sc(wsc, fold_scale=scs))))
+        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2, dtype=dt))
+        args_sc = (be.ptr(be.up(to_nhwc(x0, dt, cstride=s_cs))), s_cs, 0, sc_cin, be.ptr(be.up(L.pack_conv1x1_sc(wsc, fold_scale=scs, dtype=dt))))
         scale_ptr, shift_ptr = None, be.ptr(be.up(sh2 + shs))
         flags |= R.RD_ADD
     else:
         ref = ref * sc2[None, :, None, None] + sh2[None, :, None, None]
-        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2 if fold else None))
+        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2 if fold else None, dtype=dt))
         scale_ptr, shift_ptr = (None if fold else be.ptr(be.up(sc2))), be.ptr(be.up(sh2))
         if fold:
             flags |= R.RD_SCALE_FOLDED
         if residual:
-            r = bf16_round(rng.standard_normal((B, cout, H, Wo)).astype(np.float32))
+            r = h16_round(rng.standard_normal((B, cout, H, Wo)).astype(np.float32), dt)
             ref = ref + r
             res_ptr = (be.ptr(be.up(to_nhwc(r, dt))), cout, 0)
             flags |= R.RD_ADD
     ref = np.maximum(ref, 0)
     L.call("rd_conv3x3_bn_act_ex", be.ptr(xin), cs, 0, be.ptr(wp), scale_ptr, shift_ptr, *res_ptr, *args_sc, be.ptr(y), cout, 0,
-           B, H, W, cin, cout, stride, flags, be.stream)
+           B, H, W, cin, cout, stride, flags, dt, be.stream)
     got = from_nhwc(be.down(y, np.uint16, (B, H, Wo, cout)), dt, cout)
-    # folded scales re-round the weights (2^-9 relative each, averaging out over the >= 72-term sums) on top of the output
-    # rounding of _tol: 1.5x
+    # folded scales re-round the weights (2^-9 relative each for bf16, 2^-12 for fp16, averaging out over the >= 72-term sums)
+    # on top of the output rounding of _tol: 1.5x
     tol = 1.5 * _tol(dt, ref)
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
 
@@ -471,9 +488,21 @@ def test_conv3x3_ex(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [CONV_EX_CASES[0], CONV_EX_CASES[2], CONV_EX_CASES[3], CONV_EX_CASES[4]], ids=lambda c: "-".join(str(v) for v in c))
+def test_conv3x3_ex_fp16(be, case):
+    run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), dt=F16)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_conv3x3_ex_folded_scale(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv3x3_ex_folded_scale_fp16(be, case):
+    run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True, dt=F16)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -481,9 +510,10 @@ def test_conv3x3_ex_errors(be):
     L = be.lib
     p = be.ptr(be.empty(1 << 16))
     f = L.raw("rd_conv3x3_bn_act_ex")
-    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 64, 0, 1, 2, 33, 64, 64, 2, 4, be.stream) == R.RD_ESHAPE   # odd width
-    assert f(p, 64, 0, p, p, p, p, 64, 0, p, 64, 0, 64, p, p, 64, 0, 1, 2, 32, 64, 64, 1, 6, be.stream) == R.RD_EINVAL        # both
-    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 96, 0, 1, 2, 32, 64, 96, 1, 4, be.stream) == R.RD_ESHAPE   # cout
+    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 64, 0, 1, 2, 33, 64, 64, 2, 4, BF16, be.stream) == R.RD_ESHAPE   # odd width
+    assert f(p, 64, 0, p, p, p, p, 64, 0, p, 64, 0, 64, p, p, 64, 0, 1, 2, 32, 64, 64, 1, 6, BF16, be.stream) == R.RD_EINVAL        # both
+    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 96, 0, 1, 2, 32, 64, 96, 1, 4, BF16, be.stream) == R.RD_ESHAPE   # cout
+    assert f(p, 64, 0, p, p, p, None, 0, 0, None, 0, 0, 0, None, p, 64, 0, 1, 2, 32, 64, 64, 1, 4, F32, be.stream) == R.RD_EINVAL   # dtype
 
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")

@@ -16,16 +16,17 @@ L = R.get_lib()
 H = 64
 B = int(os.environ.get("B", "8"))
 st = torch.cuda.current_stream().cuda_stream
+DT = R.RD_F16 if os.environ.get("F16") else R.RD_BF16
 tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("RD_CONV_HB3", "RD_CONV3_DBG") if k in os.environ)
 for W in [int(v) for v in os.environ.get("WS", "2656,1328").split(",")]:
     for cin, cout in ((64, 64), (128, 128)) if os.environ.get("C128") else ((64, 64),):
         # several distinct buffers cycled so that no launch finds its input in the Infinity Cache by accident of the benchmark
         NB = 3
-        xs = [torch.randn(B * H * W * cin, device="cuda").to(torch.bfloat16) for _ in range(NB)]
-        ys = [torch.empty(B * H * W * cout, device="cuda", dtype=torch.bfloat16) for _ in range(NB)]
-        rs = [torch.randn(B * H * W * cout, device="cuda").to(torch.bfloat16) for _ in range(NB)]
+        xs = [torch.randn(B * H * W * cin, device="cuda").to(torch.float16 if DT == R.RD_F16 else torch.bfloat16) for _ in range(NB)]
+        ys = [torch.empty(B * H * W * cout, device="cuda", dtype=torch.float16 if DT == R.RD_F16 else torch.bfloat16) for _ in range(NB)]
+        rs = [torch.randn(B * H * W * cout, device="cuda").to(torch.float16 if DT == R.RD_F16 else torch.bfloat16) for _ in range(NB)]
         w = torch.from_numpy(L.pack_conv3x3_ex(np.random.randn(cout, cin, 3, 3).astype(np.float32) * 0.05, 1, cin,
-                                               fold_scale=np.ones(cout, np.float32))).cuda()
+                                               fold_scale=np.ones(cout, np.float32), dtype=DT)).cuda()
         sh = torch.zeros(cout, device="cuda")
         for res in (False, True):
             fl = R.RD_RELU_POST | R.RD_SCALE_FOLDED | (R.RD_ADD if res else 0)
@@ -33,7 +34,7 @@ for W in [int(v) for v in os.environ.get("WS", "2656,1328").split(",")]:
             def run(i):
                 L.call("rd_conv3x3_bn_act_ex", xs[i % NB].data_ptr(), cin, 0, w.data_ptr(), None, sh.data_ptr(),
                        rs[i % NB].data_ptr() if res else None, cout if res else 0, 0, None, 0, 0, 0, None,
-                       ys[i % NB].data_ptr(), cout, 0, B, H, W, cin, cout, 1, fl, st)
+                       ys[i % NB].data_ptr(), cout, 0, B, H, W, cin, cout, 1, fl, DT, st)
             for i in range(3):
                 run(i)
             torch.cuda.synchronize()

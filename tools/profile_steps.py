@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from rangedet_amd import lib as rdlib, synth  # noqa: E402
 from rangedet_amd.pipeline import RangeDetPipeline  # noqa: E402
 
-dt = rdlib.RD_F32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else rdlib.RD_BF16
+dt = {"f32": rdlib.RD_F32, "f16": rdlib.RD_F16}.get(sys.argv[1] if len(sys.argv) > 1 else "bf16", rdlib.RD_BF16)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pipe = RangeDetPipeline(synth.make_weights(seed=18), dtype=dt, batch=B)
@@ -49,7 +49,7 @@ for i, st in enumerate(pipe.plan.steps):
     # report: 8 x 30 tiles with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
     # a stride-2 conv runs on the pixel-pair view = its output grid, a transposed conv phase on its input grid)
     tps = ""
-    if dt == rdlib.RD_BF16 and k in ("conv", "deconv") and st["k"][0] == 3:
+    if dt in rdlib.H16 and k in ("conv", "deconv") and st["k"][0] == 3:
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         Wt = st["x"].W if k == "deconv" else st["out"].W
         wide_head = bool(st.get("head")) and Wt > 1400
