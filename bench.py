@@ -118,25 +118,29 @@ def backbone_forward_roofline(pipe, frame, Bf, esz, reps=2):
 
 
 def measured_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if d.get("batch") == batch:
-            return d[kernel_key]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json, tools/profile_round.sh)
+    that was taken on THESE kernel sources (csrc_sha16 == rangedet_amd.build.source_hash()) at this batch size; else None -- a
+    figure measured on other kernels is not quoted."""
+    import glob
+    from rangedet_amd.build import source_hash
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("batch") == batch and d.get("csrc_sha16") == source_hash():
+                return d[kernel_key]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
-def cpu_baseline(params, frames, budget_s=20.0):
+def cpu_baseline(params, frames, budget_s=30.0):
     """The oracle (PyTorch-CPU fp32 restatement + C++ decode/wnms) timed on this box's host cores: reported, not a target.
     Whole frames of the same workload until ~budget_s of CPU work is spent (at least 2 frames; the first one also pays
     torch's one-time thread-pool / allocator warm-up and is reported separately)."""
     import torch
     from oracle import graph_ref
     times = []
-    while len(times) < 2 or (sum(times) < budget_s and len(times) < len(frames)):
+    while len(times) < 2 or (sum(times) < budget_s and len(times) < len(frames) + 1):
         frame = frames[len(times) % len(frames)]
         t0 = time.time()
         out = graph_ref.forward(frame, params)
@@ -381,7 +385,8 @@ def main(argv=None):
                 "frac": achieved / (PEAK_BF16_TFLOPS if bf else 157.3),
                 "traffic": measured_traffic("conv3x3_stream_kernel", Bf) if bf else None,
                 "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes of "
-                                "this command (profiles/r02_pmc_traffic.json, tools/profile_round.sh)",
+                                "this command (newest profiles/r*_pmc_traffic.json whose csrc_sha16 equals the running sources' "
+                                "hash, tools/profile_round.sh; null when the kernels changed since the last PMC pass)",
                 "algorithmic_bytes_per_launch": conv_bytes(pipe.plan, 2 if bf else 4, only_conv3=bf) * Bf / nlaunch,
                 "launches_per_step": nlaunch, "avg_launch_ms": avg_ms, "gflop_per_launch": fl * Bf / nlaunch / 1e9,
                 "share_of_conv_flops": fl / fl_all,

@@ -10,6 +10,17 @@ OUT = os.path.join(HERE, "librangedet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: what a measured profile was taken on (profiles/*pmc_traffic.json
+    carry it, bench.py only quotes a measured HBM traffic figure whose hash matches the sources it runs)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(OUT):
         return True

@@ -164,17 +164,37 @@ class GetFixedLengthGTBbox(DetectionAugmentation):
 
 class Bbox3dAssigner(DetectionAugmentation):
     """rangedet/core/input.py:276-320 on the GPU (processing_cxx.assign3D_v2 -> rd_assign3d_v2): the index of the ground-truth
-    box every point lies in.  Needs the LoadRecord mask semantics, which this stage derives from the raw range image."""
+    box every point lies in.  The reference reads `pc_vehicle_frame` and `range_image_mask` AS THE EARLIER STAGES LEFT THEM: after
+    LoadRecord (mask = range > 0, masked points zeroed, :40-42) and, in the training chain where this stage runs
+    (config:345-366), after ProcessMissValue -- missing returns take their right neighbour's point and mask, what is still
+    missing becomes a zero point (:105-137).  The image stages of this package only record themselves, so this stage applies
+    exactly those two state changes (a few numpy index operations) to its own copies when the chain recorded ProcessMissValue."""
 
     def __init__(self, param=None):
         self.height, self.width = param.feat_size[0], param.feat_size[1]
 
+    @staticmethod
+    def _state_after_earlier_stages(input_record):
+        ri = np.asarray(input_record['range_image'], np.float32)
+        pc = np.asarray(input_record['pc_vehicle_frame'], np.float32).copy()
+        mask = ri[..., 0] > 0                                            # LoadRecord, input.py:40-42
+        pc[~mask] = 0
+        if any(name == "ProcessMissValue" for name, _ in input_record.get(_CHAIN, [])):
+            W = ri.shape[1]
+            miss = ri[:, :, 0] == -1                                     # input.py:112
+            nb = list(range(1, W)) + [0]                                 # fill_noise: the right neighbour, wrapping (:99-103)
+            r0 = ri[:, :, 0].copy()
+            r0[miss] = ri[:, nb, 0][miss]
+            pc[miss] = pc[:, nb][miss]
+            mask = mask.copy()
+            mask[miss] = mask[:, nb][miss]
+            pc[r0 == -1] = 0                                             # still missing (far fill or car window): zero point (:128-135)
+        return pc, mask.astype(np.float32)
+
     def apply(self, input_record):
         from .. import processing_cxx
         gt = np.asarray(input_record['gt_bbox_imu'], np.float32)
-        pc = np.asarray(input_record['pc_vehicle_frame'], np.float32).copy()
-        mask = (np.asarray(input_record['range_image'])[..., 0] > 0).astype(np.float32)
-        pc[mask == 0] = 0
+        pc, mask = self._state_after_earlier_stages(input_record)
         lim = [float(f(gt[:, :, a])) for a in range(3) for f in (np.max, np.min)]
         inds = processing_cxx.assign3D_v2(pc.reshape(-1, 3), gt.reshape(-1, 24), gt.mean(axis=1).reshape(-1, 3),
                                           np.full((len(gt), 1), 100, np.float32), mask.reshape(-1, 1),

@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256) void batch_riou_kernel(const float* __restrict
     gb[4 * j + 1] = fmaxf(fmaxf(q[0], q[2]), fmaxf(q[4], q[6]));
     gb[4 * j + 2] = fminf(fminf(q[1], q[3]), fminf(q[5], q[7]));
     gb[4 * j + 3] = fmaxf(fmaxf(q[1], q[3]), fmaxf(q[5], q[7]));
+    // fminf / fmaxf drop NaN operands: a box with ANY NaN coordinate gets bounds that are never "apart" (so the full routine runs
+    // for it, as the reference does for every pair)
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) nan |= !(q[c] == q[c]);
+    if (nan) { gb[4 * j + 0] = -INFINITY; gb[4 * j + 1] = INFINITY; gb[4 * j + 2] = -INFINITY; gb[4 * j + 3] = INFINITY; }
   }
   __syncthreads();
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -125,7 +131,9 @@ __global__ __launch_bounds__(256) void batch_riou_kernel(const float* __restrict
   for (int k = 0; k < 8; ++k) box[k] = p[k];
   const float lx = fminf(fminf(box[0], box[2]), fminf(box[4], box[6])), hx = fmaxf(fmaxf(box[0], box[2]), fmaxf(box[4], box[6]));
   const float ly = fminf(fminf(box[1], box[3]), fminf(box[5], box[7])), hy = fmaxf(fmaxf(box[1], box[3]), fmaxf(box[5], box[7]));
-  const bool finite = (lx == lx) && (hx == hx) && (ly == ly) && (hy == hy);   // a NaN coordinate: no shortcut, run the routine
+  bool finite = true;                            // ANY NaN coordinate (fminf / fmaxf would drop it): no shortcut, run the routine
+#pragma unroll
+  for (int k = 0; k < 8; ++k) finite &= box[k] == box[k];
   float best = -1.f;
   int arg = 0;
   for (int j = 0; j < ngt; ++j) {

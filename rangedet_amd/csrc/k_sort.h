@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256) void select_thresh_kernel(const unsigned* __re
     __syncthreads();
   }
   unsigned before = part[tid] - sum;                               // keys in the bins of earlier threads
+  // fallback when no bin reaches k (k > number of keys, or k == 0 -- both rejected by the callers): every key is a candidate, so
+  // the later passes never read an uninitialised threshold
+  if (tid == 255 && (k == 0 || part[255] < (unsigned)k)) { sel[0] = SEL_BINS - 1; sel[1] = part[255]; }
   if (before < (unsigned)k && before + sum >= (unsigned)k) {       // exactly one thread: the threshold bin is one of its 16
 #pragma unroll
     for (int j = 0; j < SEL_BINS / 256; ++j) {
@@ -335,6 +338,7 @@ inline int radix_sort_pairs(const SortWs& s, long N, hipStream_t st, int nb = 1,
 inline int radix_topk_pairs(const SortWs& s, long N, long k, hipStream_t st, int nb, long ws_stride, unsigned** rk, unsigned** ri) {
   const bool off = dev_switches().sort_no_select;      // dev switch
   *rk = s.keysA; *ri = s.idxA;
+  RD_REQUIRE(k > 0 && k <= N, RD_ESHAPE, "top-k: k %ld of N %ld", k, N);
   if (off || 2 * k > N) return radix_sort_pairs(s, N, st, nb, ws_stride);
   { int rc = sort_clear(s, st, nb, ws_stride, true); if (rc != RD_OK) return rc; }
   hipLaunchKernelGGL(select_hist_kernel, dim3(s.nblk, nb), dim3(256), 0, st, s.keysA, N, s.h12, ws_stride);

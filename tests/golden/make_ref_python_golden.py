@@ -183,6 +183,37 @@ def main():
                                                   hashlib.sha256(np.ascontiguousarray(r[k], dtype=np.float32).tobytes()).hexdigest()]
                                              for k in KEYS}
         json.dump(digests, open(os.path.join(HERE, "input_chain_fullsize_sha256.json"), "w"), indent=1)
+    # (a') what the reference's Bbox3dAssigner (training chain, rangedet/core/input.py:276-320) hands to assign3D_v2 after
+    # LoadRecord + ProcessMissValue: the point array and the mask, captured through a recording stand-in for the compiled call
+    RI = sys.modules["rangedet.core.input"]
+    captured = {}
+
+    def capture_assign3d(pc, bbox, center, radius, mask, nlz, *lim):
+        captured.update(pc=np.array(pc, np.float32), mask=np.array(mask, np.float32), nbox=len(bbox), lim=[float(v) for v in lim])
+        return np.full((pc.shape[0],), -1.0, np.float32)
+    sys.modules["processing_cxx"].assign3D_v2 = capture_assign3d
+    with tempfile.TemporaryDirectory() as td:
+        from rangedet_amd import synth
+        rec = synth.raw_record(1)
+        path = os.path.join(td, "rec.npz")
+        np.savez(path, **rec)
+        gt = synth.gt_boxes(3, seed=7) if hasattr(synth, "gt_boxes") else None
+        if gt is None:
+            rng = np.random.default_rng(7)
+            c = rng.uniform(-30, 30, (3, 1, 3)).astype(np.float32)
+            gt = c + rng.uniform(-2, 2, (3, 8, 3)).astype(np.float32)
+        r = dict(pc_url=path, gt_class=np.ones(3), gt_bbox_imu=gt, gt_bbox_csa=np.zeros((3, 7)), gt_bbox_yaw=np.zeros(3),
+                 points_in_box=np.zeros(3), meta_data=np.zeros((3, 4)))
+        for t in (RI.LoadRecord(), RI.LoadGTInfo(), RI.FilterGTClass([1]), RI.ProcessMissValue(),
+                  RI.Bbox3dAssigner(type("P", (), dict(feat_size=(64, 2650))))):
+            t.apply(r)
+    json.dump({"record": "synth.raw_record(1)", "gt_seed": 7, "nbox": captured["nbox"], "lim": captured["lim"],
+               "pc_sha256": hashlib.sha256(captured["pc"].tobytes()).hexdigest(), "pc_shape": list(captured["pc"].shape),
+               "mask_sha256": hashlib.sha256(captured["mask"].tobytes()).hexdigest(), "mask_shape": list(captured["mask"].shape),
+               "mask_sum": float(captured["mask"].sum())},
+              open(os.path.join(HERE, "assigner_state_sha256.json"), "w"), indent=1)
+    np.save(os.path.join(HERE, "assigner_gt.npy"), gt)
+    print("assigner_state: pc %s mask sum %d" % (captured["pc"].shape, captured["mask"].sum()))
     # (b) the test symbol the reference's builders recorded
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from graph_json import graph_to_json

@@ -375,17 +375,20 @@ def test_full_size_f32_parity_vs_oracle(be):
 # re-inject un-rounded signal (lower), ReLU clipping correlates errors (higher): the test allows 2.5x the model for the rms
 # and 6 rms (Gaussian tail over 6e5 samples, x safety) for the maximum.
 BF16_REL_RMS = 2.0 ** -9 * np.sqrt(2 * 53 / 3.0)
+F16_REL_RMS = 2.0 ** -12 * np.sqrt(2 * 53 / 3.0)    # fp16: the same model with its rounding unit (0.15 %)
 
 
 @pytest.mark.slow
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
-def test_full_size_bf16_vs_f32_oracle(be):
+@pytest.mark.parametrize("dt", [R.RD_BF16, R.RD_F16], ids=["bf16", "f16"])
+def test_full_size_bf16_vs_f32_oracle(be, dt):
     """The throughput mode (bf16 persistent kernels, fused Meta-Kernel, fused tower outputs) at the production shape against
     the SAME fp32 oracle output, with a tolerance derived from bf16 rounding depth (see BF16_REL_RMS) instead of a smoke
     threshold: rms and max error of logits / deltas relative to their spread, and the agreement of the final detections."""
     from rangedet_amd.pipeline import RangeDetPipeline
     P, fr, ref = _full_size_oracle()
-    pipe = RangeDetPipeline(P, dtype=R.RD_BF16, batch=2, wnms_cap=8192, lib=be.lib, alloc=be.alloc)
+    BF16_REL_RMS = globals()["BF16_REL_RMS"] if dt == R.RD_BF16 else F16_REL_RMS     # (the body reads "BF16_REL_RMS")
+    pipe = RangeDetPipeline(P, dtype=dt, batch=2, wnms_cap=8192, lib=be.lib, alloc=be.alloc)
     res = pipe.run(fr)
     sfg = [s for s in pipe.plan.steps if s["kind"] == "sorted_fg"][0]
     logit, delta = pipe.exe.read_flat(sfg["score"]), pipe.exe.read_flat(sfg["delta"])
@@ -395,7 +398,7 @@ def test_full_size_bf16_vs_f32_oracle(be):
         spread = want.std(axis=axes)                  # per regression channel for the deltas
         rms = np.sqrt((err ** 2).mean(axis=axes)) / spread
         mx = np.abs(err).max(axis=axes) / spread
-        print("full size bf16 vs fp32 oracle, %s: rms/std %s  max/std %s  (model rms %.4f)" %
+        print("full size " + ("bf16" if dt == R.RD_BF16 else "fp16") + " vs fp32 oracle, %s: rms/std %s  max/std %s  (model rms %.4f)" %
               (name, np.round(rms, 4), np.round(mx, 4), BF16_REL_RMS))
         assert np.all(rms < 2.5 * BF16_REL_RMS) and np.all(mx < 6 * 2.5 * BF16_REL_RMS)
     sc = np.array(be.alloc.to_numpy(res["fg_cls_score"]))

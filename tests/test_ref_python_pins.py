@@ -118,3 +118,23 @@ def test_device_box_formats_equal_reference_python(be):
     L.call("rd_dets12_to_8", be.ptr(be.up(g["b12"])), K, None, be.ptr(o8), be.stream)
     d8 = be.down(o8, np.float32, (K, 8))
     assert np.allclose(d8, g["b8"], rtol=3e-7, atol=1e-6)
+
+
+def test_assigner_sees_the_state_the_reference_chain_leaves():
+    """Bbox3dAssigner after LoadRecord + ProcessMissValue: the point array and mask this package hands to assign3D_v2 are, bit
+    for bit, the ones the reference's own stages produce (captured from the reference chain, full-size record)."""
+    from rangedet_amd import synth
+    from rangedet_amd.core import input as CI
+    d = json.load(open(os.path.join(GOLD, "assigner_state_sha256.json")))
+    rec = dict(synth.raw_record(1))
+    CI.LoadRecord().apply(rec)
+    CI.ProcessMissValue().apply(rec)
+    pc, mask = CI.Bbox3dAssigner._state_after_earlier_stages(rec)
+    assert list(pc.reshape(-1, 3).shape) == d["pc_shape"] and float(mask.sum()) == d["mask_sum"]
+    assert hashlib.sha256(np.ascontiguousarray(pc.reshape(-1, 3), np.float32).tobytes()).hexdigest() == d["pc_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(mask.reshape(-1, 1), np.float32).tobytes()).hexdigest() == d["mask_sha256"]
+    # without ProcessMissValue in the chain (LoadRecord state only) the arrays differ: the fill is what the pin is about
+    rec2 = dict(synth.raw_record(1))
+    CI.LoadRecord().apply(rec2)
+    pc2, mask2 = CI.Bbox3dAssigner._state_after_earlier_stages(rec2)
+    assert mask2.sum() < mask.sum()

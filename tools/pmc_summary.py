@@ -11,7 +11,7 @@ from collections import defaultdict
 
 KERNELS = {"conv3x3_stream_kernel": "conv3x3_stream_kernel", "conv1x1_stream_kernel": "conv1x1_stream_kernel",
            "conv_taps_kernel": "conv_taps_kernel", "input_transform_kernel": "input_transform_kernel",
-           "meta_bf16_kernel": "meta_kernel", "head_out_mfma_kernel": "head_out_mfma_kernel"}
+           "meta16_kernel": "meta_kernel", "meta_bf16_kernel": "meta_kernel", "head_out_mfma_kernel": "head_out_mfma_kernel"}
 batch = int(sys.argv[1])
 acc = defaultdict(lambda: defaultdict(list))
 for d in sys.argv[2:]:
@@ -27,7 +27,9 @@ for d in sys.argv[2:]:
             for pref, out in KERNELS.items():
                 if pref in kn:
                     acc[out][cname].append(v)
-res = {"command": "rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -- python bench.py --steps 3 --warmup 1 "
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rangedet_amd.build import source_hash  # noqa: E402
+res = {"csrc_sha16": source_hash(), "command": "rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -- python bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline  (one pass per counter group)", "batch": batch,
        "note": "per-dispatch means; FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 "
                "FETCH correction, MI355X_MICROARCH.md HBM section)"}
