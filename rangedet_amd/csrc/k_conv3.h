@@ -413,13 +413,18 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   for (int k = 0; k < ntl; ++k) {
     {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
       if constexpr (FOLD) {
-        const unsigned one2 = hi ? 0u : H16<DT>::ONE * 0x10001u;   // B: k = 0, 1 -> 1.0, the rest 0
-        unsigned ob[4] = {one2, 0u, 0u, 0u};
+        // (the zero words go through an opaque copy once per tile: as compile-time zeros the five operand tuples are loop
+        //  invariant, hipcc keeps all 20 registers live across the MFMA phase, spills them, and reloads them here from scratch --
+        //  a vector-memory load whose s_waitcnt vmcnt(0) drains the whole DMA queue at every tile start)
+        unsigned z0 = 0u;
+        asm volatile("" : "+v"(z0));
+        const unsigned one2 = hi ? z0 : H16<DT>::ONE * 0x10001u;   // B: k = 0, 1 -> 1.0, the rest 0
+        unsigned ob[4] = {one2, z0, z0, z0};
         s16x8 ones;
         memcpy(&ones, ob, 16);
 #pragma unroll
         for (int n = 0; n < NM; ++n) {
-          unsigned ab[4] = {bzw[n % NCT], 0u, 0u, 0u};
+          unsigned ab[4] = {bzw[n % NCT], z0, z0, z0};
           s16x8 bz;
           memcpy(&bz, ab, 16);
           acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
