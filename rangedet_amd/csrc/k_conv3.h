@@ -260,19 +260,37 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   int hh0 = 0, hlo = 0, hlim = 0;                         // first halo row; valid halo columns are hlo <= cc < hlim
   const unsigned char* hbase = nullptr;                   // uniform: halo pixel (0, 0), channel slot 4*hc
   bool hsok = false;
-  auto halo_begin = [&]() {                               // decode the unit to fetch, advance the cursor
-    const int t = wg + hk * G;
-    const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
-    const int hw0 = ct * C3_TW - 1;
-    hh0 = rb * C3_TH - 1;
+  // Tile t = wg + k*G of the list -> (column tile, row block, image).  Decoded ONCE for the workgroup's first tile; every later
+  // tile is the previous one plus G in mixed radix (ncol, nrow) -- a few scalar adds and selects instead of the three software
+  // integer divisions (~60 dependent scalar instructions in front of a wave's MFMAs, once per unit) a decode from t costs.
+  const int g_ct = G % a.ncol, g_rb = (G / a.ncol) % a.nrow, g_b = G / tiles_img;
+  auto tile_advance = [&](int& ct, int& rb, int& b) {
+    ct += g_ct;
+    const int c1 = ct >= a.ncol ? 1 : 0;
+    ct -= c1 ? a.ncol : 0;
+    rb += g_rb + c1;
+    const int c2 = rb >= a.nrow ? 1 : 0;
+    rb -= c2 ? a.nrow : 0;
+    b += g_b + c2;
+  };
+  int f_ct = wg % a.ncol, f_rb = (wg / a.ncol) % a.nrow, f_b = wg / tiles_img;   // tile of the NEXT halo to fetch
+  int c_ct = f_ct, c_rb = f_rb, c_b = f_b;                                        // tile being computed
+  const unsigned char* htile = nullptr;                   // uniform: halo pixel (0, 0) of the fetch tile, channel 0
+  auto halo_tile = [&]() {                                // per fetch TILE: geometry and base address
+    const int hw0 = f_ct * C3_TW - 1;
+    hh0 = f_rb * C3_TH - 1;
     hlo = hw0 < 0 ? -hw0 : 0;
     hlim = a.W - hw0;
-    hbase = (const unsigned char*)(a.x + (size_t)b * a.x_bs + a.x_co + hc * 32) +
-            ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
+    htile = (const unsigned char*)(a.x + (size_t)f_b * a.x_bs + a.x_co) + ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
+  };
+  bool hnew = true;                                       // the fetch cursor moved to a new tile: geometry not yet derived
+  auto halo_begin = [&]() {                               // per fetch UNIT: the chunk's slice of the tile; advance the cursor
+    if (hnew) { halo_tile(); hnew = false; }              // (the pieces of this unit are issued AFTER this call and use the geometry)
+    hbase = htile + hc * 64;
     hsok = hc * 4 + hs < a.nslots;
     // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
     if (hc + 1 < a.nchunk) ++hc;
-    else if (hk + 1 < ntl) { ++hk; hc = 0; }
+    else if (hk + 1 < ntl) { ++hk; hc = 0; tile_advance(f_ct, f_rb, f_b); hnew = true; }
   };
   auto halo_piece = [&](int buf, int j) {
     const int q = wave * C3_HPW + j, r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
@@ -451,8 +469,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     // Lane (m, hi) of accumulator (i, j) holds channels 32*j + 16*hi + r (r = 0..15) of pixel 32*i + m of its row.
     // Scratch: this wave's 8 KB of the halo buffer that is free until the next unit's tap-0 barrier
     // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
-    const int t = wg + k * G;
-    const int ct = t % a.ncol, rb = (t / a.ncol) % a.nrow, b = t / tiles_img;
+    const int ct = c_ct, rb = c_rb, b = c_b;
+    tile_advance(c_ct, c_rb, c_b);                                   // (for the next iteration)
     const int oh0 = rb * C3_TH + RW * wave;                          // fragment i: output row oh0 + i / FC, columns 32*(i % FC) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
     // and kept (spilled) across the whole MFMA phase
@@ -803,11 +821,11 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   // (tile shape, cout) -> instantiation; within it (tap set, shortcut).  All of these carry folded scales.
 #define C3_BODY(N, FPW_, FC_, NHB_)                                                                       \
   {                                                                                                       \
-    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a)                 \
-                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a);                \
-    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                        \
-         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                        \
-                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a);                       \
+    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a)             \
+                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a);            \
+    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                    \
+         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                    \
+                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a);                   \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
   if (w30) {
