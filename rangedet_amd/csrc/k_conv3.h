@@ -297,7 +297,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     const int cc = c16 + l4;
     const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
     const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
-    dma_v(ok ? (const void*)(sp + hlane) : (const void*)a.zero16, buf + q * 1024);   // (buf = byte offset of the halo buffer)
+    const unsigned char* src = sp + hlane;
+    if constexpr ((DBG & 256) != 0)   // ablation: the same lanes' data from the first MB of x (L2-resident REAL data: MFMA power as in production, no HBM reads)
+      src = (const unsigned char*)a.x + ((size_t)(src - (const unsigned char*)a.x) & 0xFFFF0);
+    dma_v(ok ? (const void*)src : (const void*)a.zero16, buf + q * 1024);   // (buf = byte offset of the halo buffer)
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
   const int nslab_tile = a.nchunk * NS;
@@ -787,7 +790,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   C3_DBG_CASE(2) C3_DBG_CASE(4) C3_DBG_CASE(16) C3_DBG_CASE(32)
 #undef C3_DBG_CASE
   // cout 64 on the 8 x 30 tiles (plain 3x3, folded scales): 16 halo from the zero page, 64 residual from one L2-resident pixel,
-  // 128 no residual load, 4 no DMA after the prologue, 8 no MFMAs
+  // 128 no residual load, 4 no DMA after the prologue, 8 no MFMAs, 256 halo from the first MB of x (L2-resident REAL data), 1 no stores
 #define C3_DBG64(D)                                                                                                     \
   if (cout == 64 && w30 && !sc && ts == 0 && dbg == D) {                                                                \
     if (hb3) { auto k = conv3x3_stream_kernel<2, D, 0, false, false, true, 2, 1, 3>; allow_big_lds(k);                  \
@@ -796,7 +799,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
            hipLaunchKernelGGL(k, dim3(grid), dim3(256), (C3Cfg<2, 2, 1, 2>::LDS), st, a); }                             \
     return check_launch("conv3x3_stream_kernel<dbg>");                                                                  \
   }
-  C3_DBG64(4) C3_DBG64(8) C3_DBG64(16) C3_DBG64(64) C3_DBG64(128)
+  C3_DBG64(4) C3_DBG64(8) C3_DBG64(16) C3_DBG64(64) C3_DBG64(128) C3_DBG64(256) C3_DBG64(257)
 #undef C3_DBG64
 #define C3_DBG128(D)                                                                                                    \
   if (cout == 128 && w30 && !sc && !headfuse && ts == 0 && dbg == D) {                                                  \
@@ -804,7 +807,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), (C3Cfg<4, 2, 1, 2>::LDS), st, a);                                      \
     return check_launch("conv3x3_stream_kernel<dbg>");                                                                  \
   }
-  C3_DBG128(4) C3_DBG128(8) C3_DBG128(16) C3_DBG128(2) C3_DBG128(32)
+  C3_DBG128(4) C3_DBG128(8) C3_DBG128(16) C3_DBG128(2) C3_DBG128(32) C3_DBG128(256) C3_DBG128(257)
 #undef C3_DBG128
 #endif
 #ifdef HIPEMU
