@@ -66,20 +66,28 @@ constexpr int C3_ROWB = 64 * 64;           // bytes of one halo row, FC 2
 // only -- the HBM-bound layers): the fetch runs TWO units ahead, so a piece has a whole unit (>= 9 steps) to arrive instead of
 // the 3 - 8 steps between its issue and the barrier of ordinal NS-2, and twice as many bytes are in flight per CU; the third
 // 20-KB buffer is paid for with a 5-deep instead of 8-deep weight ring and the (FOLD-unused) scale / shift array.
-template <int NCT, int FPW = 4, int FC = 2, int NHB = 2> struct C3Cfg {
+// WD (round 3): the 8-row tile with ALL 32 columns of its one fragment per row live -- 8 x 32 outputs from a halo image of 10 rows
+// x 34 pixels (row pitch 34 pixels = 2 176 B instead of 32).  On the 8 x 30 tile two of every 32 MFMA columns compute pixels that
+// are thrown away (6.25 % of every conv's MFMAs, and the convs are MFMA / power bound); 2656 = 83 x 32 exactly.
+// The halo's 340 pixels are 21.25 one-KB pieces: 6 per wave (the last ones fetch the zero page), LDS = 2 x 24 KB + ring = 80 KB
+// exactly (no scale / shift array: FOLD only; cout 64 goes back to two halo buffers and its 8-deep ring).
+template <int NCT, int FPW = 4, int FC = 2, int NHB = 2, bool WD = false> struct C3Cfg {
+  static_assert(!WD || (FPW == 2 && FC == 1 && NHB == 2), "wide tile: 8 x 32, two halo buffers");
   static constexpr int RW = FPW / FC;                    // output rows per wave
   static constexpr int TH = 4 * RW;                      // output rows per tile (8 or 4)
-  static constexpr int COLS = 32 * FC;                   // halo columns
-  static constexpr int TW = COLS - 2;                    // output columns per tile
+  static constexpr int COLS = WD ? 34 : 32 * FC;         // halo columns (= row pitch of the halo image in pixels)
+  static constexpr int TW = WD ? 32 : COLS - 2;          // output columns per tile
   static constexpr int ROWB = COLS * 64;                 // bytes of one halo row
   static constexpr int HROWS = TH + 2;                   // halo rows
-  static constexpr int HALO = HROWS * ROWB;              // bytes of one halo image
-  static constexpr int HPW = HALO / 4096;                // 1-KB halo pieces per wave and unit
+  static constexpr int NPX = HROWS * COLS;               // pixels of one halo image
+  static constexpr int HPW = WD ? (NPX + 63) / 64 : HROWS * ROWB / 4096;   // 1-KB halo pieces (16 pixels) per wave and unit
+  static constexpr int HALO = HPW * 4096;                // bytes of one halo buffer (WD: incl. the padding pieces)
+  static constexpr int HPC = WD ? 7 : HPW;               // schedule code of c3_halo_pieces
   static_assert(NHB == 2 || (NHB == 3 && FPW == 2 && FC == 1 && NCT == 2), "three halo buffers: cout 64 on 8 x 30 tiles");
   static constexpr int R = NHB == 3 ? 5 : FPW == 4 ? (NCT == 4 ? 7 : 10) : FC == 1 ? (NCT == 4 ? 4 : 8) : (NCT == 4 ? 3 : 6);   // ring depth (slabs)
   static constexpr int IPW = NCT / 2;                    // slab DMA instructions per wave per step
   static constexpr int SLAB = NCT * 2048;
-  static constexpr size_t LDS = (size_t)NHB * HALO + (size_t)R * SLAB + (NHB == 3 ? 0 : 2 * NCT * 32 * sizeof(float));
+  static constexpr size_t LDS = (size_t)NHB * HALO + (size_t)R * SLAB + (NHB == 3 || WD ? 0 : 2 * NCT * 32 * sizeof(float));
 };
 constexpr int C3_TH = C3Cfg<4, 4>::TH;     // (the FPW 4 geometry, for code that sizes things before choosing a variant)
 constexpr int C3_HALO = C3Cfg<4, 4>::HALO;
@@ -146,9 +154,11 @@ constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw
 // (ordinal NS-2).
 // (HP = 6, the 4-row tile: 2 each at ordinals 0..2 of a 9-step unit, 3 each at ordinals 0..1 of a 6-step unit;
 //  HP = 5, the 8 x 30 tile: 1 each at ordinals 0..4 of a 9-step unit; 2, 2, 1 at ordinals 0..2 of a 6-step unit.)
-constexpr int c3_halo_last(int NS, int HP) { return HP == 6 ? (NS == 9 ? 2 : 1) : (NS == 9 ? 4 : 2); }
+// (HP = 7 is the code of the wide 8 x 32 tile: 6 pieces, 2, 1, 1, 1, 1 at ordinals 0..4 of a 9-step unit; 2 each at 0..2 of a 6-step unit.)
+constexpr int c3_halo_last(int NS, int HP) { return HP == 7 ? (NS == 9 ? 4 : 2) : HP == 6 ? (NS == 9 ? 2 : 1) : (NS == 9 ? 4 : 2); }
 constexpr int c3_halo_pieces(int s, int NS, int HP) {
-  return HP == 10 ? (NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)))
+  return HP == 7 ? (NS == 9 ? (s == 0 ? 2 : s <= 4 ? 1 : 0) : (s <= 2 ? 2 : 0))
+       : HP == 10 ? (NS == 9 ? (s <= 4 ? 2 : 0) : (s <= 1 ? 4 : (s == 2 ? 2 : 0)))
        : HP == 6  ? (NS == 9 ? (s <= 2 ? 2 : 0) : (s <= 1 ? 3 : 0))
                   : (NS == 9 ? (s <= 4 ? 1 : 0) : (s <= 1 ? 2 : (s == 2 ? 1 : 0)));
 }
@@ -178,14 +188,15 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
 // DT = RD_BF16 or RD_F16: the element type of activations and weights (same layouts; the MFMA instruction and the conversions
 // of the epilogue differ, rd_common.h H16<DT>).
 template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2,
-          int DT = RD_BF16>
+          int DT = RD_BF16, bool WD = false>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
-  static_assert(NHB == 2 || FOLD, "three halo buffers: no room for the scale / shift array");
+  static_assert((NHB == 2 && !WD) || FOLD, "three halo buffers / wide tile: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
   static_assert(FC == 2 || (FC == 1 && FPW == 2), "30-column tiles: two fragments per wave");
-  using Cfg = C3Cfg<NCT, FPW, FC, NHB>;
+  using Cfg = C3Cfg<NCT, FPW, FC, NHB, WD>;
+  constexpr int HPC = Cfg::HPC;
   constexpr int R = Cfg::R, IPW = Cfg::IPW, SLAB = Cfg::SLAB, COUT = NCT * 32;
   constexpr int C3_HALO = Cfg::HALO, C3_HPW = Cfg::HPW, C3_TH = Cfg::TH;   // (shadow the FPW 4 file-scope constants)
   constexpr int C3_TW = Cfg::TW, C3_ROWB = Cfg::ROWB, RW = Cfg::RW;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   auto hprev = [](int a_) { return NHB == 2 ? C3_HALO - a_ : (a_ == 0 ? (NHB - 1) * C3_HALO : a_ - C3_HALO); };
   float* Sc = (float*)(smem + RING + R * SLAB);
   constexpr int HWOFF = RING + R * SLAB + 2 * COUT * (int)sizeof(float);   // HEAD: 16 KB of packed output-conv weights
-  if (NHB == 2 && tid < COUT) {
+  if (NHB == 2 && !WD && tid < COUT) {
     Sc[tid] = a.scale ? a.scale[tid] : 1.f;
     Sc[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
   }
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   int hh0 = 0, hlo = 0, hlim = 0;                         // first halo row; valid halo columns are hlo <= cc < hlim
   const unsigned char* hbase = nullptr;                   // uniform: halo pixel (0, 0), channel slot 4*hc
   bool hsok = false;
+  int hcur = 0;                                           // chunk of the unit being fetched (WD: the slot test is per piece)
   // Tile t = wg + k*G of the list -> (column tile, row block, image).  Decoded ONCE for the workgroup's first tile; every later
   // tile is the previous one plus G in mixed radix (ncol, nrow) -- a few scalar adds and selects instead of the three software
   // integer divisions (~60 dependent scalar instructions in front of a wave's MFMAs, once per unit) a decode from t costs.
@@ -288,16 +300,35 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     if (hnew) { halo_tile(); hnew = false; }              // (the pieces of this unit are issued AFTER this call and use the geometry)
     hbase = htile + hc * 64;
     hsok = hc * 4 + hs < a.nslots;
+    hcur = hc;
     // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
     if (hc + 1 < a.nchunk) ++hc;
     else if (hk + 1 < ntl) { ++hk; hc = 0; tile_advance(f_ct, f_rb, f_b); hnew = true; }
   };
   auto halo_piece = [&](int buf, int j) {
-    const int q = wave * C3_HPW + j, r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
+    const int q = wave * C3_HPW + j;
+    bool ok;
+    const unsigned char* src;
+    if constexpr (WD) {
+      // row pitch 34 pixels: this lane's halo pixel p = 16 q + (lane >> 2) = (r, c) with r = p / 34 (exact for p < 400 as
+      // (p * 1928) >> 16); the slot swizzle is by COLUMN, ((c >> 2) & 3), so that a fragment read sees the same bank pattern in
+      // every row; pixels past the image's 340 (the padding pieces) read the zero page
+      // (through an opaque copy of the lane id: per piece index everything below is loop invariant, and hipcc would keep the six
+      //  pieces' rows / columns / offsets live across the MFMA phase -- 30+ spilled registers on the cout-128 form -- instead of
+      //  recomputing a dozen VALU instructions per piece)
+      int ol = lane;
+      asm volatile("" : "+v"(ol));
+      const int pp = 16 * q + (ol >> 2), r = (pp * 1928) >> 16, cc = pp - 34 * r;
+      const int hsp = (ol & 3) ^ ((cc >> 2) & 3);
+      ok = hcur * 4 + hsp < a.nslots && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && pp < Cfg::NPX && !(DBG & 16);
+      src = hbase + (long)((r * a.W + cc) * a.x_cs * 2 + hsp * 16);
+    } else {
+    const int r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
     const int cc = c16 + l4;
-    const bool ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
+    ok = hsok && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && !(DBG & 16);
     const unsigned char* sp = hbase + ((long)r * a.W + c16) * (long)a.x_cs * 2;
-    const unsigned char* src = sp + hlane;
+    src = sp + hlane;
+    }
     if constexpr ((DBG & 256) != 0)   // ablation: the same lanes' data from the first MB of x (L2-resident REAL data: MFMA power as in production, no HBM reads)
       src = (const unsigned char*)a.x + ((size_t)(src - (const unsigned char*)a.x) & 0xFFFF0);
     dma_v(ok ? (const void*)src : (const void*)a.zero16, buf + q * 1024);   // (buf = byte offset of the halo buffer)
@@ -332,7 +363,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   {                                                                                                       \
     if ((K) == 0) fa[BUF][0] = *(const s16x8*)(smem + (AADDR));                                            \
     else if ((K) <= NCT) fb[BUF][(K) - 1] = *(const s16x8*)(smem + (BADDR) + ((KS) * NCT + (K) - 1) * 1024); \
-    else fa[BUF][(K) - NCT] = *(const s16x8*)(smem + (AADDR) + ((K) - NCT) * 2048);                        \
+    else fa[BUF][(K) - NCT] = *(const s16x8*)(smem + (AADDR) + (((K) - NCT) / FC) * C3_ROWB + (((K) - NCT) % FC) * 2048); \
     C3_FENCE();                                                                                           \
   }
   // MFMA n of a k-step: pixel fragment n / NCT against channel fragment n % NCT (transposed: weights are operand A)
@@ -398,7 +429,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   {                                                                                                                  \
     constexpr int T_ = c3_tap(TS, (S)), TN_ = c3_tap(TS, ((S) + 1) % NS);                                            \
     constexpr int dh_ = T_ / 3, dw_ = T_ % 3, ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                        \
-    constexpr int NH_ = c3_halo_pieces((S), NS, C3_HPW), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
+    constexpr int NH_ = c3_halo_pieces((S), NS, HPC), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
     const int acur_ = (aoff[dw_] + abuf + dh_ * C3_ROWB) ^ 32;                                                         \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
@@ -415,14 +446,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       if (n < NR) C3_RD(0, n, anext_, bnext_, 0)                                                                     \
     }                                                                                                                \
     if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RD(0, n, anext_, bnext_, 0) }          \
-    C3_SYNC(c3_younger(R, IPW, (S), NS, C3_HPW, NHB), NR)                                                            \
+    C3_SYNC(c3_younger(R, IPW, (S), NS, HPC, NHB), NR)                                                            \
     if ((S) == 0) halo_begin();                                                                                      \
     _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
       C3_MM(1, n)                                                                                                    \
       if (!(DBG & 4)) {   /* the step's DMA pieces, spread over the MFMA slots of this half block (slab pieces first) */ \
         _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                              \
           if (p * (NM / 2) / NP_ == n - NM / 2) {                                                                    \
-            if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS, C3_HPW) + p - IPW);                    \
+            if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS, HPC) + p - IPW);                    \
             C3_FENCE();                                                                                              \
           }                                                                                                          \
       }                                                                                                              \
@@ -698,12 +729,12 @@ inline int conv_num_cus() {
 }
 
 // One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
-template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT>
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
-  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT>;
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD>;
   static const bool once = (allow_big_lds(k), true);
   (void)once;
-  constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
+  constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
   return check_launch("conv3x3_stream_kernel");
 }
@@ -779,7 +810,8 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
   const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !headfuse) || w30_128);
   RD_REQUIRE(!headfuse || !th4 || w30, RD_EINVAL, "conv3 + output conv: two workgroups per CU only on the 8 x 30 tiles");
-  const int th = th4 && !w30 ? 4 : C3_TH, tw = w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
+  const bool wd = sw_.conv_wide && w30;   // 8 x 32 tiles (34-pixel halo pitch) instead of 8 x 30: no discarded MFMA columns
+  const int th = th4 && !w30 ? 4 : C3_TH, tw = wd ? 32 : w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
   a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
@@ -815,22 +847,28 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
 #else
   constexpr bool kAllForms = true;
 #endif
-  RD_REQUIRE(kAllForms || (fold && w30 && (cout == 128 || hb3)) || (headfuse && fold), RD_ESHAPE,
+  RD_REQUIRE(kAllForms || (fold && w30 && (cout == 128 || hb3 || sw_.conv_wide)) || (headfuse && fold), RD_ESHAPE,
              "conv3: this fp16 launch form is not instantiated in the emulator build (conv3_has_form)");
   if (sc) {
     RD_REQUIRE(ts == 0 || ts == 1, RD_ESHAPE, "conv3 + shortcut: tap set %d", ts);
     RD_REQUIRE(fold, RD_EINVAL, "conv3 + shortcut: the weights must carry the folded scales (RD_SCALE_FOLDED)");
   }
   // (tile shape, cout) -> instantiation; within it (tap set, shortcut).  All of these carry folded scales.
-#define C3_BODY(N, FPW_, FC_, NHB_)                                                                       \
+#define C3_BODY(N, FPW_, FC_, NHB_) C3_BODY_(N, FPW_, FC_, NHB_, false)
+#define C3_BODY_(N, FPW_, FC_, NHB_, WD_)                                                                 \
   {                                                                                                       \
-    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a)             \
-                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_, DT>(grid, st, a);            \
-    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                    \
-         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a)                    \
-                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT>(grid, st, a);                   \
+    if (sc) return ts == 0 ? c3_go<N, 0, false, true, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a)        \
+                           : c3_go<N, 1, false, true, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);       \
+    return ts == 0 ? c3_go<N, 0, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a)               \
+         : ts == 1 ? c3_go<N, 1, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a)               \
+                   : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);              \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
+  if (wd) {
+    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT, true>(grid, st, a);
+    if (cout == 128) C3_BODY_(4, 2, 1, 2, true)
+    C3_BODY_(2, 2, 1, 2, true)
+  }
   if (w30) {
     if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT>(grid, st, a);
     if (cout == 128) C3_BODY(4, 2, 1, 2)
@@ -842,6 +880,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   if (head && !sc) return c3_go<4, 0, true, false, false, 4, 2, 2, DT>(grid, st, a);
   if (fold) { if (cout == 128) C3_BODY(4, 4, 2, 2) else C3_BODY(2, 4, 2, 2) }
 #undef C3_BODY
+#undef C3_BODY_
   // scale / shift applied in the epilogue (stand-alone use of the C ABI; the lowering always folds)
 #define C3_PLAIN(N) return ts == 0 ? c3_go<N, 0, false, false, false, 4, 2, 2, DT>(grid, st, a) : ts == 1 ? c3_go<N, 1, false, false, false, 4, 2, 2, DT>(grid, st, a) : c3_go<N, 2, false, false, false, 4, 2, 2, DT>(grid, st, a);
   if (cout == 128) { C3_PLAIN(4) }

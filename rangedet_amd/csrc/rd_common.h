@@ -46,6 +46,7 @@ struct DevSwitches {
   int conv_th4;            // RD_CONV_TH4 (0..3, default 1), RD_CONV_W30 (0..2, default 2), RD_CONV_HEAD30 (0..2, default 1): tile shapes
   int conv_w30, conv_head30;
   int conv_hb3;            // RD_CONV_HB3 (default 1): cout 64 on 8 x 30 tiles fetches its halo two units ahead (three buffers)
+  int conv_wide;           // RD_CONV_WIDE (default 1): 8 x 32 tiles (34-pixel halo pitch, every MFMA column live) instead of 8 x 30
   bool sort_no_select;     // RD_SORT_NO_SELECT
   bool wnms_one_round;     // RD_WNMS_ONE_ROUND
 };
@@ -58,6 +59,7 @@ inline const DevSwitches& dev_switches() {
     d.conv_w30 = num("RD_CONV_W30", 2);
     d.conv_head30 = num("RD_CONV_HEAD30", 1);
     d.conv_hb3 = num("RD_CONV_HB3", 1);
+    d.conv_wide = num("RD_CONV_WIDE", 1);
     d.sort_no_select = getenv("RD_SORT_NO_SELECT") != nullptr;
     d.wnms_one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;
     return d;

@@ -46,14 +46,14 @@ for i, st in enumerate(pipe.plan.steps):
         desc = st.get("name", "")
     rows.append((us, k, desc, fl))
     # tiles per resident workgroup slot of the persistent 3x3 kernel (the rule of launch_conv3, k_conv3.h, restated for this
-    # report: 8 x 30 tiles with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
+    # report: 8 x 32 tiles (RD_CONV_WIDE=0: 8 x 30) with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
     # a stride-2 conv runs on the pixel-pair view = its output grid, a transposed conv phase on its input grid)
     tps = ""
     if dt in rdlib.H16 and k in ("conv", "deconv") and st["k"][0] == 3:
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         Wt = st["x"].W if k == "deconv" else st["out"].W
         wide_head = bool(st.get("head")) and Wt > 1400
-        tw, slots = (62, cus) if wide_head else (30, 2 * cus)
+        tw, slots = (62, cus) if wide_head else (32 if os.environ.get("RD_CONV_WIDE", "1") != "0" else 30, 2 * cus)
         ntiles = -(-Wt // tw) * -(-st["out"].H // 8) * B
         tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, slots, ntiles / slots) + (" per phase" if k == "deconv" else "")
     print("%3d %-9s %-52s %8.1f us %8.1f TFLOP/s%s" % (i, k, desc[:52], us, fl / us / 1e6 if fl else 0, tps), flush=True)
