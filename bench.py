@@ -39,25 +39,27 @@ def is_conv3(s):
 
 def conv_flops(plan, only_conv3=False):
     """Algorithmic FLOPs of the conv-family launches of one frame, and the number of launches (from the lowered plan)."""
+    from rangedet_amd.lower import conv_steps
     fl, n = 0.0, 0
-    for s in plan.steps:
+    for s, launches in conv_steps(plan.steps):   # (a "conv_pair" -- two tower convs in one launch -- counts as two convs, one launch)
         if s["kind"] == "conv" and (not only_conv3 or is_conv3(s)):
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
             if s.get("sc"):   # the block's 1x1 projection shortcut, accumulated in this launch's epilogue
                 fl += 2.0 * s["out"].H * s["out"].W * s["sc"]["cin"] * s["cout"]
-            n += 1
+            n += launches
         elif s["kind"] == "deconv":   # bf16: every phase runs on the persistent kernel too (3x3 tap embedding)
             # every output pixel sums kh*kw/stride taps
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1] / s["stride_w"]
-            n += s["stride_w"]
-    return fl, n
+            n += launches
+    return fl, int(round(n))
 
 
 def conv_bytes(plan, esz, only_conv3=False):
     """Algorithmic HBM bytes of the conv-family launches of one frame: every layer reads its input once, writes its
     output once, reads its residual once (BN/ReLU/add fused), weights once (SURVEY.md section 8d bytes model)."""
+    from rangedet_amd.lower import conv_steps
     by = 0.0
-    for s in plan.steps:
+    for s, _ in conv_steps(plan.steps):
         if s["kind"] == "deconv" or (s["kind"] == "conv" and (not only_conv3 or is_conv3(s))):
             x, o = s["x"], s["out"]
             by += (x.H * x.W * s["cin"] + o.H * o.W * s["cout"]) * esz

@@ -143,6 +143,22 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
                               const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, int dtype,
                               void* stream);
 
+/* The cls and the reg tower of a head level (head/builder.py:221-240: rpn_cls_conv_i / rpn_reg_conv_i, i = 0..3, the same
+ * 3x3 conv + BN + ReLU shape twice on every level) as ONE launch: two problems -- input, packed weights (rd_pack_conv3x3_ex_host
+ * with fold_scale), shift, output each -- that share B, H, W, cin, cout = 128, the channel strides and flags (RD_SCALE_FOLDED
+ * required, no residual).  Same numbers as two rd_conv3x3_bn_act_ex / rd_conv2d_bn_act_head_out calls; the launch has twice
+ * the tiles per resident workgroup (half the tail round) and one pipeline fill / drain instead of two.
+ * rd_conv2d_bn_act_head_out_pair: the towers' LAST convs, each fused with its own 1x1 output conv (rpn_cls_logit: nout0,
+ * rpn_reg_delta: nout1; head_w*_packed from rd_pack_head_weight_host; outputs as in rd_conv2d_bn_act_head_out, same n_off). */
+int rd_conv3x3_bn_act_pair(const void* x0, int x0_coff, const void* w0_packed, const float* shift0, void* y0, int y0_coff,
+                           const void* x1, int x1_coff, const void* w1_packed, const float* shift1, void* y1, int y1_coff,
+                           int x_cstride, int y_cstride, int B, int H, int W, int cin, int flags, int dtype, void* stream);
+int rd_conv2d_bn_act_head_out_pair(const void* x0, int x0_coff, const void* w0_packed, const float* shift0, const void* head_w0_packed,
+                                   const float* head_bias0, float* out0, long out0_batch_stride, int nout0,
+                                   const void* x1, int x1_coff, const void* w1_packed, const float* shift1, const void* head_w1_packed,
+                                   const float* head_bias1, float* out1, long out1_batch_stride, int nout1,
+                                   int x_cstride, long n_off, int B, int H, int W, int cin, int flags, int dtype, void* stream);
+
 /* Transposed conv, kernel (3,kw), stride (1,stride_w), pad (1,pad_w); one call per output phase. */
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase,
                        const float* scale, const float* shift, const void* residual, int r_cstride,

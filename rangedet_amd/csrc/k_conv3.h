@@ -43,6 +43,12 @@ struct Conv3Args {
   const bf16_t* sx; int s_cs, s_co; long s_bs;
   const unsigned char* scw;  // packed [ks][Cout/32][64 lanes][8 bf16] (pack_sc_frag)
   int s_nks;                 // 16-channel k-steps of the shortcut input (<= 8)
+  // GRP variant: TWO problems of the same shape in one launch (the cls and the reg tower conv of a head level,
+  // head/builder.py:221-240).  Images B .. 2B-1 of the tile list are problem 1; every per-problem pointer / size of problem 1 is
+  // problem 0's plus the delta below (elements of the pointer's type; g_w, g_hw in bytes), and the image index restarts at 0.
+  int ngrp;                  // 1 or 2
+  long g_x, g_res, g_y, g_w, g_shift, g_hw, g_hb, g_ho, g_ho_bs;
+  int g_hn;
 };
 
 // Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
@@ -187,9 +193,13 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
 // it reads the accumulators, adds the residual if any, converts and clamps.
 // DT = RD_BF16 or RD_F16: the element type of activations and weights (same layouts; the MFMA instruction and the conversions
 // of the epilogue differ, rd_common.h H16<DT>).
+// GRP: two problems per launch (Conv3Args::ngrp): the tile list runs over 2B images, the group of an image selects the input,
+// weight image, shift, residual, output (and fused output conv) -- the launch then has twice the tiles per resident workgroup
+// slot (half the tail round) and one prologue / drain instead of two.  Only for the forms the lowering pairs: FOLD, no SC.
 template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2,
-          int DT = RD_BF16, bool WD = false>
+          int DT = RD_BF16, bool WD = false, bool GRP = false>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(!GRP || (FOLD && !SC && !(HEAD && FPW == 4)), "two problems per launch: folded scales, no shortcut, output-conv weights from L2");
   static_assert((NHB == 2 && !WD) || FOLD, "three halo buffers / wide tile: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
@@ -219,14 +229,24 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   // FOLD: per channel block j the dword {bf16 hi, bf16 lo} of this lane's shift (A-operand row m = channel
   // 32*j + conv_row_perm(m), k = 0 and 1 live in the hi == 0 half of the wave), and the B operand of ones
   unsigned bzw[NCT];
-  if constexpr (FOLD) {
+  auto load_shift = [&](const float* shp) {
 #pragma unroll
     for (int j = 0; j < NCT; ++j) {
-      const float t = a.shift ? a.shift[32 * j + conv_row_perm(m)] : 0.f;
+      const float t = shp ? shp[32 * j + conv_row_perm(m)] : 0.f;
       const bf16_t th = H16<DT>::from_f32(t);
       const bf16_t tl = H16<DT>::from_f32(t - H16<DT>::to_f32(th));
       bzw[j] = hi ? 0u : ((unsigned)th | ((unsigned)tl << 16));
     }
+  };
+  if constexpr (FOLD && !GRP) load_shift(a.shift);
+  // GRP: the fragment of BOTH problems, loaded once (4 more registers; a reload inside the tile loop would be a vector-memory
+  // load whose wait drains the LDS-DMA queue -- measured +8 .. 12 us per launch); the tile's one is selected per tile
+  unsigned bzw1[GRP ? NCT : 1];
+  if constexpr (GRP) {
+    load_shift(a.shift ? a.shift + a.g_shift : nullptr);
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) bzw1[j] = bzw[j];
+    load_shift(a.shift);
   }
   int tpt = 0;
 #define C3_TRACE() { if (a.trace && tid == 0 && tpt < 7) a.trace[(size_t)blockIdx.x * 8 + tpt++] = wall_clock64(); }
@@ -293,7 +313,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     hh0 = f_rb * C3_TH - 1;
     hlo = hw0 < 0 ? -hw0 : 0;
     hlim = a.W - hw0;
-    htile = (const unsigned char*)(a.x + (size_t)f_b * a.x_bs + a.x_co) + ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
+    const bool fg = GRP && f_b >= a.B;                     // (GRP) problem 1: its own input, image index from 0
+    htile = (const unsigned char*)(a.x + (size_t)(fg ? f_b - a.B : f_b) * a.x_bs + a.x_co + (fg ? a.g_x : 0)) +
+            ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
   };
   bool hnew = true;                                       // the fetch cursor moved to a new tile: geometry not yet derived
   auto halo_begin = [&]() {                               // per fetch UNIT: the chunk's slice of the tile; advance the cursor
@@ -335,12 +357,26 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
   const int nslab_tile = a.nchunk * NS;
+  // GRP: the slab stream runs R steps ahead of the MFMAs, so it has its own tile cursor -- the weight image is the one of the
+  // problem that tile belongs to (past the end of the list the dummy fetches read whichever image the cursor has reached)
+  // (n0 = how many of this workgroup's tiles wg, wg + G, ... belong to problem 0, i.e. lie below tiles_img * B: one division per
+  //  workgroup instead of a third mixed-radix tile cursor advanced in every step)
+  const int t0_ = tiles_img * a.B;
+  const int n0 = GRP ? (wg < t0_ ? (t0_ - wg + G - 1) / G : 0) : 0;
+  int stile = 0;                                          // ordinal (within the workgroup's list) of the tile the slab stream is in
+  const unsigned char* wsrc = a.w + (GRP && n0 == 0 ? a.g_w : 0);
   auto slab_piece = [&](int j) {
-    dma_s(a.w + (size_t)fslab * SLAB + (wave * IPW + j) * 1024, lane * 16, RING + fslot * SLAB + (wave * IPW + j) * 1024);
+    dma_s(wsrc + (size_t)fslab * SLAB + (wave * IPW + j) * 1024, lane * 16, RING + fslot * SLAB + (wave * IPW + j) * 1024);
   };
   auto slab_advance = [&]() {
     fslot = fslot + 1 == R ? 0 : fslot + 1;
     fslab = fslab + 1 == nslab_tile ? 0 : fslab + 1;
+    if constexpr (GRP) {
+      if (fslab == 0) {
+        ++stile;
+        wsrc = a.w + (stile >= n0 ? a.g_w : 0);
+      }
+    }
   };
 
   // ---- fragment addressing -------------------------------------------------------------------------------------
@@ -476,7 +512,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
         memcpy(&ones, ob, 16);
 #pragma unroll
         for (int n = 0; n < NM; ++n) {
-          unsigned ab[4] = {bzw[n % NCT], z0, z0, z0};
+          unsigned ab[4] = {GRP && k >= n0 ? bzw1[GRP ? n % NCT : 0] : bzw[n % NCT], z0, z0, z0};
           s16x8 bz;
           memcpy(&bz, ab, 16);
           acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
@@ -503,7 +539,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     // Lane (m, hi) of accumulator (i, j) holds channels 32*j + 16*hi + r (r = 0..15) of pixel 32*i + m of its row.
     // Scratch: this wave's 8 KB of the halo buffer that is free until the next unit's tap-0 barrier
     // (row = one pixel = COUT*2 bytes, 16-byte slot index XORed with the pixel number: conflict-free both ways).
-    const int ct = c_ct, rb = c_rb, b = c_b;
+    const int ct = c_ct, rb = c_rb;
+    const bool eg = GRP && c_b >= a.B;                               // (GRP) problem 1: image index from 0, pointers + deltas
+    const int b = eg ? c_b - a.B : c_b;
     tile_advance(c_ct, c_rb, c_b);                                   // (for the next iteration)
     const int oh0 = rb * C3_TH + RW * wave;                          // fragment i: output row oh0 + i / FC, columns 32*(i % FC) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
@@ -516,9 +554,15 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1 || FPW == 2), "transpose scratch");
     constexpr int ROWB = CW * 2, SPR = CW / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + hprev(abuf) + wave * (C3_HALO / 4);   // (the buffer of the unit just consumed)
-    bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
+    bf16_t* __restrict__ yrow0 = a.y + (eg ? a.g_y : 0) + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
     // (base of image b, not of the wave's first row: rows past the image bottom must not even form an address beyond the buffer)
-    const bf16_t* __restrict__ rimg0 = a.res + (size_t)b * a.r_bs + a.r_co;
+    const bf16_t* __restrict__ rimg0 = a.res + (eg ? a.g_res : 0) + (size_t)b * a.r_bs + a.r_co;
+    // fused output conv of the tile's problem
+    const unsigned char* __restrict__ e_hw = a.hw + (eg ? a.g_hw : 0);
+    const float* __restrict__ e_hb = a.hb + (eg ? a.g_hb : 0);
+    float* __restrict__ e_ho = a.ho + (eg ? a.g_ho : 0);
+    const long e_ho_bs = a.ho_bs + (eg ? a.g_ho_bs : 0);
+    const int e_hn = a.hn + (eg ? a.g_hn : 0);
     const int sh = a.sw - 1;   // stride 2: shift by 1, keep even columns
     if constexpr (SC) {
       // projection shortcut: B operand = this wave's pixels of the block input straight from global memory (lane (m, hi)
@@ -624,7 +668,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           for (int part = 0; part < 2; ++part)
 #pragma unroll
             for (int ks = 0; ks < KSP; ++ks)
-              hwq[part][ks] = *(const s16x8*)(a.hw + part * 8192 + (jp * KSP + ks) * 1024 + el * 16);
+              hwq[part][ks] = *(const s16x8*)(e_hw + part * 8192 + (jp * KSP + ks) * 1024 + el * 16);
         }
 #pragma unroll
         for (int j = jp * JW; j < (jp + 1) * JW; ++j) {
@@ -678,10 +722,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           }
           const int tcs = 32 * (i % FC) + em, ows = ct * C3_TW + tcs, ohs = oh0 + i / FC;
           if (jp == NPASS - 1 && tcs < C3_TW && ows < a.W && ohs < a.H) {
-            float* o = a.ho + (size_t)b * a.ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * a.hn + 4 * ehi;
+            float* o = e_ho + (size_t)b * e_ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * e_hn + 4 * ehi;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (4 * ehi + r < a.hn) o[r] = (h0[r] + h1[r]) + a.hb[4 * ehi + r];
+              if (4 * ehi + r < e_hn) o[r] = (h0[r] + h1[r]) + e_hb[4 * ehi + r];
           }
         } else {
           // read back pixel-major and store: lane -> (pixel it*RPI + el / SPR, slot el % SPR)
@@ -729,9 +773,9 @@ inline int conv_num_cus() {
 }
 
 // One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
-template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false>
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
-  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD>;
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP>;
   static const bool once = (allow_big_lds(k), true);
   (void)once;
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
@@ -760,24 +804,39 @@ inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int
   return !dev_switches().conv_v1;
 }
 
-template <int DT>
-inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
-                           const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head);
-inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
-                        const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                        int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, int dt) {
-  RD_REQUIRE(is_h16(dt), RD_EINVAL, "conv3: dtype %d (the persistent 3x3 kernel takes RD_BF16 or RD_F16)", dt);
-  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head);
-  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head);
+// Second problem of a two-problem launch (GRP): same shapes, channel strides and flags as the first, its own tensors.
+struct Conv3Second {
+  const void* x; int x_co;
+  const void* w; const float* shift;
+  const void* res; int r_co;
+  void* y; int y_co;
+  const void* hw; const float* hb; float* ho; long ho_bs; int hn;   // fused output conv (when the first problem has one)
+};
+inline bool conv3_pair_eligible(int cout, int flags, int W) {
+  const DevSwitches& sw_ = dev_switches();
+  return cout == 128 && (flags & RD_SCALE_FOLDED) && sw_.conv_th4 && sw_.conv_w30 == 2 && sw_.conv_wide && (sw_.conv_th4 != 2 || W >= 600);
 }
 
 template <int DT>
 inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                            const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head) {
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1);
+inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                        const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                        int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, int dt,
+                        const Conv3Second* g1) {
+  RD_REQUIRE(is_h16(dt), RD_EINVAL, "conv3: dtype %d (the persistent 3x3 kernel takes RD_BF16 or RD_F16)", dt);
+  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1);
+  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1);
+}
+
+template <int DT>
+inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
+                           const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
+  a.ngrp = g1 ? 2 : 1;
   if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
   const bool sc = head && head->sx;
   const bool fold = (flags & RD_SCALE_FOLDED) != 0;
@@ -805,14 +864,30 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   // (fused output conv on the two-workgroup tiles: its 16 KB of weights no longer fit in LDS and are re-read from L2 per
   //  fragment and pass; measured per layer: W = 1328 213 -> 205 us, W = 664 109 -> 107 us, W = 2656 398 -> 405 us, so the
   //  full-width level stays on the 8 x 62 tile.  RD_CONV_HEAD30=0 -> never, =2 -> always)
-  const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && W <= 1400));   // (only exists on the 8 x 30 tiles)
+  // (a two-problem launch always takes the two-workgroup tile: its output-conv weights are per problem and come from L2)
+  const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && W <= 1400) || (g1 && head30));   // (only exists on the 8 x 30 tiles)
   const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
   const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !headfuse) || w30_128);
   RD_REQUIRE(!headfuse || !th4 || w30, RD_EINVAL, "conv3 + output conv: two workgroups per CU only on the 8 x 30 tiles");
   const bool wd = sw_.conv_wide && w30;   // 8 x 32 tiles (34-pixel halo pitch) instead of 8 x 30: no discarded MFMA columns
   const int th = th4 && !w30 ? 4 : C3_TH, tw = wd ? 32 : w30 ? C3Cfg<2, 2, 1>::TW : C3_TW;
-  a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B;
+  a.ncol = (W + tw - 1) / tw; a.nrow = (H + th - 1) / th; a.ntiles = a.ncol * a.nrow * B * a.ngrp;
+  if (g1) {
+    RD_REQUIRE(wd && fold && !sc && ts == 0 && cout == 128 && sw == 1, RD_ESHAPE,
+               "conv3: two problems per launch need the 8 x 32 tile form (cout 128, folded scales, stride 1, no shortcut)");
+    RD_REQUIRE(!headfuse == !g1->hw && !res == !g1->res && !shift == !g1->shift, RD_EINVAL,
+               "conv3: the two problems of a launch must have the same structure (output conv / residual / shift)");
+    a.g_x = ((const bf16_t*)g1->x + g1->x_co) - ((const bf16_t*)x + x_co);
+    a.g_w = (const unsigned char*)g1->w - (const unsigned char*)w;
+    a.g_shift = shift ? g1->shift - shift : 0;
+    a.g_res = res ? ((const bf16_t*)g1->res + g1->r_co) - ((const bf16_t*)res + r_co) : 0;
+    a.g_y = y ? ((bf16_t*)g1->y + g1->y_co) - ((bf16_t*)y + y_co) : 0;
+    if (headfuse) {
+      a.g_hw = (const unsigned char*)g1->hw - a.hw; a.g_hb = g1->hb - a.hb; a.g_ho = g1->ho - a.ho;
+      a.g_ho_bs = g1->ho_bs - a.ho_bs; a.g_hn = g1->hn - a.hn;
+    }
+  }
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);
@@ -864,6 +939,10 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
                    : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);              \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
+  if (wd && g1) {
+    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT, true, true>(grid, st, a);
+    return c3_go<4, 0, false, false, true, 2, 1, 2, DT, true, true>(grid, st, a);
+  }
   if (wd) {
     if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT, true>(grid, st, a);
     if (cout == 128) C3_BODY_(4, 2, 1, 2, true)

@@ -323,6 +323,65 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
                       (hipStream_t)stream, 0, &h, dtype);
 }
 
+// ---- the cls and the reg tower conv of a head level as ONE launch (two problems of the same shape) -------------------------
+static int pair_checks(const char* fn, const void* x0, const void* x1, const void* w0, const void* w1, const float* shift0,
+                       const float* shift1, int x_cstride, int x0_coff, int x1_coff, int B, int H, int W, int cin, int flags,
+                       int dtype) {
+  RD_REQUIRE(x0 && x1 && w0 && w1 && shift0 && shift1, RD_EINVAL, "%s: null pointer", fn);
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "%s: dtype %d (RD_BF16 or RD_F16)", fn, dtype);
+  RD_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0, RD_ESHAPE, "%s: shape", fn);
+  RD_REQUIRE((flags & RD_SCALE_FOLDED) && !(flags & RD_ADD), RD_EINVAL, "%s: needs RD_SCALE_FOLDED weights, takes no residual", fn);
+  RD_REQUIRE(x_cstride % 8 == 0 && x0_coff % 8 == 0 && x1_coff % 8 == 0 && x0_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride &&
+             x1_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "%s: x channel stride/offset", fn);
+  RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "%s: needs the persistent 3x3 kernel (RD_CONV_V1 is set)", fn);
+  return RD_OK;
+}
+int rd_conv3x3_bn_act_pair(const void* x0, int x0_coff, const void* w0_packed, const float* shift0, void* y0, int y0_coff,
+                           const void* x1, int x1_coff, const void* w1_packed, const float* shift1, void* y1, int y1_coff,
+                           int x_cstride, int y_cstride, int B, int H, int W, int cin, int flags, int dtype, void* stream) {
+  if (int rc = pair_checks("conv3x3_pair", x0, x1, w0_packed, w1_packed, shift0, shift1, x_cstride, x0_coff, x1_coff, B, H, W, cin, flags, dtype)) return rc;
+  RD_REQUIRE(y0 && y1, RD_EINVAL, "conv3x3_pair: null output");
+  RD_REQUIRE(y0_coff >= 0 && y1_coff >= 0 && y0_coff + 128 <= y_cstride && y1_coff + 128 <= y_cstride, RD_ESHAPE, "conv3x3_pair: y channels exceed stride");
+  allow_conv_lds();
+  if (!conv3_pair_eligible(128, flags, W)) {   // (a dev-switch combination without the two-workgroup 8 x 32 tiles: two launches)
+    if (int rc = launch_conv3(x0, x_cstride, x0_coff, w0_packed, nullptr, shift0, nullptr, 0, 0, y0, y_cstride, y0_coff, B, H, W, cin, 128,
+                              flags, 1, (hipStream_t)stream, 0, nullptr, dtype)) return rc;
+    return launch_conv3(x1, x_cstride, x1_coff, w1_packed, nullptr, shift1, nullptr, 0, 0, y1, y_cstride, y1_coff, B, H, W, cin, 128, flags, 1,
+                        (hipStream_t)stream, 0, nullptr, dtype);
+  }
+  Conv3Second g;
+  memset(&g, 0, sizeof(g));
+  g.x = x1; g.x_co = x1_coff; g.w = w1_packed; g.shift = shift1; g.y = y1; g.y_co = y1_coff;
+  return launch_conv3(x0, x_cstride, x0_coff, w0_packed, nullptr, shift0, nullptr, 0, 0, y0, y_cstride, y0_coff, B, H, W, cin, 128, flags, 1,
+                      (hipStream_t)stream, 0, nullptr, dtype, &g);
+}
+int rd_conv2d_bn_act_head_out_pair(const void* x0, int x0_coff, const void* w0_packed, const float* shift0, const void* head_w0_packed,
+                                   const float* head_bias0, float* out0, long out0_batch_stride, int nout0,
+                                   const void* x1, int x1_coff, const void* w1_packed, const float* shift1, const void* head_w1_packed,
+                                   const float* head_bias1, float* out1, long out1_batch_stride, int nout1,
+                                   int x_cstride, long n_off, int B, int H, int W, int cin, int flags, int dtype, void* stream) {
+  if (int rc = pair_checks("conv2d_head_out_pair", x0, x1, w0_packed, w1_packed, shift0, shift1, x_cstride, x0_coff, x1_coff, B, H, W, cin, flags, dtype)) return rc;
+  RD_REQUIRE(head_w0_packed && head_w1_packed && head_bias0 && head_bias1 && out0 && out1, RD_EINVAL, "conv2d_head_out_pair: null pointer");
+  RD_REQUIRE(nout0 >= 1 && nout0 <= 8 && nout1 >= 1 && nout1 <= 8, RD_ESHAPE, "conv2d_head_out_pair: nout %d / %d (1..8)", nout0, nout1);
+  allow_conv_lds();
+  Conv3Args h;
+  memset(&h, 0, sizeof(h));
+  h.hw = (const unsigned char*)head_w0_packed; h.hb = head_bias0; h.ho = out0; h.ho_bs = out0_batch_stride; h.ho_off = n_off; h.hn = nout0;
+  if (!conv3_pair_eligible(128, flags, W)) {
+    if (int rc = launch_conv3(x0, x_cstride, x0_coff, w0_packed, nullptr, shift0, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
+                              (hipStream_t)stream, 0, &h, dtype)) return rc;
+    h.hw = (const unsigned char*)head_w1_packed; h.hb = head_bias1; h.ho = out1; h.ho_bs = out1_batch_stride; h.hn = nout1;
+    return launch_conv3(x1, x_cstride, x1_coff, w1_packed, nullptr, shift1, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
+                        (hipStream_t)stream, 0, &h, dtype);
+  }
+  Conv3Second g;
+  memset(&g, 0, sizeof(g));
+  g.x = x1; g.x_co = x1_coff; g.w = w1_packed; g.shift = shift1;
+  g.hw = head_w1_packed; g.hb = head_bias1; g.ho = out1; g.ho_bs = out1_batch_stride; g.hn = nout1;
+  return launch_conv3(x0, x_cstride, x0_coff, w0_packed, nullptr, shift0, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
+                      (hipStream_t)stream, 0, &h, dtype, &g);
+}
+
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase, const float* scale,
                        const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
                        int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
@@ -542,9 +601,11 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs,
                      (float)hash_scale, w.novf);
   // RD_WNMS_TILE_W / RD_WNMS_MERGE_LDS: test switches that force the column-chunked scan and the merge overflow path at small K
-  const char* e_tw = getenv("RD_WNMS_TILE_W");
-  const char* e_ml = getenv("RD_WNMS_MERGE_LDS");
-  const int tile_w = std::min(w.nwcap, e_tw ? std::max(1, atoi(e_tw)) : 256);
+  // (read per call, once per batch of frames: the tests set them around single calls)
+  const char* e_tw_ = getenv("RD_WNMS_TILE_W");
+  const char* e_ml_ = getenv("RD_WNMS_MERGE_LDS");
+  const int e_tw = e_tw_ ? atoi(e_tw_) : 0, e_ml = e_ml_ ? atoi(e_ml_) : 0;
+  const int tile_w = std::min(w.nwcap, e_tw ? std::max(1, e_tw) : 256);
   const size_t scan_lds = ((size_t)w.nwcap + (size_t)64 * tile_w) * 8;
   allow_big_lds(wnms_scan_kernel);
   // Two rounds.  The greedy scan only ever reads the thr / vote rows of boxes it KEEPS, and the highest-scoring boxes
@@ -556,22 +617,36 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const bool two = Kcap >= 4 * R1 && !one_round;
   // pair tiles are strided over a fixed number of single-wave workgroups per frame: one tile each at the pipeline's typical K
   // (1 - 2 k rows: <= 2048 tiles per round), grid-strided beyond that -- so the launch size does not grow with the capacity
-  const int pgrid = std::min(2048, std::max(64, nb * WN_CT * std::min(nb, 16)));
-  hipLaunchKernelGGL(wnms_pairs_kernel, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
-                     thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)nullptr, (const int*)nullptr,
-                     (const unsigned long long*)nullptr, 0, two ? nb1 : nb);
-  hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
-                     w.keep_q, keep, d_nkeep, bs, 0, two ? nb1 : nb, two ? w.supp_state : (unsigned long long*)nullptr, tile_w);
+  const int ct = dev_switches().wnms_ct == 32 ? 32 : dev_switches().wnms_ct == 16 ? 16 : 8;   // columns per pair tile
+  const int pgrid = std::min(2048, std::max(64, nb * (64 / ct) * std::min(nb, 16)));
+  auto pairs = [&](const int* rows, const int* nrows, const unsigned long long* supp, int rb_end) {
+    auto k = dev_switches().wnms_bal ? (ct == 8 ? wnms_pairs_kernel<8, true> : ct == 16 ? wnms_pairs_kernel<16, true> : wnms_pairs_kernel<32, true>)
+                                     : (ct == 8 ? wnms_pairs_kernel<8, false> : ct == 16 ? wnms_pairs_kernel<16, false> : wnms_pairs_kernel<32, false>);
+    hipLaunchKernelGGL(k, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d, w.thr, w.vote,
+                       w.nwcap, bs, rows, nrows, supp, 0, rb_end);
+  };
+  pairs(nullptr, nullptr, nullptr, two ? nb1 : nb);
+  // capacities up to 8 192 rows: the four-wave scan with grouped staging (RD_WNMS_SCAN1 / a forced tile width: the single-wave form)
+  const bool scan4 = w.nwcap <= 128 && !e_tw && !dev_switches().wnms_scan1;
+  const int tile_words = 64 * 128;
+  const size_t scan4_lds = ((size_t)w.nwcap + tile_words) * 8;
+  if (scan4) allow_big_lds(wnms_scan4_kernel);
+  auto scan = [&](int c_begin, int c_end, unsigned long long* state) {
+    if (scan4)
+      hipLaunchKernelGGL(wnms_scan4_kernel, dim3(1, 1, B), dim3(256), scan4_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
+                         w.keep_q, keep, d_nkeep, bs, c_begin, c_end, state, tile_words);
+    else
+      hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
+                         w.keep_q, keep, d_nkeep, bs, c_begin, c_end, state, tile_w);
+  };
+  scan(0, two ? nb1 : nb, two ? w.supp_state : (unsigned long long*)nullptr);
   if (two) {
     hipLaunchKernelGGL(wnms_alive_kernel, dim3(1, 1, B), dim3(256), 0, st, w.supp_state, Kcap, d_count, R1, w.alive, w.nalive, bs);
-    hipLaunchKernelGGL(wnms_pairs_kernel, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh,
-                       thresh_vote, is3d, w.thr, w.vote, w.nwcap, bs, (const int*)w.alive, (const int*)w.nalive,
-                       (const unsigned long long*)w.supp_state, 0, 0);
-    hipLaunchKernelGGL(wnms_scan_kernel, dim3(1, 1, B), dim3(64), scan_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
-                       w.keep_q, keep, d_nkeep, bs, nb1, nb, w.supp_state, tile_w);
+    pairs((const int*)w.alive, (const int*)w.nalive, (const unsigned long long*)w.supp_state, 0);
+    scan(nb1, nb, w.supp_state);
   }
   allow_big_lds(wnms_merge_kernel);
-  const int lds_cap = std::min(Kcap + 2, e_ml ? std::max(4, atoi(e_ml)) : 16384);
+  const int lds_cap = std::min(Kcap + 2, e_ml ? std::max(4, e_ml) : 16384);
   hipLaunchKernelGGL(wnms_merge_kernel, dim3(std::min(Kcap, 4096), 1, B), dim3(64), (size_t)lds_cap * 8, st, dets, ord, w.vote,
                      w.snap, Kcap, d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs, lds_cap, w.ovf, w.novf);
   if (Kcap + 2 > lds_cap)

@@ -49,6 +49,9 @@ struct DevSwitches {
   int conv_wide;           // RD_CONV_WIDE (default 1): 8 x 32 tiles (34-pixel halo pitch, every MFMA column live) instead of 8 x 30
   bool sort_no_select;     // RD_SORT_NO_SELECT
   bool wnms_one_round;     // RD_WNMS_ONE_ROUND
+  int wnms_bal;            // RD_WNMS_BAL (default 0; measured slower): the candidate pairs of a pair tile are dealt out evenly over the wave's lanes
+  bool wnms_scan1;         // RD_WNMS_SCAN1: the single-wave scan at every capacity (default: four waves with grouped staging up to 8 192 rows)
+  int wnms_ct;             // RD_WNMS_CT (8 default, 16, 32): columns per pair tile
 };
 inline const DevSwitches& dev_switches() {
   static const DevSwitches s = [] {
@@ -62,6 +65,9 @@ inline const DevSwitches& dev_switches() {
     d.conv_wide = num("RD_CONV_WIDE", 1);
     d.sort_no_select = getenv("RD_SORT_NO_SELECT") != nullptr;
     d.wnms_one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;
+    d.wnms_ct = num("RD_WNMS_CT", 8);
+    d.wnms_scan1 = getenv("RD_WNMS_SCAN1") != nullptr;
+    d.wnms_bal = num("RD_WNMS_BAL", 0);
     return d;
   }();
   return s;

@@ -52,6 +52,10 @@ SIGNATURES = {
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p]),
+    "rd_conv3x3_bn_act_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] * 2 +
+                               [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_conv2d_bn_act_head_out_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int] * 2 +
+                                       [c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p]),
     "rd_meta_packed_bytes": (c_size_t, [c_int]),

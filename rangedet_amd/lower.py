@@ -53,6 +53,20 @@ class Plan:
     num_classes: int = 1
 
 
+def conv_steps(steps):
+    """The conv / deconv steps of a plan one by one: the two members of a "conv_pair" (one launch) as two entries.
+    Yields (step, launches): launches = what the step adds to the launch count (1, 0.5 + 0.5 for a pair, stride_w for the phases
+    of a transposed conv)."""
+    for st in steps:
+        if st["kind"] == "conv_pair":
+            yield st["a"], 0.5
+            yield st["b"], 0.5
+        elif st["kind"] == "conv":
+            yield st, 1
+        elif st["kind"] == "deconv":
+            yield st, st["stride_w"]
+
+
 def _strip_cast(s):
     while s.op == "cast":
         s = s.inputs[0]
@@ -81,8 +95,68 @@ class Lowering:
         for out in group.inputs:
             self.plan.outputs.append(self.emit_value(out))
         self._fuse_head_out()
+        self._pair_equal_convs()
 
     # ---- fusion ------------------------------------------------------------------------------------------------
+    def _pair_equal_convs(self):
+        """16-bit: two 3x3 convs of the SAME shape whose inputs are both ready run as ONE launch (rd_conv3x3_bn_act_pair /
+        rd_conv2d_bn_act_head_out_pair) -- in this graph the cls and the reg tower conv i of every head level
+        (builder.py:221-240: the towers are built one after the other, layer i of both only depends on layer i-1 of its own
+        tower).  The later conv moves up to the earlier one's place in the plan; it may only do so when the tensor it reads was
+        written before that place.  Plan step kind "conv_pair": a / b = the two conv steps as they were."""
+        # OFF by default (RD_PAIR=1 turns it on, RD_PAIR_MAXW limits it to narrow levels).  Measured on one box, DESIGN.md 6.4: serial on
+        # one stream a pair is 10 % faster than its two launches at W = 664, equal at W = 1328, 2 - 7 % slower at W = 2656 (real
+        # activations); end to end +0.65 % with one batch in flight, -0.4 .. -0.7 % with the default two (the other stream's launches
+        # already fill the tail rounds, and finer launches interleave better).
+        if not self.h16 or os.environ.get("RD_PAIR", "0") in ("", "0"):
+            return
+        max_w = int(os.environ.get("RD_PAIR_MAXW", "100000"))
+
+        def sig(st):
+            if st["kind"] != "conv" or not st.get("ex") or not st.get("fold") or st.get("sc") or st.get("s2view"):
+                return None
+            if st["res"] is not None or st["cout"] != 128 or st["stride_w"] != 1 or tuple(st["k"]) != (3, 3) or st["flags"] != RD_RELU_POST:
+                return None
+            x, o, h = st["x"], st["out"], st.get("head")
+            if x.W > max_w:
+                return None
+            return (x.H, x.W, x.cs, len(st["cmap"]) if st.get("cmap") else st["cin"], o.cs if not h else None,
+                    (h["n_off"], h["N"]) if h else None)
+
+        def is_write(key):
+            return key in ("out", "out1", "head_out", "head_out1", "keep") or key.startswith("out_")
+
+        out, written, touched, open_ = [], {}, {}, {}
+        for st in self.plan.steps:
+            k = sig(st)
+            if k is not None:
+                # the tensor it reads was written before place j, and nothing from place j on touches what it writes
+                ready = written.get(st["x"].buf, -1)
+                clear = max(touched.get(v.buf, -1) for v in (st["out"], st.get("head_out")) if v is not None)
+                j = next((j for j in open_.get(k, []) if ready < j and clear < j), None)
+                if j is not None:
+                    open_[k].remove(j)
+                    a = out[j]
+                    p = dict(kind="conv_pair", name=a["name"] + " + " + st["name"], a=a, b=st, x=a["x"], x1=st["x"], out=a["out"],
+                             out1=st["out"])
+                    if a.get("head"):
+                        p["head_out"], p["head_out1"] = a["head_out"], st["head_out"]
+                    out[j] = p
+                    for v in (st["out"], st.get("head_out")):
+                        if v is not None:
+                            written[v.buf] = max(written.get(v.buf, -1), j)
+                            touched[v.buf] = max(touched.get(v.buf, -1), j)
+                    touched[st["x"].buf] = max(touched.get(st["x"].buf, -1), j)
+                    continue
+                open_.setdefault(k, []).append(len(out))
+            for key, v in st.items():
+                if isinstance(v, (TRef, FlatRef)):
+                    touched[v.buf] = len(out)
+                    if is_write(key):
+                        written[v.buf] = len(out)
+            out.append(st)
+        self.plan.steps = out
+
     def _fuse_head_out(self):
         """bf16: the last conv of a head tower whose ONLY consumer is one 1x1 output conv (rpn_cls_logit / rpn_reg_delta of a
         single-class head) runs as rd_conv2d_bn_act_head_out: the output conv is applied in the 3x3 kernel's epilogue and the

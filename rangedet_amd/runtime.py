@@ -140,6 +140,9 @@ class Executor:
         L, A, dt = self.lib, self.alloc, self.dtype
         k = st["kind"]
         b = dict(st)
+        if k == "conv_pair":
+            b["a"], b["b"] = self._bind(st["a"], P), self._bind(st["b"], P)
+            return b
         if k == "conv":
             w = np.asarray(P[st["name"] + "_weight"], np.float32)
             if st.get("cmap"):   # the input is a concat buffer with alignment padding: zero weight columns there
@@ -231,6 +234,24 @@ class Executor:
                 src = din(b["name"])
                 assert tuple(src.shape) == (B, o.C, o.H, o.W), (b["name"], tuple(src.shape), (B, o.C, o.H, o.W))
                 L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
+            elif k == "conv_pair":
+                # two convs of one shape in ONE launch (lower._pair_equal_convs: the cls and reg tower conv of a head level)
+                p, q = b["a"], b["b"]
+                x0, x1 = p["x"], q["x"]
+                cin = len(p["cmap"]) if p.get("cmap") else p["cin"]
+                if p.get("head"):
+                    h0, h1 = p["head"], q["head"]
+                    L.call("rd_conv2d_bn_act_head_out_pair",
+                           self.p(x0), x0.co, A.ptr(p["w"]), A.ptr(p["shift"]), A.ptr(p["head_w"]), A.ptr(p["head_bias"]),
+                           self.p(h0["out"]), h0["N"] * h0["nout"], h0["nout"],
+                           self.p(x1), x1.co, A.ptr(q["w"]), A.ptr(q["shift"]), A.ptr(q["head_w"]), A.ptr(q["head_bias"]),
+                           self.p(h1["out"]), h1["N"] * h1["nout"], h1["nout"],
+                           x0.cs, h0["n_off"], B, x0.H, x0.W, cin, p["flags"], dt, st_)
+                else:
+                    o0, o1 = p["out"], q["out"]
+                    L.call("rd_conv3x3_bn_act_pair", self.p(x0), x0.co, A.ptr(p["w"]), A.ptr(p["shift"]), self.p(o0), o0.co,
+                           self.p(x1), x1.co, A.ptr(q["w"]), A.ptr(q["shift"]), self.p(o1), o1.co, x0.cs, o0.cs, B, x0.H, x0.W, cin,
+                           p["flags"], dt, st_)
             elif k == "conv" and b.get("head"):
                 x, h = b["x"], b["head"]
                 L.call("rd_conv2d_bn_act_head_out", self.p(x), x.cs, x.co, A.ptr(b["w"]),

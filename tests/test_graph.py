@@ -14,11 +14,11 @@ from oracle import input_ref as IR
 from rangedet_amd import lib as R
 from rangedet_amd import mx, synth
 from rangedet_amd.config import rangedet_veh_wo_aug_4_18e as cfgmod
-from rangedet_amd.lower import lower
+from rangedet_amd.lower import conv_steps, lower
 from rangedet_amd.runtime import Executor
 
 
-def test_config_and_full_graph_lowering():
+def test_config_and_full_graph_lowering(monkeypatch):
     cfg = cfgmod.get_config(False)
     assert len(cfg) == 14
     General, _, RpnParam, _, _, _, ModelParam, _, TestParam = cfg[:9]
@@ -39,6 +39,22 @@ def test_config_and_full_graph_lowering():
     # bf16: the six 1x1 output convs ride in the epilogue of their tower's last conv (lower._fuse_head_out) and the nine
     # 1x1 projection shortcuts in the epilogue of their block's second conv (lower._fusable_projection)
     assert kinds["conv"] == 73 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
+    convs = [s for s, _ in conv_steps(plan.steps) if s["kind"] == "conv"]
+    # RD_PAIR=1 (opt-in): the cls and the reg tower conv i of a level are ONE launch (lower._pair_equal_convs): 24 tower convs = 12
+    # pairs, each pair at the place of its cls conv, nothing else moves
+    monkeypatch.setenv("RD_PAIR", "1")
+    pplan = lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
+    monkeypatch.delenv("RD_PAIR")
+    pk = Counter(s["kind"] for s in pplan.steps)
+    assert pk["conv"] == 49 and pk["conv_pair"] == 12 and pk["deconv"] == 4 and pk["meta"] == 1
+    for s in pplan.steps:
+        if s["kind"] == "conv_pair":
+            na, nb = s["a"]["name"], s["b"]["name"]
+            assert na.startswith("rpn_cls_conv_") and nb == na.replace("rpn_cls_", "rpn_reg_"), (na, nb)
+    order = [s["name"] for s in pplan.steps if s["kind"] == "conv_pair"]
+    assert order[:4] == ["rpn_cls_conv_%d_lvl_0 + rpn_reg_conv_%d_lvl_0" % (i, i) for i in range(4)]
+    assert sorted(s["name"] for s, _ in conv_steps(pplan.steps)) == sorted(s["name"] for s, _ in conv_steps(plan.steps))
+    assert sum(n for _, n in conv_steps(pplan.steps)) == 49 + 12 + 12 and sum(n for _, n in conv_steps(plan.steps)) == 73 + 12
     scs = [s for s in plan.steps if s.get("sc")]
     assert sorted(s["sc"]["name"] for s in scs) == sorted(n + "_unit1_sc" for n in (
         "res1", "res2a", "res2", "res3a", "res3", "agg2_res", "agg2a_res", "agg1_res", "agg3_res"))
@@ -47,7 +63,7 @@ def test_config_and_full_graph_lowering():
     assert all(s["ex"] for s in plan.steps if s["kind"] == "conv" and s["stride_w"] == 2)
     f32_kinds = Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_F32, 1).steps)
     assert f32_kinds["conv"] == 82                                  # fp32 parity mode: every conv is its own launch
-    fused = [s for s in plan.steps if s.get("head")]
+    fused = [s for s in convs if s.get("head")]
     assert sorted(s["name"] for s in fused) == sorted("rpn_%s_conv_3_lvl_%d" % (t, l) for t in ("cls", "reg") for l in range(3))
     assert sorted(s["head"]["nout"] for s in fused) == [1, 1, 1, 8, 8, 8]
     assert Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_F32, 1).steps)["head_out"] == 6   # fp32: separate
@@ -55,7 +71,7 @@ def test_config_and_full_graph_lowering():
     assert [o[0] for o in plan.outputs] == ["input", "flat", "flat", "zeros", "input", "input"]
     assert plan.outputs[1][1].shape == (50000,) and plan.outputs[2][1].shape == (50000, 10)
     macs = 0
-    for s in plan.steps:
+    for s in convs:
         if s["kind"] == "conv":
             macs += s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
             if s.get("sc"):
@@ -637,7 +653,7 @@ def _reduced_symbol(cfg, H, W):
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("dt", [R.RD_BF16, R.RD_F16], ids=["bf16", "f16"])
-def test_e2e_bf16_tolerance(be, dt):
+def test_e2e_bf16_tolerance(be, dt, monkeypatch):
     """16-bit runs of the lowered plan: bf16 (BASELINE config 2) and fp16 (the reference's own mixed-precision type, config:35;
     rounding unit 2^-12 instead of 2^-9, the same error model).
     bf16 run of the lowered plan -- persistent 3x3 kernel incl. the stride-2 pixel-pair view and the
@@ -648,7 +664,7 @@ def test_e2e_bf16_tolerance(be, dt):
     cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
     sym, Cfg = _reduced_symbol(cfg, H, W) if emu else (cfg[6].test_symbol, G.Cfg)
     plan = lower(sym, small_shapes(H, W), dt, 1)
-    assert sum(1 for s in plan.steps if s.get("sc")) == 9 and sum(1 for s in plan.steps if s.get("head")) == 6
+    assert sum(1 for s in plan.steps if s.get("sc")) == 9 and sum(1 for s, _ in conv_steps(plan.steps) if s.get("head")) == 6
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
     fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
     ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
@@ -665,6 +681,21 @@ def test_e2e_bf16_tolerance(be, dt):
         rms, mx = np.sqrt((err ** 2).mean(axis=axes)) / spread, np.abs(err).max(axis=axes) / spread
         print(("bf16" if dt == R.RD_BF16 else "fp16") + " vs fp32 oracle (%s), %s: rms/std %s max/std %s (model rms %.4f)" % (be.name, name, np.round(rms, 4), np.round(mx, 4), model))
         assert np.all(rms < 2.5 * model) and np.all(mx < 6 * 2.5 * model)
+    # RD_PAIR=1: the cls and reg tower convs of a level as one launch each (lower._pair_equal_convs) -- the same numbers, bit for bit
+    # (batch 2: with one frame the reduced graph's low levels have fewer tiles than workgroups)
+    monkeypatch.setenv("RD_PAIR", "1")
+    pplan = lower(sym, small_shapes(H, W), dt, 2)
+    monkeypatch.delenv("RD_PAIR")
+    assert sum(1 for s in pplan.steps if s["kind"] == "conv_pair") == sum(1 for s, _ in conv_steps(plan.steps) if s["name"].startswith("rpn_cls_conv"))
+    fr2 = {kk: np.concatenate([v, IR.make_frame(1, W=Wr, pad_W=W, H=H)[kk]], 0) for kk, v in fr.items()}
+    outs = []
+    for pl in (lower(sym, small_shapes(H, W), dt, 2), pplan):
+        e2 = Executor(pl, P, lib=be.lib, alloc=be.alloc)
+        e2.forward(fr2)
+        sf = [s for s in pl.steps if s["kind"] == "sorted_fg"][0]
+        outs.append((e2.read_flat(sf["score"]).copy(), e2.read_flat(sf["delta"]).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0][0], logit[0])            # (and frame 0 of the batch equals the single-frame run)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

@@ -157,6 +157,74 @@ def test_conv_fused_with_head_out(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(2, 9, 70, 128, True, BF16), (1, 8, 64, 72, False, BF16), (3, 17, 40, 64, True, BF16), (2, 9, 70, 128, True, F16),
+                                  (1, 8, 33, 72, False, F16)])
+def test_conv_pair_equals_two_launches(be, case):
+    """rd_conv3x3_bn_act_pair / rd_conv2d_bn_act_head_out_pair (the cls and reg tower conv of a head level as ONE launch,
+    head/builder.py:221-261) == the two single launches, bit for bit: same tiles, same MFMA order, only the tile list is shared.
+    Shapes: tile lists that cross from problem 0 into problem 1 inside a workgroup, workgroups that START in problem 1 (fewer
+    tiles than resident slots), a shared input (layer 0 of the towers) and separate inputs (layers 1-3)."""
+    B, H, W, cin, shared_x, dt = case
+    rng = np.random.default_rng(11)
+    cs = -(-cin // 16) * 16
+    L = be.lib
+    xs = [h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), dt) for _ in range(2)]
+    if shared_x:
+        xs[1] = xs[0]
+    ws = [h16_round((rng.standard_normal((128, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dt) for _ in range(2)]
+    scs = [rng.uniform(0.5, 1.5, 128).astype(np.float32) for _ in range(2)]
+    shs = [rng.standard_normal(128).astype(np.float32) for _ in range(2)]
+    dx = [be.up(to_nhwc(x, dt, cstride=cs)) for x in xs]
+    if shared_x:
+        dx[1] = dx[0]
+    dw = [be.up(L.pack_conv3x3_ex(w, 1, cs, fold_scale=sc, dtype=dt)) for w, sc in zip(ws, scs)]
+    dsh = [be.up(sh) for sh in shs]
+    fl = R.RD_RELU_POST | R.RD_SCALE_FOLDED
+    nb = B * H * W * 128 * 2
+    ys, yp = [be.empty(nb) for _ in range(2)], [be.empty(nb) for _ in range(2)]
+    for g in range(2):
+        L.call("rd_conv3x3_bn_act_ex", be.ptr(dx[g]), cs, 0, be.ptr(dw[g]), None, be.ptr(dsh[g]), None, 0, 0, None, 0, 0, 0, None,
+               be.ptr(ys[g]), 128, 0, B, H, W, cin, 128, 1, fl, dt, be.stream)
+    L.call("rd_conv3x3_bn_act_pair", be.ptr(dx[0]), 0, be.ptr(dw[0]), be.ptr(dsh[0]), be.ptr(yp[0]), 0,
+           be.ptr(dx[1]), 0, be.ptr(dw[1]), be.ptr(dsh[1]), be.ptr(yp[1]), 0, cs, 128, B, H, W, cin, fl, dt, be.stream)
+    for g in range(2):
+        a, b = be.down(ys[g], np.uint16, (B, H, W, 128)), be.down(yp[g], np.uint16, (B, H, W, 128))
+        assert np.abs(from_nhwc(a, dt, 128)).max() > 0.5
+        assert np.array_equal(a, b), (g, int((a != b).sum()))
+    # torch fp32 reference of problem 1 (the single launch is checked against it elsewhere; this pins the pair on its own)
+    ref = F.conv2d(torch.from_numpy(xs[1]), torch.from_numpy(ws[1]), padding=1).numpy() * scs[1][None, :, None, None] + shs[1][None, :, None, None]
+    ref = np.maximum(ref, 0)
+    got = from_nhwc(be.down(yp[1], np.uint16, (B, H, W, 128)), dt, 128)
+    assert np.abs(got - ref).max() <= 3 * _ulp(dt) * max(1.0, float(np.abs(ref).max()))   # (folded scale: w*s is rounded, not w)
+    # the towers' last convs with their 1x1 output convs: logits (1 output) and deltas (8 outputs) of one level
+    nouts = (1, 8)
+    hws = [(rng.standard_normal((n, 128)) / np.sqrt(128)).astype(np.float32) for n in nouts]
+    hbs = [rng.standard_normal(n).astype(np.float32) for n in nouts]
+    dhp = [be.up(L.pack_head_weight(hw, dtype=dt)) for hw in hws]
+    dhb = [be.up(hb) for hb in hbs]
+    N, off = H * W + 29, 13
+    os_, op = [be.empty(B * N * n * 4) for n in nouts], [be.empty(B * N * n * 4) for n in nouts]
+    for g in range(2):
+        L.call("rd_conv2d_bn_act_head_out", be.ptr(dx[g]), cs, 0, be.ptr(dw[g]), None, be.ptr(dsh[g]), B, H, W, cin, fl,
+               be.ptr(dhp[g]), be.ptr(dhb[g]), be.ptr(os_[g]), N * nouts[g], off, nouts[g], dt, be.stream)
+    L.call("rd_conv2d_bn_act_head_out_pair",
+           be.ptr(dx[0]), 0, be.ptr(dw[0]), be.ptr(dsh[0]), be.ptr(dhp[0]), be.ptr(dhb[0]), be.ptr(op[0]), N * nouts[0], nouts[0],
+           be.ptr(dx[1]), 0, be.ptr(dw[1]), be.ptr(dsh[1]), be.ptr(dhp[1]), be.ptr(dhb[1]), be.ptr(op[1]), N * nouts[1], nouts[1],
+           cs, off, B, H, W, cin, fl, dt, be.stream)
+    for g in range(2):
+        a, b = be.down(os_[g], np.float32, (B, N, nouts[g])), be.down(op[g], np.float32, (B, N, nouts[g]))
+        assert np.abs(a[:, off:off + H * W]).max() > 0.3
+        assert np.array_equal(a, b), (g, float(np.abs(a - b).max()))
+        assert (b[:, :off] == 0).all() and (b[:, off + H * W:] == 0).all()
+    buf = be.ptr(be.empty(1 << 16))
+    f = L.raw("rd_conv3x3_bn_act_pair")
+    assert f(buf, 0, buf, buf, buf, 0, buf, 0, buf, buf, buf, 0, 128, 128, 1, 4, 8, 128, R.RD_RELU_POST, dt, be.stream) == R.RD_EINVAL      # not folded
+    assert f(buf, 0, buf, buf, buf, 0, buf, 0, buf, None, buf, 0, 128, 128, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_EINVAL               # null shift
+    assert f(buf, 0, buf, buf, buf, 64, buf, 0, buf, buf, buf, 0, 128, 128, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_ESHAPE               # y channels
+    assert f(buf, 0, buf, buf, buf, 0, buf, 0, buf, buf, buf, 0, 128, 128, 1, 4, 8, 128, fl, F32, be.stream) == R.RD_EINVAL
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 10, 128, 64, (3, 8), 4, 2), (BF16, 1, 2, 20, 128, 128, (3, 8), 4, 2),
                                   (F32, 2, 2, 13, 64, 64, (3, 4), 2, 1), (BF16, 1, 3, 24, 128, 64, (3, 4), 2, 1),
                                   (F16, 1, 2, 20, 128, 128, (3, 8), 4, 2), (F16, 1, 3, 24, 128, 64, (3, 4), 2, 1)])

@@ -35,7 +35,12 @@ for i, st in enumerate(pipe.plan.steps):
     k = st["kind"]
     fl = 0.0
     desc = ""
-    if k in ("conv", "deconv"):
+    if k == "conv_pair":   # two tower convs of one shape in one launch
+        a = st["a"]
+        o = a["out"]
+        fl = 2 * B * 2.0 * o.H * o.W * a["cin"] * a["cout"] * 9
+        desc = "%s %d->%d x2 W%d" % (st["name"].replace("rpn_", "").replace("_conv", ""), a["cin"], a["cout"], o.W)
+    elif k in ("conv", "deconv"):
         o = st["out"]
         fl = B * 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
         desc = "%s %d->%d k%s W%d->%d s%d" % (st["name"], st["cin"], st["cout"], st["k"], st["x"].W, o.W, st["stride_w"])
@@ -49,7 +54,11 @@ for i, st in enumerate(pipe.plan.steps):
     # report: 8 x 32 tiles (RD_CONV_WIDE=0: 8 x 30) with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
     # a stride-2 conv runs on the pixel-pair view = its output grid, a transposed conv phase on its input grid)
     tps = ""
-    if dt in rdlib.H16 and k in ("conv", "deconv") and st["k"][0] == 3:
+    if dt in rdlib.H16 and k == "conv_pair":
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        ntiles = 2 * -(-st["out"].W // 32) * -(-st["out"].H // 8) * B
+        tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, 2 * cus, ntiles / (2 * cus))
+    elif dt in rdlib.H16 and k in ("conv", "deconv") and st["k"][0] == 3:
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         Wt = st["x"].W if k == "deconv" else st["out"].W
         wide_head = bool(st.get("head")) and Wt > 1400
