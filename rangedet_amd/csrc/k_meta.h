@@ -39,6 +39,7 @@ __host__ __device__ inline MetaLayout meta_layout(int dt) {
   L.total = L.w0f + (h ? 1024 : 0);
   return L;
 }
+constexpr int META_CENTRE_TAP = 4;   // (dh, dw) = (0, 0)
 inline int meta_perm(int blk, int m) {  // MFMA row m of 32-block blk -> channel
   return 32 * blk + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
 }
@@ -92,7 +93,13 @@ inline void pack_meta(const float* w0, const float* b0, const float* w1, const f
   float* ft1 = (float*)(base + L.t1);
   for (int k = 0; k < 9; ++k)
     for (int c = 0; c < 64; ++c) {
-      fb1[k * 64 + c] = s1[c * 9 + k] * b1[c];
+      // Centre tap (k = 4): rel = coord[p] - coord[p] = 0 for every pixel, so its hidden vector is relu(b0) and its dynamic
+      // weight W1 relu(b0) + b1 is a per-channel CONSTANT (meta_kernel.py:193-214 evaluates the MLP on zeros there).  It is
+      // folded into the tap's bias slot here (double precision) and the kernels skip both MLP layers of that tap.
+      double w = b1[c];
+      if (k == META_CENTRE_TAP)
+        for (int j = 0; j < 32; ++j) w += (double)w1[c * 32 + j] * (double)(b0[j] > 0.f ? b0[j] : 0.f);
+      fb1[k * 64 + c] = (float)((double)s1[c * 9 + k] * w);
       ft1[k * 64 + c] = t1[c * 9 + k];
     }
   float* fw0 = (float*)(base + L.w0p);
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) d1[mt][4 * g + e] = bq[e];
         }
+      if (k != META_CENTRE_TAP)   // (centre tap: the dynamic weight is the constant already in d1, see pack_meta)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
     commit();
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);   // in flight during this tile's math
+    // (issuing it at tap 3 instead -- 214 instead of 240 registers -- changes nothing: 272 vs 272 us, gpurun_out/r3zg)
 
     const int h = h0 + wv, w = w0 + px;
     const bool live = (h < a.H) && (w < a.W);
@@ -409,9 +418,14 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
       constexpr int dummy = 0; (void)dummy;
       const int dh = k / 3 - 1, dw = k % 3 - 1;
       const int pl = pl0 + dh * HC + dw;
+      // (centre tap: rel = 0 for every pixel, the dynamic weight is the per-channel constant pack_meta put into the bias slot:
+      //  no hidden layer, no MFMA #1 -- 5 of the 117 MFMAs and ~30 of the ~1000 vector instructions of a pixel fragment)
+      const bool centre = k == META_CENTRE_TAP;
+      f32x16 pre = f32x16{};
+      s16x8 hfrag[2] = {};
+      if (!centre) {
       const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
       // MFMA #0: pre[j][px] = W0[j][0..2] . rel + b0[j], one bf16 MFMA on high / low split operands (~fp32 accurate)
-      f32x16 pre;
       {
         const unsigned hxy = HT::pk(r0, r1), hz1 = HT::pk(r2, 1.0f);
         const f32x2 uxy = HT::unpk(hxy), uz1 = HT::unpk(hz1);
@@ -424,7 +438,6 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
         pre = HT::mfma(w0frag, b0frag, f32x16{});
       }
       // hidden vector as the two B fragments of MFMA #1 (ReLU on the packed pairs: negative bf16 = negative int16)
-      s16x8 hfrag[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         unsigned pk[4];
@@ -434,6 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
           pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
         }
         memcpy(&hfrag[ks], pk, 16);
+      }
       }
       const unsigned char* hp = halo + pl * PXB;
       const int swz = (pl >> 1) & 7;
@@ -447,10 +461,12 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) d1[4 * q + e] = bq[e];
         }
+        if (!centre) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const s16x8 af = *(const s16x8*)(w1l + ((k * 2 + mt) * 2 + ks) * 1024);
           d1 = HT::mfma(af, hfrag[ks], d1);
+        }
         }
         // element-wise: a = relu(data[p+d] * d1 + t1), channels 32mt+16hi+r of the neighbour pixel (from the halo)
 #pragma unroll

@@ -683,6 +683,8 @@ def test_e2e_bf16_tolerance(be, dt, monkeypatch):
         assert np.all(rms < 2.5 * model) and np.all(mx < 6 * 2.5 * model)
     # RD_PAIR=1: the cls and reg tower convs of a level as one launch each (lower._pair_equal_convs) -- the same numbers, bit for bit
     # (batch 2: with one frame the reduced graph's low levels have fewer tiles than workgroups)
+    if emu and dt != R.RD_BF16:
+        return                                                  # (CPU tier: once, in bf16)
     monkeypatch.setenv("RD_PAIR", "1")
     pplan = lower(sym, small_shapes(H, W), dt, 2)
     monkeypatch.delenv("RD_PAIR")

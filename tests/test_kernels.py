@@ -160,6 +160,8 @@ def test_conv_fused_with_head_out(be, case):
 @pytest.mark.parametrize("case", [(2, 9, 70, 128, True, BF16), (1, 8, 64, 72, False, BF16), (3, 17, 40, 64, True, BF16), (2, 9, 70, 128, True, F16),
                                   (1, 8, 33, 72, False, F16)])
 def test_conv_pair_equals_two_launches(be, case):
+    if be.name == "emu" and case[:3] in ((3, 17, 40), (2, 9, 70)) and case[5] == F16:
+        pytest.skip("CPU tier: the fp16 forms of the larger shapes run on the GPU only (emulator time)")
     """rd_conv3x3_bn_act_pair / rd_conv2d_bn_act_head_out_pair (the cls and reg tower conv of a head level as ONE launch,
     head/builder.py:221-261) == the two single launches, bit for bit: same tiles, same MFMA order, only the tile list is shared.
     Shapes: tile lists that cross from problem 0 into problem 1 inside a workgroup, workgroups that START in problem 1 (fewer
