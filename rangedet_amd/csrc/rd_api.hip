@@ -646,7 +646,11 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
     scan(nb1, nb, w.supp_state);
   }
   allow_big_lds(wnms_merge_kernel);
-  const int lds_cap = std::min(Kcap + 2, e_ml ? std::max(4, e_ml) : 16384);
+  // neighbourhood list of a kept row: 2 048 entries (16 KB) in LDS -- the lists are a few dozen entries long; a frame with more
+  // candidates than that counts each row's list first and sends the rare longer one through the global-scratch kernel.  (With the
+  // former 16 384 entries every single-wave workgroup asked for 65 KB: in the pipeline, where the conv workgroups hold 2 x 80 KB
+  // per CU, the merge took 80 us instead of 21; +0.3 % frames/s)
+  const int lds_cap = std::min(Kcap + 2, e_ml ? std::max(4, e_ml) : 2048);
   hipLaunchKernelGGL(wnms_merge_kernel, dim3(std::min(Kcap, 4096), 1, B), dim3(64), (size_t)lds_cap * 8, st, dets, ord, w.vote,
                      w.snap, Kcap, d_count, w.nwcap, w.keep_q, d_nkeep, out_dets, bs, lds_cap, w.ovf, w.novf);
   if (Kcap + 2 > lds_cap)
