@@ -8,6 +8,8 @@
  *   rd_conv2d_bn_act          mx.sym.Convolution + BatchNorm (+ReLU, +residual)   mxnext/simple.py:123-158,
  *                             mxnext/complicate.py:26-45, dla_backbone.py:18-56, head/builder.py:221-240
  *   rd_conv3x3_bn_act_ex      BasicBlock conv2 (+ stride (1,2), + projection shortcut)   dla_backbone.py:18-56,139-143
+ *   rd_conv3x3_bn_act_pair,   the cls and the reg tower conv i of a head level in ONE launch (the last pair with the towers'
+ *   rd_conv2d_bn_act_head_out_pair   1x1 output convs)                            head/builder.py:221-261
  *   rd_deconv2d_bn_act        mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
  *                             dla_backbone.py:117-127
  *   rd_head_out               1x1 logit / delta convs + cast + per-class flatten  head/builder.py:242-261,99-154
