@@ -1,0 +1,211 @@
+"""Tight on-hardware parity of EVERY production 16-bit launch at the production geometry.
+
+The unit tests of test_kernels.py run the persistent 3x3 kernel / the Meta-Kernel at sizes where every workgroup owns one
+tile.  This test runs the real lowered plan of rangedet_veh_wo_aug_4_18e at B = 8, 64 x 2656 -- 5 312 tiles on 512 resident
+slots at full width, the 83rd column tile, the W = 1328 / 664 / 332 layers, the 0.75-tile-per-slot W = 166 launches, the
+stride-2 pixel-pair views, the fused projection shortcuts, every transposed-conv phase, the 160-byte-pitch concat buffer, the
+fused tower output convs on both tile shapes and the Meta-Kernel's register prefetch of the next tile -- ONE PLAN STEP AT A
+TIME: the step's actual device inputs are read back (exact: they are 16-bit values), the layer is recomputed by PyTorch-CPU in
+fp32 from those inputs and the SAME 16-bit weights the packer makes (folded BatchNorm scale, dla_backbone.py:18-56,117-127;
+mxnext/complicate.py:26-45), and the device output must agree PER ELEMENT to one rounding of the output type
+(|got - ref| <= 2^-8 |ref| for bf16, 2^-11 for fp16, plus fp32 summation-order noise).  The Meta-Kernel step is checked
+against oracle/graph_ref.meta_kernel_unit (meta_kernel.py:166-240) with test_meta_kernel_unit's error model.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import HIP_ONLY
+from oracle import graph_ref as G
+from oracle import input_ref as IR
+from rangedet_amd import lib as R
+from rangedet_amd import synth
+from rangedet_amd.lower import TRef
+from rangedet_amd.runtime import bn_affine
+
+BF16, F16 = R.RD_BF16, R.RD_F16
+
+
+def _round_t(t, dt):
+    """torch float32 -> rounded to the 16-bit type -> float32 (multi-threaded; numpy's astype is single-threaded)."""
+    return t.to(torch.bfloat16 if dt == BF16 else torch.float16).to(torch.float32)
+
+
+def _expand(w, cmap):
+    """logical input channels -> the physical channels of a concat buffer with alignment padding (runtime.Executor._bind)."""
+    if not cmap:
+        return w
+    wp = np.zeros((w.shape[0], len(cmap)) + w.shape[2:], np.float32)
+    for pc, lc in enumerate(cmap):
+        if lc >= 0:
+            wp[:, pc] = w[:, lc]
+    return wp
+
+
+class _Host:
+    """Host copies (NCHW float32 torch tensors) of the plan's activation buffers, keyed by logical buffer: every TRef is
+    written by the steps that name it as `out`, so one download per produced tensor instead of one per use."""
+
+    def __init__(self, exe, plan):
+        self.exe, self.cache = exe, {}
+        self.last = {}
+        for i, st in enumerate(plan.steps):
+            for v in st.values():
+                if isinstance(v, TRef):
+                    self.last[v.buf] = i
+
+    def get(self, ref, fresh=False):
+        key = (ref.buf, ref.co, ref.C)
+        if fresh or key not in self.cache:
+            self.cache[key] = torch.from_numpy(np.ascontiguousarray(self.exe.debug_tensor(ref)))
+        return self.cache[key]
+
+    def retire(self, i):
+        for key in [k for k in self.cache if self.last.get(k[0], -1) <= i]:
+            del self.cache[key]
+
+    def invalidate(self, ref):
+        for key in [k for k in self.cache if k[0] == ref.buf]:
+            del self.cache[key]
+
+
+def _check(name, got, ref, dt, report, extra_abs=0.0):
+    """per-element: one rounding of the output type (half an ulp <= 2^-8 |v| for bf16's 8 significant bits, 2^-11 |v| for
+    fp16's 11) + fp32 summation-order noise (1e-5 of the largest value; the BatchNorm shift enters the accumulators as a
+    16-bit hi + lo pair: 2^-17 of the shift in bf16 mode, passed as extra_abs)"""
+    u = 2.0 ** -8 if dt == BF16 else 2.0 ** -11
+    scale = float(ref.abs().max())
+    tol = u * ref.abs() + (1e-5 * max(1.0, scale) + extra_abs)
+    err = (got - ref).abs()
+    bad = err > tol
+    nbad = int(bad.sum())
+    worst = float((err / tol).max())
+    report.append((name, tuple(ref.shape), worst, nbad))
+    return nbad == 0
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "f16"])
+def test_every_production_launch_tight_at_full_geometry(be, dt):
+    from rangedet_amd.pipeline import RangeDetPipeline
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    t00 = time.time()
+    B = 8
+    P = synth.make_weights(seed=18)
+    pipe = RangeDetPipeline(P, dtype=dt, batch=B, wnms_cap=4096, lib=be.lib, alloc=be.alloc)
+    plan, exe = pipe.plan, pipe.exe
+    fr = IR.make_batch(list(range(B)))
+    dev = {}
+    host = _Host(exe, plan)
+    report, failed = [], []
+    seen_forms = set()
+    for i, st in enumerate(plan.steps):
+        k = st["kind"]
+        if k not in ("conv", "deconv", "meta"):
+            exe.forward(fr, only=i, dev=dev)
+            if isinstance(st.get("out"), TRef):
+                host.invalidate(st["out"])
+            continue
+        x = host.get(st["x"])
+        res = host.get(st["res"]) if st.get("res") is not None else None
+        sx = host.get(st["sc_x"]) if st.get("sc_x") is not None else None
+        exe.forward(fr, only=i, dev=dev)
+        if isinstance(st.get("out"), TRef):
+            host.invalidate(st["out"])
+        name = st.get("name", "meta unit")
+        if k == "meta":
+            coord = torch.from_numpy(np.ascontiguousarray(fr[st["coord"]], dtype=np.float32))
+            got = host.get(st["out"], fresh=True)
+            refs = [G.meta_kernel_unit(x[b:b + 1], coord[b:b + 1], P, "res1_unit2") for b in range(B)]
+            ref = torch.cat(refs, 0)
+            u = 2.0 ** -9 if dt == BF16 else 2.0 ** -12
+            rel = u * np.sqrt(4.0 / 3.0)
+            err = got - ref
+            rms = float(err.std() / ref.std())
+            tol = 6 * 2.0 * rel * float(ref.std()) + u * float(ref.abs().max()) + 1e-4
+            worst = float(err.abs().max()) / tol
+            report.append((name, tuple(ref.shape), worst, int((err.abs() > tol).sum())))
+            if not (rms < 2.0 * rel and worst <= 1.0):
+                failed.append(name + " (rms/std %.5f vs model %.5f)" % (rms, rel))
+            host.retire(i)
+            continue
+        cout = st["cout"]
+        s, t = bn_affine(P, st["bn"], st["eps"])
+        if k == "deconv":
+            assert st.get("fold"), "production deconvs carry the folded scale"
+            w = np.asarray(P[name + "_weight"], np.float32)                       # (cin, cout, kh, kw)
+            wq = _round_t(torch.from_numpy(w * s[None, :, None, None]), dt)
+            y = F.conv_transpose2d(x, wq, stride=(1, st["stride_w"]), padding=(1, st["pad_w"]))
+            y = y + torch.from_numpy(t)[None, :, None, None]
+            assert st["flags"] == (R.RD_RELU_PRE | R.RD_ADD)
+            ref = torch.relu(y) + res
+            got = host.get(st["out"], fresh=True)
+            form = ("deconv", st["cin"], cout, x.shape[3], st["stride_w"])
+        else:
+            assert st.get("ex") and st.get("fold"), "production 16-bit convs are 3x3 with the folded scale"
+            w = _expand(np.asarray(P[name + "_weight"], np.float32), st.get("cmap"))
+            wq = _round_t(torch.from_numpy(w * s[:, None, None, None]), dt)
+            y = F.conv2d(x, wq, stride=(1, st["stride_w"]), padding=1)
+            shift = t.astype(np.float64)
+            if st.get("sc"):
+                sc = st["sc"]
+                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(cout, -1)
+                wsc = _expand(wsc, sc.get("cmap"))
+                ss, ts = bn_affine(P, sc["bn"], sc["eps"])
+                wscq = _round_t(torch.from_numpy(wsc * ss[:, None]), dt)
+                y = y + F.conv2d(sx, wscq[:, :, None, None], stride=(1, st["stride_w"]))
+                shift = shift + ts
+            y = y + torch.from_numpy(shift.astype(np.float32))[None, :, None, None]
+            fl = st["flags"]
+            if fl & R.RD_RELU_PRE:
+                y = torch.relu(y)
+            if res is not None:
+                y = y + res
+            if fl & R.RD_RELU_POST:
+                y = torch.relu(y)
+            form = ("conv", st["cin"], cout, x.shape[3], st["stride_w"], bool(st.get("sc")), res is not None, bool(st.get("head")),
+                    st["out"].cs if isinstance(st.get("out"), TRef) else 0)
+            if st.get("head"):
+                # the tower's last conv + its 1x1 output conv in one launch: the 128-channel activation is rounded to the type,
+                # then out = W . act + bias with fp32-accurate weights (hi + lo pair); head/builder.py:242-255
+                h = st["head"]
+                r0, r1 = h["rows"]
+                hw = torch.from_numpy(np.asarray(P[h["name"] + "_weight"], np.float32).reshape(-1, cout)[r0:r1].copy())
+                hb = torch.from_numpy(np.asarray(P[h["name"] + "_bias"], np.float32)[r0:r1].copy())
+                act = _round_t(y, dt)
+                ref = torch.einsum("oc,bchw->bhwo", hw, act).reshape(B, -1, r1 - r0) + hb
+                flat = torch.from_numpy(exe.read_flat(h["out"]))
+                flat = flat.reshape(B, h["N"], -1)
+                got = flat[:, h["n_off"]:h["n_off"] + x.shape[2] * x.shape[3]]
+                # an activation within fp32 noise of a rounding boundary may round the other way: one unit of the activation
+                # times its weight -- a few such flips per output at most
+                u = 2.0 ** -8 if dt == BF16 else 2.0 ** -11
+                extra = 4 * u * float(act.abs().max()) * float(hw.abs().max())
+                err = (got - ref).abs()
+                tol = 1e-5 * max(1.0, float(ref.abs().max())) + extra
+                worst = float(err.max()) / tol
+                report.append((name + " + " + h["name"], tuple(ref.shape), worst, int((err > tol).sum())))
+                if worst > 1.0:
+                    failed.append(name)
+                seen_forms.add(form)
+                host.retire(i)
+                continue
+            ref = y
+            got = host.get(st["out"], fresh=True)
+        seen_forms.add(form)
+        shift_err = 2.0 ** -16 * float(np.abs(t).max()) if dt == BF16 else 0.0
+        if not _check(name, got, ref, dt, report, extra_abs=shift_err):
+            failed.append(name)
+        host.retire(i)
+    dtn = "bf16" if dt == BF16 else "fp16"
+    print("\nper-step tight parity at B = 8, 64 x 2656, %s (worst |err| / tolerance, elements over):" % dtn)
+    for name, shape, worst, nbad in report:
+        print("  %-44s %-22s %.3f  %d" % (name, "x".join(str(v) for v in shape), worst, nbad))
+    print("%d distinct launch forms, %d steps checked, %.0f s" % (len(seen_forms), len(report), time.time() - t00))
+    kinds = [s["kind"] for s in plan.steps]
+    assert len(report) == kinds.count("conv") + kinds.count("deconv") + kinds.count("meta") == 78
+    assert not failed, failed
