@@ -72,6 +72,36 @@ class _Host:
             del self.cache[key]
 
 
+def _meta_ref_and_sigma(data, coord, P, name, u):
+    """oracle/graph_ref.meta_kernel_unit (meta_kernel.py:166-240 + dla_backbone.py:92-97) for ONE image, restated here only to
+    also return the per-element standard deviation the 16-bit Meta-Kernel's roundings imply (u = half an ulp of the type):
+      h (32 hidden units) and s1*W1 are rounded            -> var(w_c)  = u^2/3 * 2 * sum_j (W1_cj h_j)^2
+      a = relu(s1 d w + t1) is rounded                      -> var(a)    = (s1 d)^2 var(w_c) + u^2/3 a^2
+      A (576 -> 64) is rounded                              -> var(pre)  = sum A^2 var(a) + u^2/3 sum (A a)^2
+      y = relu(s2 pre + t2)                                 -> sigma_y   = |s2| sqrt(var(pre))     (the output rounding is added by the caller)
+    The relative coordinates / the 3 -> 32 layer are fp32-accurate on the device (hi + lo split operands)."""
+    B, C, H, W = data.shape
+    pre_, Wn = name + "_", str(W)
+    T = G.T
+    cs = F.unfold(coord, 3, padding=1).view(B, 3, 9, H, W)
+    rel = (cs - coord.unsqueeze(2)).reshape(B, 3, 9 * H, W)
+    h = F.relu(F.conv2d(rel, T(P[pre_ + Wn + "_mlp0_weight"]), T(P[pre_ + Wn + "_mlp0_bias"])))
+    W1 = T(P[pre_ + Wn + "_mlp1_weight"])
+    wts = F.conv2d(h, W1, T(P[pre_ + Wn + "_mlp1_bias"])).view(B, 64, 9, H, W)
+    t1q = F.conv2d(h * h, W1 * W1).view(B, 64, 9, H, W)                  # sum_j (W1_cj h_j)^2
+    ds = F.unfold(data, 3, padding=1).view(B, C, 9, H, W)
+    s1, t1 = (torch.from_numpy(v) for v in bn_affine(P, name + "point_wise_mlp_bn1", G.EPS))
+    s2, t2 = (torch.from_numpy(v) for v in bn_affine(P, name + "aggregation_bn1", G.EPS))
+    a = F.relu((ds * wts).reshape(B, C * 9, H, W) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1))
+    q = u * u / 3.0
+    var_a = (ds.reshape(B, C * 9, H, W) * s1.view(1, -1, 1, 1)) ** 2 * (2.0 * q) * t1q.reshape(B, C * 9, H, W) + 2.0 * q * a * a
+    A = T(P[name + "aggregation_conv1_weight"])
+    pre = F.conv2d(a, A)
+    var = F.conv2d(var_a, A * A)                                        # (the A-rounding term is the second q a^2 above)
+    y = F.relu(pre * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
+    return y, s2.abs().view(1, -1, 1, 1) * var.sqrt()
+
+
 def _check(name, got, ref, dt, report, extra_abs=0.0):
     """per-element: one rounding of the output type (half an ulp <= 2^-8 |v| for bf16's 8 significant bits, 2^-11 |v| for
     fp16's 11) + fp32 summation-order noise (1e-5 of the largest value; the BatchNorm shift enters the accumulators as a
@@ -120,17 +150,26 @@ def test_every_production_launch_tight_at_full_geometry(be, dt):
         if k == "meta":
             coord = torch.from_numpy(np.ascontiguousarray(fr[st["coord"]], dtype=np.float32))
             got = host.get(st["out"], fresh=True)
-            refs = [G.meta_kernel_unit(x[b:b + 1], coord[b:b + 1], P, "res1_unit2") for b in range(B)]
-            ref = torch.cat(refs, 0)
             u = 2.0 ** -9 if dt == BF16 else 2.0 ** -12
-            rel = u * np.sqrt(4.0 / 3.0)
-            err = got - ref
-            rms = float(err.std() / ref.std())
-            tol = 6 * 2.0 * rel * float(ref.std()) + u * float(ref.abs().max()) + 1e-4
-            worst = float(err.abs().max()) / tol
-            report.append((name, tuple(ref.shape), worst, int((err.abs() > tol).sum())))
-            if not (rms < 2.0 * rel and worst <= 1.0):
-                failed.append(name + " (rms/std %.5f vs model %.5f)" % (rms, rel))
+            zmax, zsq, n, nover = 0.0, 0.0, 0, 0
+            for b in range(B):
+                ref, sig = _meta_ref_and_sigma(x[b:b + 1], coord[b:b + 1], P, "res1_unit2", u)
+                # the unit test's model (test_meta_kernel_unit), evaluated PER ELEMENT: sigma = the quadrature sum of the independent
+                # 16-bit roundings inside the 576-term contraction, + one rounding of the output.  The rounding of a hidden unit enters
+                # all 64 dynamic weights of its tap COHERENTLY, which the quadrature sum does not model: the tail is heavier than a
+                # Gaussian's (9 sigma seen on 5e4 elements of the emulator build), so: rms within 1.5x the model, at most 1e-4 of the
+                # elements beyond 7 sigma, none beyond 28 sigma (a mis-addressed halo pixel is an error of >= 100 sigma)
+                tol = 7.0 * sig + u * ref.abs() + 1e-5
+                err = (got[b:b + 1] - ref).abs()
+                z = err / tol
+                zmax = max(zmax, float(z.max()))
+                nover += int((z > 1.0).sum())
+                zsq += float(((got[b:b + 1] - ref) ** 2 / (sig ** 2 + (u * ref.abs()) ** 2 / 3 + 1e-12)).sum())
+                n += ref.numel()
+            zr = np.sqrt(zsq / n)
+            report.append((name + " (rms err / model sigma %.2f; > 7 sigma: %d)" % (zr, nover), tuple(got.shape), zmax / 4.0, int(zmax > 4.0)))
+            if not (zr < 1.5 and nover <= 1e-4 * n and zmax <= 4.0):
+                failed.append(name + " (rms err / model sigma %.3f, worst |err| / (7 sigma) %.3f, %d of %d beyond 7 sigma)" % (zr, zmax, nover, n))
             host.retire(i)
             continue
         cout = st["cout"]
