@@ -10,8 +10,8 @@
  *   rd_conv3x3_bn_act_ex      BasicBlock conv2 (+ stride (1,2), + projection shortcut)   dla_backbone.py:18-56,139-143
  *   rd_conv3x3_bn_act_pair,   the cls and the reg tower conv i of a head level in ONE launch (the last pair with the towers'
  *   rd_conv2d_bn_act_head_out_pair   1x1 output convs)                            head/builder.py:221-261
- *   rd_deconv2d_bn_act        mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
- *                             dla_backbone.py:117-127
+ *   rd_deconv2d_bn_act,       mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
+ *   rd_deconv2d_bn_act_all    (one call per output phase / all phases in one launch)  dla_backbone.py:117-127
  *   rd_head_out               1x1 logit / delta convs + cast + per-class flatten  head/builder.py:242-261,99-154
  *   rd_sorted_foreground      Custom op 'get_sorted_foreground'                   operator_py/get_sorted_foreground.py:11-40
  *   rd_decode3d_bbox          _contrib_Decode3DBbox                               operator_cxx/contrib/decode_3d_bbox-inl.h:169-305
@@ -161,12 +161,33 @@ int rd_conv2d_bn_act_head_out_pair(const void* x0, int x0_coff, const void* w0_p
                                    const float* head_bias1, float* out1, long out1_batch_stride, int nout1,
                                    int x_cstride, long n_off, int B, int H, int W, int cin, int flags, int dtype, void* stream);
 
+/* 3x3 stride-1 conv + BatchNorm (+ReLU) over the channel concatenation [x1 (cin1, a multiple of 32) | x2 (cin2, a multiple of 8)]
+ * of two tensors of the same B x H x W -- the concat itself (mx.sym.concat of the range image with the agg3 feature map,
+ * dla_backbone.py:153-154, consumed by the level-0 tower convs head/builder.py:221-240) is never written: each tensor keeps its own
+ * channel stride.  16-bit types, RD_SCALE_FOLDED weights: w_packed = rd_pack_conv3x3_ex_host of the (cout, cin1 + cin2, 3, 3) weight
+ * in that channel order, stride 1.  No residual. */
+int rd_conv3x3_bn_act_cat(const void* x1, int x1_cstride, int x1_coff, int cin1, const void* x2, int x2_cstride, int x2_coff, int cin2,
+                          const void* w_packed, const float* shift, void* y, int y_cstride, int y_coff, int B, int H, int W, int cout,
+                          int flags, int dtype, void* stream);
+
 /* Transposed conv, kernel (3,kw), stride (1,stride_w), pad (1,pad_w); one call per output phase. */
 int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed_phase,
                        const float* scale, const float* shift, const void* residual, int r_cstride,
                        int r_coff, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
                        int cout, int kh, int kw, int stride_w, int pad_w, int phase, int flags, int dtype,
                        void* stream);
+
+/* The same transposed conv, ALL stride_w output phases in ONE launch (16-bit types, RD_SCALE_FOLDED weights): the tile list is
+ * (tile, phase) with a tile's phases computed back to back by one workgroup, so the input is read from HBM once instead of once
+ * per phase launch (mx.sym.Deconvolution + BatchNorm + ReLU + add, mxnext/simple.py:545-580, dla_backbone.py:117-127).
+ * w_packed_all: the stride_w images of rd_pack_deconv_weight_folded_host, phase p at byte offset p * w_phase_bytes.
+ * rd_deconv2d_all_phases_ok: 1 if this (kernel, stride, pad, cout, dtype) can run in that form -- every phase a 3 x 2 tap set
+ * inside the 3 x 3 window and Wout == stride_w * Win, which k(3,8) s4 p2 and k(3,4) s2 p1 are -- else 0 (call per phase). */
+int rd_deconv2d_all_phases_ok(int kh, int kw, int stride_w, int pad_w, int cout, int dtype);
+int rd_deconv2d_bn_act_all(const void* x, int x_cstride, int x_coff, const void* w_packed_all, long w_phase_bytes,
+                           const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                           int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                           int flags, int dtype, void* stream);
 
 /* 1x1 conv with bias to nout <= 8 float32 outputs per pixel, written flattened: out[(n_off + h*W + w)*nout + o]
  * (== the (B, N, nout) tensor after sep_level_type's reshape/transpose/concat; nout == 1 gives (B, N)).

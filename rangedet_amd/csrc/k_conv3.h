@@ -49,6 +49,19 @@ struct Conv3Args {
   int ngrp;                  // 1 or 2
   long g_x, g_res, g_y, g_w, g_shift, g_hw, g_hb, g_ho, g_ho_bs;
   int g_hn;
+  // PH variant (TS == 3): ALL phases of a transposed conv in one launch (dla_backbone.py:117-127, mxnext/simple.py:545-580).  The
+  // tile list is (spatial tile, phase) with the phase running fastest inside a workgroup's list, so the nph phases of a tile are
+  // computed back to back by one workgroup: its halo comes from HBM once (the re-fetches of the other phases hit L2) instead of
+  // once per phase launch, and a small layer (W = 166: 384 tiles on 512 slots) gets nph times the work per resident slot.
+  // Phase ph uses weight image w + ph * w_pb, the two-column tap set 1 (dw in {-1, 0}) or 2 (dw in {0, +1}) by bit ph of ts_mask,
+  // and writes / reads channels y_co + ph * y_pc (residual: r_co + ph * r_pc) of the output seen as [H][W][nph * C].
+  int nph, ts_mask, y_pc, r_pc;
+  long w_pb;
+  // Two-tensor input (8 x 32 tiles only): the conv runs over the channel concatenation [x (nchunk1 32-channel chunks) | x2] without
+  // that tensor ever existing -- dla_backbone.py:153-154 concatenates the 8-channel range image with the 64 agg3 channels, and a
+  // shared 80-channel buffer gives the agg3 producer a 160-byte pixel pitch (every 128-byte row it stores straddles two cache
+  // lines).  Chunk c >= nchunk1 is chunk c - nchunk1 of x2 (same H, W; its own channel stride / offset / slot count).
+  const bf16_t* x2; int x2_cs, x2_co, nchunk1, nslots2; long x2_bs;
 };
 
 // Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
@@ -152,6 +165,8 @@ inline void pack_sc_frag(const float* w, const float* scale, int cin, int cout, 
 // Tap sets.  TS = 0: all nine taps (convs).  A transposed-conv phase only has taps in two of the three columns:
 // TS = 1 -> dw in {-1, 0}, TS = 2 -> dw in {0, +1}; its unit is 6 steps instead of 9 (no MFMAs on zero weights).
 constexpr int c3_nsteps(int TS) { return TS == 0 ? 9 : 6; }
+// TS = 3: a two-column tap set whose side (1 or 2) is a run-time property of the tile (Conv3Args::ts_mask): numbered like TS 1, the
+// column index T % 3 in {0, 1} then selects one of the tile's two column offsets instead of a fixed one
 constexpr int c3_tap(int TS, int s) {            // tap index T = 3*(dh+1) + (dw+1) of step ordinal s
   return TS == 0 ? s : 3 * (s / 2) + (s % 2) + (TS == 2 ? 1 : 0);
 }
@@ -202,6 +217,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   static_assert(!GRP || (FOLD && !SC && !(HEAD && FPW == 4)), "two problems per launch: folded scales, no shortcut, output-conv weights from L2");
   static_assert((NHB == 2 && !WD) || FOLD, "three halo buffers / wide tile: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
+  constexpr bool PH = TS == 3;                   // all phases of a transposed conv: (tile, phase) list, run-time tap-set side
+  static_assert(!PH || (FOLD && !SC && !HEAD && !GRP), "all-phase transposed conv: folded scales, no shortcut / output conv / second problem");
   static_assert(!(HEAD && SC), "a head tower has no shortcut");
   static_assert(FPW == 4 || FPW == 2, "4 or 2 pixel fragments per wave");
   static_assert(FC == 2 || (FC == 1 && FPW == 2), "30-column tiles: two fragments per wave");
@@ -254,7 +271,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   const unsigned long long clk0 = __builtin_readcyclecounter();
 
   const int G = gridDim.x, wg = blockIdx.x;
-  const int ntl = (a.ntiles - wg + G - 1) / G;   // tiles of this workgroup: wg, wg + G, ...  (grid <= ntiles)
+  const int nph = PH ? a.nph : 1;
+  const int ntl = ((a.ntiles - wg + G - 1) / G) * nph;   // list entries of this workgroup: spatial tiles wg, wg + G, ... (grid <= ntiles), PH: x phases
   const int tiles_img = a.ncol * a.nrow;
 
   // ---- DMA issue -----------------------------------------------------------------------------------------------
@@ -307,7 +325,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   };
   int f_ct = wg % a.ncol, f_rb = (wg / a.ncol) % a.nrow, f_b = wg / tiles_img;   // tile of the NEXT halo to fetch
   int c_ct = f_ct, c_rb = f_rb, c_b = f_b;                                        // tile being computed
+  int f_ph = 0, c_ph = 0, s_ph = 0;                                               // (PH) phase of the fetch / compute / slab cursor
   const unsigned char* htile = nullptr;                   // uniform: halo pixel (0, 0) of the fetch tile, channel 0
+  const unsigned char* htile2 = nullptr;                  // (two-tensor input) the same pixel of x2
+  int hpxb = a.x_cs * 2, hns = 0;                         // bytes per pixel and valid 16-byte slots of the chunk being fetched
   auto halo_tile = [&]() {                                // per fetch TILE: geometry and base address
     const int hw0 = f_ct * C3_TW - 1;
     hh0 = f_rb * C3_TH - 1;
@@ -316,6 +337,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     const bool fg = GRP && f_b >= a.B;                     // (GRP) problem 1: its own input, image index from 0
     htile = (const unsigned char*)(a.x + (size_t)(fg ? f_b - a.B : f_b) * a.x_bs + a.x_co + (fg ? a.g_x : 0)) +
             ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
+    if constexpr (WD) {
+      if (a.x2) htile2 = (const unsigned char*)(a.x2 + (size_t)f_b * a.x2_bs + a.x2_co) + ((long)hh0 * a.W + hw0) * (long)a.x2_cs * 2;
+    }
   };
   bool hnew = true;                                       // the fetch cursor moved to a new tile: geometry not yet derived
   auto halo_begin = [&]() {                               // per fetch UNIT: the chunk's slice of the tile; advance the cursor
@@ -323,9 +347,18 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     hbase = htile + hc * 64;
     hsok = hc * 4 + hs < a.nslots;
     hcur = hc;
+    if constexpr (WD) {
+      hpxb = a.x_cs * 2; hns = a.nslots - 4 * hc;
+      if (a.x2 && hc >= a.nchunk1) { hbase = htile2 + (hc - a.nchunk1) * 64; hpxb = a.x2_cs * 2; hns = a.nslots2 - 4 * (hc - a.nchunk1); }
+    }
     // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
     if (hc + 1 < a.nchunk) ++hc;
-    else if (hk + 1 < ntl) { ++hk; hc = 0; tile_advance(f_ct, f_rb, f_b); hnew = true; }
+    else if (hk + 1 < ntl) {
+      ++hk; hc = 0;
+      if constexpr (PH) {   // next phase of the same tile (same geometry, same source lines: L2 hits), then the next tile
+        if (++f_ph == nph) { f_ph = 0; tile_advance(f_ct, f_rb, f_b); hnew = true; }
+      } else { tile_advance(f_ct, f_rb, f_b); hnew = true; }
+    }
   };
   auto halo_piece = [&](int buf, int j) {
     const int q = wave * C3_HPW + j;
@@ -342,8 +375,8 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       asm volatile("" : "+v"(ol));
       const int pp = 16 * q + (ol >> 2), r = (pp * 1928) >> 16, cc = pp - 34 * r;
       const int hsp = (ol & 3) ^ ((cc >> 2) & 3);
-      ok = hcur * 4 + hsp < a.nslots && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && pp < Cfg::NPX && !(DBG & 16);
-      src = hbase + (long)((r * a.W + cc) * a.x_cs * 2 + hsp * 16);
+      ok = hsp < hns && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && pp < Cfg::NPX && !(DBG & 16);
+      src = hbase + (long)((r * a.W + cc) * hpxb + hsp * 16);
     } else {
     const int r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
     const int cc = c16 + l4;
@@ -377,6 +410,12 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
         wsrc = a.w + (stile >= n0 ? a.g_w : 0);
       }
     }
+    if constexpr (PH) {   // the slab stream's own phase cursor (it runs R steps ahead of the MFMAs)
+      if (fslab == 0) {
+        s_ph = s_ph + 1 == nph ? 0 : s_ph + 1;
+        wsrc = a.w + (size_t)s_ph * a.w_pb;
+      }
+    }
   };
 
   // ---- fragment addressing -------------------------------------------------------------------------------------
@@ -390,6 +429,17 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * RW * C3_ROWB;
   }
   const int boff = RING + lane * 16;
+  // PH: the two column offsets of the tile's tap-set side; pq0 = column 0 of the NEXT list entry's side (the last step of a tile
+  // pre-reads the first fragment of the next one)
+  auto side2 = [&](int ph) { return (a.ts_mask >> ph) & 1; };
+  int pcol[2] = {aoff[0], aoff[1]}, pq0 = aoff[0];
+  if constexpr (PH) {
+    const int s0_ = side2(0), s1_ = side2(nph > 1 ? 1 : 0);
+    pcol[0] = s0_ ? aoff[1] : aoff[0]; pcol[1] = s0_ ? aoff[2] : aoff[1];
+    pq0 = s1_ ? aoff[1] : aoff[0];
+  }
+  bool lastc = false;   // (PH) the unit being computed is the last chunk of its tile
+#define C3_AO(D) (PH ? pcol[(D)] : aoff[(D)])
 
   f32x16 acc[FPW][NCT];
   s16x8 fa[2][FPW], fb[2][NCT];
@@ -454,7 +504,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
 #pragma unroll
   for (int k = 0; k < NR; ++k)   // fragments of (unit 0, first tap, ks 0)
-    C3_RD(0, k, aoff[c3_tap(TS, 0) % 3] + abuf + (c3_tap(TS, 0) / 3) * C3_ROWB, boff + rslot * SLAB, 0)
+    C3_RD(0, k, C3_AO(c3_tap(TS, 0) % 3) + abuf + (c3_tap(TS, 0) / 3) * C3_ROWB, boff + rslot * SLAB, 0)
 
   // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
   //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
@@ -466,10 +516,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     constexpr int T_ = c3_tap(TS, (S)), TN_ = c3_tap(TS, ((S) + 1) % NS);                                            \
     constexpr int dh_ = T_ / 3, dw_ = T_ % 3, ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                        \
     constexpr int NH_ = c3_halo_pieces((S), NS, HPC), NP_ = IPW + NH_;   /* DMA pieces of this step */                    \
-    const int acur_ = (aoff[dw_] + abuf + dh_ * C3_ROWB) ^ 32;                                                         \
+    const int acur_ = (C3_AO(dw_) + abuf + dh_ * C3_ROWB) ^ 32;                                                        \
     const int bcur_ = boff + rslot * SLAB;                                                                           \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
-    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? hnext(abuf) : abuf) + ndh_ * C3_ROWB;                          \
+    const int anext_ = ((S) == NS - 1 && PH && lastc ? pq0 : C3_AO(ndw_)) + ((S) == NS - 1 ? hnext(abuf) : abuf) + ndh_ * C3_ROWB; \
     const int bnext_ = boff + rnext_ * SLAB;                                                                         \
     const int hbuf_ = hprev(abuf);   /* NHB 2: the other buffer (unit u+1); NHB 3: unit u-1's, for unit u+2 */       \
     C3_FENCE();                                                                                                      \
@@ -499,6 +549,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   }
 
   for (int k = 0; k < ntl; ++k) {
+    if constexpr (PH) lastc = a.nchunk == 1;
     {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
       if constexpr (FOLD) {
         // (the zero words go through an opaque copy once per tile: as compile-time zeros the five operand tuples are loop
@@ -528,6 +579,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     }
 #pragma unroll 1
     for (int c = 1; c < a.nchunk; ++c) {
+      if constexpr (PH) lastc = c == a.nchunk - 1;
       C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
       abuf = hnext(abuf);
@@ -542,6 +594,15 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     const int ct = c_ct, rb = c_rb;
     const bool eg = GRP && c_b >= a.B;                               // (GRP) problem 1: image index from 0, pointers + deltas
     const int b = eg ? c_b - a.B : c_b;
+    const int e_ph = c_ph;                                           // (PH) phase of the tile just computed
+    if constexpr (PH) {
+      // next list entry: the following phase of this tile, then the next tile; its tap-set side becomes the current one, and the
+      // side of the entry after it is looked up for the pre-read at the end of the next tile
+      if (++c_ph == nph) { c_ph = 0; tile_advance(c_ct, c_rb, c_b); }
+      const int sn_ = side2(c_ph), sq_ = side2(c_ph + 1 == nph ? 0 : c_ph + 1);
+      pcol[0] = sn_ ? aoff[1] : aoff[0]; pcol[1] = sn_ ? aoff[2] : aoff[1];
+      pq0 = sq_ ? aoff[1] : aoff[0];
+    } else
     tile_advance(c_ct, c_rb, c_b);                                   // (for the next iteration)
     const int oh0 = rb * C3_TH + RW * wave;                          // fragment i: output row oh0 + i / FC, columns 32*(i % FC) ..
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
@@ -554,9 +615,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     static_assert(32 * CW * 2 <= C3_HALO / 4 && (!HEAD || NPASS == 1 || FPW == 2), "transpose scratch");
     constexpr int ROWB = CW * 2, SPR = CW / 8, RPI = 64 / SPR;   // row bytes, 16-B slots per row, rows per store instr
     unsigned char* scr = smem + hprev(abuf) + wave * (C3_HALO / 4);   // (the buffer of the unit just consumed)
-    bf16_t* __restrict__ yrow0 = a.y + (eg ? a.g_y : 0) + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co;
+    bf16_t* __restrict__ yrow0 = a.y + (eg ? a.g_y : 0) + (size_t)b * a.y_bs + (size_t)oh0 * a.Wo * a.y_cs + a.y_co + (PH ? e_ph * a.y_pc : 0);
     // (base of image b, not of the wave's first row: rows past the image bottom must not even form an address beyond the buffer)
-    const bf16_t* __restrict__ rimg0 = a.res + (eg ? a.g_res : 0) + (size_t)b * a.r_bs + a.r_co;
+    const bf16_t* __restrict__ rimg0 = a.res + (eg ? a.g_res : 0) + (size_t)b * a.r_bs + a.r_co + (PH ? e_ph * a.r_pc : 0);
     // fused output conv of the tile's problem
     const unsigned char* __restrict__ e_hw = a.hw + (eg ? a.g_hw : 0);
     const float* __restrict__ e_hb = a.hb + (eg ? a.g_hb : 0);
@@ -745,6 +806,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     };
     if (a.flags == RD_RELU_POST) epilogue(std::integral_constant<int, RD_RELU_POST>{});
     else if (a.flags == (RD_ADD | RD_RELU_POST)) epilogue(std::integral_constant<int, RD_ADD | RD_RELU_POST>{});
+    else if (TS != 0 && a.flags == (RD_RELU_PRE | RD_ADD)) epilogue(std::integral_constant<int, RD_RELU_PRE | RD_ADD>{});   // skip + relu(BN(deconv))
     else epilogue(std::integral_constant<int, -1>{});
     if (k == 0) C3_TRACE()
   }
@@ -752,6 +814,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
   C3_TRACE()
   if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - clk0;   // shader-clock ticks of the whole life
+#undef C3_AO
 #undef C3_STEP
 #undef C3_STEP_
 #undef C3_MMZ
@@ -812,6 +875,16 @@ struct Conv3Second {
   void* y; int y_co;
   const void* hw; const float* hb; float* ho; long ho_bs; int hn;   // fused output conv (when the first problem has one)
 };
+// All phases of a transposed conv in one launch (PH form, TS = 3): per-phase weight images w + ph * w_pb, tap-set side per phase
+struct Conv3Phases { int nph, ts_mask, y_pc, r_pc; long w_pb; };
+// Second input tensor of a conv over a channel concatenation [x | x2] (Conv3Args::x2): cin of the launch = cin1 + cin2 where cin1
+// (a multiple of 32) channels come from x
+struct Conv3Src2 { const void* x; int cs, co, cin1, cin2; };
+inline bool conv3_phases_eligible(int cout, int flags) {
+  const DevSwitches& sw_ = dev_switches();
+  return (cout == 64 || cout == 128) && (flags & RD_SCALE_FOLDED) && sw_.conv_w30 && sw_.conv_wide && !sw_.conv_v1 &&
+         ((cout == 64 && sw_.conv_th4 != 3) || (cout == 128 && sw_.conv_th4 && sw_.conv_w30 == 2));
+}
 inline bool conv3_pair_eligible(int cout, int flags, int W) {
   const DevSwitches& sw_ = dev_switches();
   return cout == 128 && (flags & RD_SCALE_FOLDED) && sw_.conv_th4 && sw_.conv_w30 == 2 && sw_.conv_wide && (sw_.conv_th4 != 2 || W >= 600);
@@ -820,23 +893,27 @@ inline bool conv3_pair_eligible(int cout, int flags, int W) {
 template <int DT>
 inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                            const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1);
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1,
+                           const Conv3Phases* ph, const Conv3Src2* s2);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
                         int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, int dt,
-                        const Conv3Second* g1) {
+                        const Conv3Second* g1, const Conv3Phases* ph, const Conv3Src2* s2) {
   RD_REQUIRE(is_h16(dt), RD_EINVAL, "conv3: dtype %d (the persistent 3x3 kernel takes RD_BF16 or RD_F16)", dt);
-  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1);
-  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1);
+  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2);
+  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2);
 }
 
 template <int DT>
 inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                            const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
-                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1) {
+                           int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1,
+                           const Conv3Phases* ph, const Conv3Src2* s2) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
   a.ngrp = g1 ? 2 : 1;
+  a.nph = 1;
+  if (ph) { a.nph = ph->nph; a.ts_mask = ph->ts_mask; a.y_pc = ph->y_pc; a.r_pc = ph->r_pc; a.w_pb = ph->w_pb; }
   if (head) { a.hw = head->hw; a.hb = head->hb; a.ho = head->ho; a.ho_bs = head->ho_bs; a.ho_off = head->ho_off; a.hn = head->hn; }
   const bool sc = head && head->sx;
   const bool fold = (flags & RD_SCALE_FOLDED) != 0;
@@ -887,6 +964,12 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
       a.g_hw = (const unsigned char*)g1->hw - a.hw; a.g_hb = g1->hb - a.hb; a.g_ho = g1->ho - a.ho;
       a.g_ho_bs = g1->ho_bs - a.ho_bs; a.g_hn = g1->hn - a.hn;
     }
+  }
+  if (s2) {   // conv over [x | x2]: cin = cin1 + cin2, the first cin1 (full 32-channel chunks) from x
+    RD_REQUIRE(wd && !g1 && sw == 1 && s2->cin1 > 0 && s2->cin1 % 32 == 0 && s2->cin1 + s2->cin2 == cin && s2->cin2 > 0, RD_ESHAPE,
+               "conv3: a two-tensor input needs the 8 x 32 tile form and cin1 a multiple of 32 (cin1 %d, cin2 %d, cin %d)", s2->cin1, s2->cin2, cin);
+    a.x2 = (const bf16_t*)s2->x; a.x2_cs = s2->cs; a.x2_co = s2->co; a.x2_bs = (long)H * W * s2->cs;
+    a.nchunk1 = s2->cin1 / 32; a.nslots2 = cin_slots(s2->cin2, RD_BF16); a.nslots = a.nchunk1 * 4;
   }
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
@@ -939,6 +1022,12 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
                    : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);              \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
+  if (ph) {
+    RD_REQUIRE(wd && fold && !sc && !head && !g1 && ts == 3 && sw == 1 && ph->nph >= 1 && ph->nph <= 8, RD_ESHAPE,
+               "conv3: all phases per launch need the 8 x 32 tile form (folded scales, no shortcut / output conv)");
+    if (cout == 128) return c3_go<4, 3, false, false, true, 2, 1, 2, DT, true>(grid, st, a);
+    return c3_go<2, 3, false, false, true, 2, 1, 2, DT, true>(grid, st, a);
+  }
   if (wd && g1) {
     if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT, true, true>(grid, st, a);
     return c3_go<4, 0, false, false, true, 2, 1, 2, DT, true, true>(grid, st, a);

@@ -295,6 +295,30 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
                       sc_x ? &e : nullptr, dtype);
 }
 
+// ---- 3x3 conv over the channel concatenation [x1 | x2] of two tensors that is never materialised (16-bit, folded scales) -----------
+// dla_backbone.py:153-154 (concat of the range image with the agg3 feature map) feeding head/builder.py:221-240: w_packed is
+// rd_pack_conv3x3_ex_host of the weight whose input channels are laid out [cin1 channels of x1 | cin2 channels of x2] (stride 1).
+int rd_conv3x3_bn_act_cat(const void* x1, int x1_cstride, int x1_coff, int cin1, const void* x2, int x2_cstride, int x2_coff, int cin2,
+                          const void* w_packed, const float* shift, void* y, int y_cstride, int y_coff, int B, int H, int W, int cout,
+                          int flags, int dtype, void* stream) {
+  RD_REQUIRE(x1 && x2 && w_packed && y && shift, RD_EINVAL, "conv3x3_cat: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "conv3x3_cat: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE((flags & RD_SCALE_FOLDED) && !(flags & RD_ADD), RD_EINVAL, "conv3x3_cat: needs RD_SCALE_FOLDED weights, takes no residual");
+  RD_REQUIRE(B > 0 && H > 0 && W > 0 && (cout == 64 || cout == 128), RD_ESHAPE, "conv3x3_cat: shape / cout %d", cout);
+  RD_REQUIRE(cin1 > 0 && cin1 % 32 == 0 && cin2 > 0 && cin2 % 8 == 0, RD_ESHAPE, "conv3x3_cat: cin1 %d (multiple of 32), cin2 %d (multiple of 8)", cin1, cin2);
+  RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "conv3x3_cat: y channels exceed stride");
+  RD_REQUIRE(x1_cstride % 8 == 0 && x1_coff % 8 == 0 && x1_coff + cin1 <= x1_cstride && x2_cstride % 8 == 0 && x2_coff % 8 == 0 &&
+             x2_coff + cin2 <= x2_cstride, RD_ESHAPE, "conv3x3_cat: channel stride/offset");
+  const DevSwitches& sw_ = dev_switches();
+  RD_REQUIRE(!sw_.conv_v1 && sw_.conv_wide && sw_.conv_w30 && (cout == 64 ? sw_.conv_th4 != 3 : (sw_.conv_th4 && sw_.conv_w30 == 2)), RD_ESHAPE,
+             "conv3x3_cat: needs the 8 x 32 tile form of the persistent 3x3 kernel (a dev switch turned it off)");
+  allow_conv_lds();
+  Conv3Src2 s2;
+  s2.x = x2; s2.cs = x2_cstride; s2.co = x2_coff; s2.cin1 = cin1; s2.cin2 = cin2;
+  return launch_conv3(x1, x1_cstride, x1_coff, w_packed, nullptr, shift, nullptr, 0, 0, y, y_cstride, y_coff, B, H, W, cin1 + cin2, cout, flags,
+                      1, (hipStream_t)stream, 0, nullptr, dtype, nullptr, nullptr, &s2);
+}
+
 // ---- last tower conv + the tower's 1x1 output conv in one launch (bf16) ---------------------------------------------
 size_t rd_head_packed_bytes(void) { return 16384; }
 int rd_pack_head_weight_host(const float* w, int nout, int cin, int dtype, void* out_host) {
@@ -413,6 +437,39 @@ int rd_deconv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_p
   return launch_conv(tl, x, x_cstride, x_coff, w_packed_phase, scale, shift, residual, r_cstride, r_coff, y,
                      y_cstride, y_coff, B, H, Win, Wq, Wout, cin, cout, 1, stride_w, phase, flags, dtype,
                      (hipStream_t)stream);
+}
+
+// ---- ALL phases of a transposed conv in ONE launch (16-bit, folded scales) -------------------------------------------------------
+// w_packed_all = the stride_w phase images of rd_pack_deconv_weight_folded_host one after the other, w_phase_bytes apart.
+int rd_deconv2d_all_phases_ok(int kh, int kw, int stride_w, int pad_w, int cout, int dtype) {
+  if (!is_h16(dtype) || kh != 3 || stride_w < 2 || stride_w > 8 || !conv3_phases_eligible(cout, RD_SCALE_FOLDED)) return 0;
+  if (kw - 2 * pad_w != stride_w) return 0;   // Wout = (Win - 1) * stride_w - 2 * pad_w + kw must equal stride_w * Win
+  for (int p = 0; p < stride_w; ++p)
+    if (!deconv_tap_set(deconv_taps_sorted(kh, kw, stride_w, pad_w, p))) return 0;
+  return 1;
+}
+int rd_deconv2d_bn_act_all(const void* x, int x_cstride, int x_coff, const void* w_packed_all, long w_phase_bytes,
+                           const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                           int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                           int flags, int dtype, void* stream) {
+  RD_REQUIRE(x && w_packed_all && y, RD_EINVAL, "deconv2d_all: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "deconv2d_all: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE(flags & RD_SCALE_FOLDED, RD_EINVAL, "deconv2d_all: needs RD_SCALE_FOLDED weights (rd_pack_deconv_weight_folded_host)");
+  RD_REQUIRE(!((flags & RD_ADD) && !residual), RD_EINVAL, "deconv2d_all: RD_ADD without residual");
+  RD_REQUIRE(B > 0 && H > 0 && Win > 0 && cin > 0, RD_ESHAPE, "deconv2d_all: shape");
+  RD_REQUIRE(y_coff >= 0 && y_coff + cout <= y_cstride, RD_ESHAPE, "deconv2d_all: y channels exceed stride");
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "deconv2d_all: x channel stride/offset");
+  RD_REQUIRE(rd_deconv2d_all_phases_ok(kh, kw, stride_w, pad_w, cout, dtype), RD_ESHAPE,
+             "deconv2d_all: kernel (%d,%d) stride %d pad %d cout %d is not a set of two-column 3x2 phases (use rd_deconv2d_bn_act per phase)",
+             kh, kw, stride_w, pad_w, cout);
+  RD_REQUIRE(w_phase_bytes >= (long)conv_packed_bytes(6, cin, cout, RD_BF16) && w_phase_bytes % 16 == 0, RD_EINVAL, "deconv2d_all: w_phase_bytes");
+  allow_conv_lds();
+  Conv3Phases ph;
+  ph.nph = stride_w; ph.ts_mask = 0; ph.y_pc = y_cstride; ph.r_pc = r_cstride; ph.w_pb = w_phase_bytes;
+  for (int p = 0; p < stride_w; ++p)
+    if (deconv_tap_set(deconv_taps_sorted(kh, kw, stride_w, pad_w, p)) == 2) ph.ts_mask |= 1 << p;
+  return launch_conv3(x, x_cstride, x_coff, w_packed_all, nullptr, shift, residual, r_cstride * stride_w, r_coff, y, y_cstride * stride_w,
+                      y_coff, B, H, Win, cin, cout, flags, 1, (hipStream_t)stream, 3, nullptr, dtype, nullptr, &ph);
 }
 
 int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const float* bias, float* out,

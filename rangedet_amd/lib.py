@@ -48,6 +48,12 @@ SIGNATURES = {
     "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p]),
+    "rd_conv3x3_bn_act_cat": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_deconv2d_all_phases_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rd_deconv2d_bn_act_all": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -8,7 +8,8 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
                                                       kernel's epilogue; stride (1,2) 3x3 convs run on the pixel-pair view
   skip + relu(BN(Deconvolution(u)))                -> rd_deconv2d_bn_act per phase, RD_RELU_PRE|RD_ADD   (dla_backbone.py:117-126)
   meta_baseline_bias(...) + BN + relu + 1x1 + BN + relu   -> rd_meta_kernel_fwd                (meta_kernel.py:166-240, dla_backbone.py:92-97)
-  concat(data, agg3)                               -> producers write straight into one buffer (dla_backbone.py:153-154)
+  concat(data, agg3)                               -> 16-bit: never written, the consuming convs read both tensors (rd_conv3x3_bn_act_cat);
+                                                      fp32: producers write straight into one buffer  (dla_backbone.py:153-154)
   1x1 logit/delta conv + cast + reshape/slice/squeeze/transpose + concat over levels
                                                    -> rd_head_out into flat (B,N[,8]) buffers   (builder.py:242-261,99-154)
   sigmoid + Custom(get_sorted_foreground)          -> rd_sorted_foreground(apply_sigmoid=1)     (builder.py:459-461,512-521)
@@ -33,6 +34,8 @@ class TRef:
     cs: int
     co: int = 0
     cmap: tuple = None   # physical channel -> logical channel (-1 = zero padding) when a concat had to align its parts
+    tail: "TRef" = None  # 16-bit "virtual concat": the channels after this tensor's C come from THAT tensor (its cs channels);
+    #                      the concatenation is never written, the consuming conv reads both (rd_conv3x3_bn_act_cat)
 
 
 @dataclass
@@ -113,7 +116,7 @@ class Lowering:
         max_w = int(os.environ.get("RD_PAIR_MAXW", "100000"))
 
         def sig(st):
-            if st["kind"] != "conv" or not st.get("ex") or not st.get("fold") or st.get("sc") or st.get("s2view"):
+            if st["kind"] != "conv" or not st.get("ex") or not st.get("fold") or st.get("sc") or st.get("s2view") or st.get("x2") is not None:
                 return None
             if st["res"] is not None or st["cout"] != 128 or st["stride_w"] != 1 or tuple(st["k"]) != (3, 3) or st["flags"] != RD_RELU_POST:
                 return None
@@ -180,7 +183,7 @@ class Lowering:
                 continue
             c = steps[prod[0]]
             if not (c["kind"] == "conv" and tuple(c["k"]) == (3, 3) and c["cout"] == 128 and c["stride_w"] == 1 and
-                    c["flags"] == RD_RELU_POST and c.get("res") is None and c["out"] == x):
+                    c["flags"] == RD_RELU_POST and c.get("res") is None and c["out"] == x and c.get("x2") is None):
                 continue
             c["head"] = dict(name=st["name"], rows=st["rows"], nout=st["nout"], out=st["out"], n_off=st["n_off"], N=st["N"])
             c["head_out"] = st["out"]        # top level: the executor's buffer liveness pass looks at step values
@@ -283,6 +286,8 @@ class Lowering:
         cout = conv.attrs["num_filter"]
         if cout not in (64, 128):
             raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
+        if x.tail is not None and (k != (3, 3) or sw != 1 or residual is not None or sc is not None or os.environ.get("RD_NO_FOLD")):
+            raise NotImplementedError("Convolution %s reads a virtual concat: only 3x3 stride 1 without residual / shortcut" % conv.name)
         out = self._out(cout, x.H, Wout, dest)
         # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
         # and, unless RD_NO_FOLD is set, every bf16 3x3 conv with the BatchNorm scale folded into its weights (RD_SCALE_FOLDED)
@@ -295,7 +300,10 @@ class Lowering:
             scx = self.emit_act(sc[0].inputs[0])
             kw["sc"] = dict(name=sc[0].name, bn=sc[1].name, eps=sc[1].attrs["eps"], cin=scx.C, cmap=scx.cmap)
             kw["sc_x"] = scx                      # top level: the executor's buffer liveness pass looks at step values
-        self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual, cin=x.C,
+        if x.tail is not None:
+            kw["x2"] = x.tail                     # (top level: buffer liveness)
+        self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual,
+                  cin=sum(1 for m in x.cmap if m >= 0) if x.tail is not None else x.C,   # (logical channels of a virtual concat)
                   cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw_fold, **kw)
         return out
 
@@ -376,6 +384,23 @@ class Lowering:
             return q.attrs["num_filter"]
         cs_list = [chans(p) for p in parts]
         Ctot = sum(cs_list)
+        # 16-bit, [input variable(s) of at most one channel granule in total | ONE computed feature map of a multiple of 32 channels]
+        # (dla_backbone.py:153-154: the 8-channel range image + agg3): no shared buffer.  The feature map keeps its own buffer
+        # (128-byte pixel rows instead of rows at a 160-byte pitch that straddle cache lines), the variable its zero-padded
+        # one-granule buffer, and the consuming convs read [feature map | variable] (rd_conv3x3_bn_act_cat) with their weight
+        # columns permuted accordingly (cmap).  RD_CONCAT_BUFFER=1: the shared buffer, for A/B runs.
+        acts = [i for i, p in enumerate(parts) if p.op != "var"]
+        if self.h16 and len(parts) == 2 and len(acts) == 1 and cs_list[acts[0]] % 32 == 0 and cs_list[1 - acts[0]] <= self.gran and \
+                not os.environ.get("RD_CONCAT_BUFFER") and not os.environ.get("RD_NO_FOLD") and os.environ.get("RD_PAIR", "0") in ("", "0"):
+            # (RD_PAIR=1, the opt-in two-problem tower launches, keeps the shared buffer: that launch form takes one input tensor)
+            ia, iv = acts[0], 1 - acts[0]
+            fa = self.emit_act(parts[ia])
+            fv = self.emit_act(parts[iv])
+            if (fa.H, fa.W) != (fv.H, fv.W) or fa.cmap is not None or fa.tail is not None or fa.co != 0 or fv.co != 0:
+                raise ValueError("concat %s: parts do not line up" % s.name)
+            start = [0, cs_list[0]]               # logical channel offset of each part in the concatenation
+            cmap = list(range(start[ia], start[ia] + fa.C)) + list(range(start[iv], start[iv] + fv.C)) + [-1] * (fv.cs - fv.C)
+            return TRef(fa.buf, fa.C, fa.H, fa.W, fa.cs, fa.co, tuple(cmap), fv)
         ref_hw = None
         for p, d in zip(parts, dims):
             if d is not None:

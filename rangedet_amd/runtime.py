@@ -5,6 +5,8 @@ This is the build's counterpart of the reference's DetModule.bind/set_params/for
 (utils/detection_module.py:419-510,627-679,783-805) for the test symbol: ``Executor(plan, params).forward(inputs)``
 returns the Group outputs [rec_id, fg_cls_score, decoded_bbox, zeros, gt_bbox_imu, gt_class] (builder.py:77).
 """
+import os
+
 import numpy as np
 
 from . import lib as rdlib
@@ -179,8 +181,14 @@ class Executor:
             w = P[st["name"] + "_weight"]
             s, t = bn_affine(P, st["bn"], st["eps"])
             fs = s if st.get("fold") else None
-            b["w"] = [A.upload(L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt, fold_scale=fs))
-                      for ph in range(st["stride_w"])]
+            imgs = [L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt, fold_scale=fs) for ph in range(st["stride_w"])]
+            # all phases in ONE launch when the library has that form for this layer (16-bit, folded scale, 3 x 2 phases):
+            # the phase images back to back in one buffer (RD_DECONV_PER_PHASE=1: one launch per phase, for A/B runs)
+            b["all_phases"] = bool(st.get("fold")) and not os.environ.get("RD_DECONV_PER_PHASE") and len({len(i) for i in imgs}) == 1 and \
+                L.raw("rd_deconv2d_all_phases_ok")(st["k"][0], st["k"][1], st["stride_w"], st["pad_w"], st["cout"], dt) == 1
+            if b["all_phases"]:
+                b["w_all"], b["w_pb"] = A.upload(np.concatenate(imgs)), len(imgs[0])
+            b["w"] = [A.upload(i) for i in imgs]
             b["scale"], b["shift"] = (None if st.get("fold") else A.upload(s)), A.upload(t)
             if st.get("fold"):
                 b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
@@ -258,6 +266,11 @@ class Executor:
                        A.ptr(b["scale"]) if b["scale"] is not None else None, A.ptr(b["shift"]), B,
                        x.H, x.W, b["cin"], b["flags"], A.ptr(b["head_w"]), A.ptr(b["head_bias"]), self.p(h["out"]),
                        h["N"] * h["nout"], h["n_off"], h["nout"], dt, st_)
+            elif k == "conv" and b.get("x2") is not None:
+                # conv over the virtual concat [x | x2] (lower._concat): neither a shared buffer nor a copy exists
+                x, x2, o = b["x"], b["x2"], b["out"]
+                L.call("rd_conv3x3_bn_act_cat", self.p(x), x.cs, x.co, x.C, self.p(x2), x2.cs, x2.co, x2.cs, A.ptr(b["w"]), A.ptr(b["shift"]),
+                       self.p(o), o.cs, o.co, B, x.H, x.W, b["cout"], b["flags"], dt, st_)
             elif k == "conv" and b.get("ex"):
                 x, o, r, sx = b["x"], b["out"], b["res"], b.get("sc_x")
                 cin = len(b["cmap"]) if b.get("cmap") else b["cin"]
@@ -274,6 +287,11 @@ class Executor:
                        b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["flags"], dt, st_)
             elif k == "deconv":
                 x, o, r = b["x"], b["out"], b["res"]
+                if b.get("all_phases"):
+                    L.call("rd_deconv2d_bn_act_all", self.p(x), x.cs, x.co, A.ptr(b["w_all"]), b["w_pb"], A.ptr(b["shift"]), self.p(r), r.cs,
+                           r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["pad_w"],
+                           b["flags"], dt, st_)
+                    continue
                 for ph in range(b["stride_w"]):
                     L.call("rd_deconv2d_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"][ph]),
                            A.ptr(b["scale"]) if b["scale"] is not None else None, A.ptr(b["shift"]), self.p(r), r.cs, r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"],

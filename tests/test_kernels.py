@@ -263,6 +263,47 @@ def test_deconv2d_bn_act(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(BF16, 2, 9, 70, 128, 128, (3, 8), 4, 2), (BF16, 3, 17, 40, 128, 64, (3, 4), 2, 1), (BF16, 1, 20, 45, 64, 64, (3, 4), 2, 1),
+                                  (F16, 2, 9, 70, 128, 64, (3, 8), 4, 2), (F16, 1, 11, 33, 64, 64, (3, 4), 2, 1)])
+def test_deconv2d_all_phases_in_one_launch(be, case):
+    """rd_deconv2d_bn_act_all (every output phase of a transposed conv in ONE launch: the tile list is (tile, phase), the tap-set
+    side and the weight image change per list entry) == the stride_w per-phase launches of rd_deconv2d_bn_act, bit for bit, and
+    within one output rounding of torch's conv_transpose2d (mxnext/simple.py:545-580, dla_backbone.py:117-127).  Shapes: several
+    tiles per workgroup so that phases and tiles alternate inside a list, partial column / row tiles, batch > 1."""
+    dt, B, H, W, cin, cout, k, s, pw = case
+    rng = np.random.default_rng(21)
+    x = h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), dt)
+    w = (rng.standard_normal((cin, cout, k[0], k[1])) / np.sqrt(cin * k[0] * k[1] / s)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    Wout = (W - 1) * s - 2 * pw + k[1]
+    res = h16_round(rng.standard_normal((B, cout, H, Wout)).astype(np.float32), dt)
+    L = be.lib
+    assert L.raw("rd_deconv2d_all_phases_ok")(k[0], k[1], s, pw, cout, dt) == 1
+    assert L.raw("rd_deconv2d_all_phases_ok")(3, 3, 2, 1, cout, dt) == 0          # Wout != 2 Win
+    assert L.raw("rd_deconv2d_all_phases_ok")(k[0], k[1], s, pw, cout, F32) == 0
+    xin, rin, dsh = be.up(to_nhwc(x, dt)), be.up(to_nhwc(res, dt)), be.up(sh)
+    fl = R.RD_RELU_PRE | R.RD_ADD | R.RD_SCALE_FOLDED
+    imgs = [L.pack_deconv_weight(w, s, pw, ph, dt, fold_scale=sc) for ph in range(s)]
+    y1, y2 = be.empty(B * H * Wout * cout * 2), be.empty(B * H * Wout * cout * 2)
+    for ph in range(s):
+        L.call("rd_deconv2d_bn_act", be.ptr(xin), cin, 0, be.ptr(be.up(imgs[ph])), None, be.ptr(dsh), be.ptr(rin), cout, 0, be.ptr(y1), cout, 0,
+               B, H, W, cin, cout, k[0], k[1], s, pw, ph, fl, dt, be.stream)
+    L.call("rd_deconv2d_bn_act_all", be.ptr(xin), cin, 0, be.ptr(be.up(np.concatenate(imgs))), len(imgs[0]), be.ptr(dsh), be.ptr(rin), cout, 0,
+           be.ptr(y2), cout, 0, B, H, W, cin, cout, k[0], k[1], s, pw, fl, dt, be.stream)
+    a, b = be.down(y1, np.uint16, (B, H, Wout, cout)), be.down(y2, np.uint16, (B, H, Wout, cout))
+    assert np.array_equal(a, b), int((a != b).sum())
+    ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, s), padding=(1, pw)).numpy()
+    ref = np.maximum(ref * sc[None, :, None, None] + sh[None, :, None, None], 0) + res
+    assert np.abs(from_nhwc(b, dt, cout) - ref).max() <= 1.5 * _tol(dt, ref)
+    buf = be.ptr(be.empty(1 << 16))
+    f = L.raw("rd_deconv2d_bn_act_all")
+    assert f(buf, 128, 0, buf, 1 << 20, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, R.RD_RELU_PRE | R.RD_ADD, dt, be.stream) == R.RD_EINVAL   # not folded
+    assert f(buf, 128, 0, buf, 1 << 20, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 3, 2, 1, fl, dt, be.stream) == R.RD_ESHAPE                       # not 3 x 2 phases
+    assert f(buf, 128, 0, buf, 16, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, fl, dt, be.stream) == R.RD_EINVAL                             # phase images overlap
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40)])
 def test_meta_kernel_unit(be, case):
     """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97."""
@@ -573,6 +614,44 @@ def test_conv3x3_ex_folded_scale(be, case):
 @pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_conv3x3_ex_folded_scale_fp16(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True, dt=F16)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(BF16, 2, 9, 70, 64, 8, 16, 128), (BF16, 1, 17, 40, 32, 8, 16, 64), (F16, 2, 9, 70, 64, 8, 16, 128), (BF16, 1, 8, 33, 64, 24, 24, 128)])
+def test_conv3x3_cat_two_tensor_input(be, case):
+    """rd_conv3x3_bn_act_cat: 3x3 conv + BN + ReLU over the channel concatenation [x1 | x2] of two tensors with their own channel
+    strides (dla_backbone.py:153-154 concat -> head/builder.py:221-240), against torch on the materialised concatenation, and bit
+    for bit against rd_conv3x3_bn_act_ex on a shared buffer that holds the same channels."""
+    dt, B, H, W, c1, c2, cs2, cout = case
+    rng = np.random.default_rng(31)
+    x1 = h16_round(rng.standard_normal((B, c1, H, W)).astype(np.float32), dt)
+    x2 = h16_round(rng.standard_normal((B, c2, H, W)).astype(np.float32), dt)
+    cin2 = -(-c2 // 8) * 8
+    w = (rng.standard_normal((cout, c1 + cin2, 3, 3)) / np.sqrt((c1 + c2) * 9)).astype(np.float32)
+    w[:, c1 + c2:] = 0
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    L = be.lib
+    fl = R.RD_RELU_POST | R.RD_SCALE_FOLDED
+    d1, d2 = be.up(to_nhwc(x1, dt)), be.up(to_nhwc(x2, dt, cstride=cs2))
+    wp, dsh = be.up(L.pack_conv3x3_ex(w, 1, c1 + cin2, fold_scale=sc, dtype=dt)), be.up(sh)
+    y = be.empty(B * H * W * cout * 2)
+    L.call("rd_conv3x3_bn_act_cat", be.ptr(d1), c1, 0, c1, be.ptr(d2), cs2, 0, cin2, be.ptr(wp), be.ptr(dsh), be.ptr(y), cout, 0, B, H, W, cout,
+           fl, dt, be.stream)
+    got = be.down(y, np.uint16, (B, H, W, cout))
+    xc = np.concatenate([x1, x2, np.zeros((B, cin2 - c2, H, W), np.float32)], 1)
+    ref = F.conv2d(torch.from_numpy(xc), torch.from_numpy(w), padding=1).numpy() * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = np.maximum(ref, 0)
+    assert np.abs(from_nhwc(got, dt, cout) - ref).max() <= 1.5 * _tol(dt, ref)
+    cs = -(-(c1 + cin2) // 16) * 16
+    y2 = be.empty(B * H * W * cout * 2)
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(be.up(to_nhwc(xc, dt, cstride=cs))), cs, 0, be.ptr(wp), None, be.ptr(dsh), None, 0, 0, None, 0, 0, 0, None,
+           be.ptr(y2), cout, 0, B, H, W, c1 + cin2, cout, 1, fl, dt, be.stream)
+    assert np.array_equal(got, be.down(y2, np.uint16, (B, H, W, cout)))
+    buf = be.ptr(be.empty(1 << 16))
+    f = L.raw("rd_conv3x3_bn_act_cat")
+    assert f(buf, 64, 0, 48, buf, 16, 0, 16, buf, buf, buf, 128, 0, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_ESHAPE        # cin1 not a multiple of 32
+    assert f(buf, 64, 0, 64, buf, 16, 0, 16, buf, buf, buf, 128, 0, 1, 4, 8, 128, R.RD_RELU_POST, dt, be.stream) == R.RD_EINVAL   # not folded
+    assert f(buf, 64, 0, 64, buf, 16, 8, 16, buf, buf, buf, 128, 0, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_ESHAPE        # x2 channels exceed its stride
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

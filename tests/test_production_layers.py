@@ -3,7 +3,8 @@
 The unit tests of test_kernels.py run the persistent 3x3 kernel / the Meta-Kernel at sizes where every workgroup owns one
 tile.  This test runs the real lowered plan of rangedet_veh_wo_aug_4_18e at B = 8, 64 x 2656 -- 5 312 tiles on 512 resident
 slots at full width, the 83rd column tile, the W = 1328 / 664 / 332 layers, the 0.75-tile-per-slot W = 166 launches, the
-stride-2 pixel-pair views, the fused projection shortcuts, every transposed-conv phase, the 160-byte-pitch concat buffer, the
+stride-2 pixel-pair views, the fused projection shortcuts, every transposed conv with all its phases in one launch, the level-0
+tower convs that read the never-materialised concat of the agg3 feature map and the range image from two tensors, the
 fused tower output convs on both tile shapes and the Meta-Kernel's register prefetch of the next tile -- ONE PLAN STEP AT A
 TIME: the step's actual device inputs are read back (exact: they are 16-bit values), the layer is recomputed by PyTorch-CPU in
 fp32 from those inputs and the SAME 16-bit weights the packer makes (folded BatchNorm scale, dla_backbone.py:18-56,117-127;
@@ -141,6 +142,9 @@ def test_every_production_launch_tight_at_full_geometry(be, dt):
                 host.invalidate(st["out"])
             continue
         x = host.get(st["x"])
+        if st.get("x2") is not None:      # conv over the virtual concat [x | x2 | zero padding of x2's buffer] (rd_conv3x3_bn_act_cat)
+            x2 = host.get(st["x2"])
+            x = torch.cat([x, x2, torch.zeros(x2.shape[0], st["x2"].cs - x2.shape[1], x2.shape[2], x2.shape[3])], 1)
         res = host.get(st["res"]) if st.get("res") is not None else None
         sx = host.get(st["sc_x"]) if st.get("sc_x") is not None else None
         exe.forward(fr, only=i, dev=dev)
