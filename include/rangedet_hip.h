@@ -267,6 +267,13 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
 /* OverlapChecker::single_overlap (nms.h:195-249) of n row pairs: out[i] = overlap(dets_a[i], dets_b[i]) -- BEV IoU of the two
  * 4-corner boxes, or volume IoU with is3d (rows are (n,12) dets rows).  The measure the weighted NMS thresholds. */
 int rd_single_overlap(const float* dets_a, const float* dets_b, long n, int is3d, float* out, void* stream);
+/* The pair kernel's rejection test on n independent row pairs (dets rows as in rd_wnms_4c): out[i] = 1 if rd_wnms_4c would NOT run
+ * the polygon clip on (dets_a[i], dets_b[i]) because the reference's value cannot reach a threshold >= 1e-3 -- both boxes rectangles
+ * with 0.2 .. 25 m edges and |coordinates| <= 200 m, bounding rectangles > 0.01 m apart, edge directions >= 0.01 rad apart mod 90
+ * degrees (characterised on the compiled reference: oracle/ref_overlap_study.cpp; nms.h:96-149,195-249 has no empty-intersection
+ * test).  Test / characterisation aid: results of rd_wnms_4c do not depend on it. */
+int rd_wnms_pair_skippable(const float* dets_a, const float* dets_b, long n, unsigned char* out, void* stream);
+
 /* HOST: the reference's own ordering (std::sort, score descending, unstable) for dets_host (K,12). */
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host);
 

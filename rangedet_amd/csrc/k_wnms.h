@@ -20,7 +20,54 @@ namespace rd {
 
 struct WPt { float x, y; };
 struct WEdge { WPt a, b; float ang; };
-constexpr int PREP_F = 20;  // floats per prepped box: 8 corners, 4 angles, area, bottom, height, pad, 4 hash-cell bounds (int bits)
+#define RD_NOCONTRACT _Pragma("clang fp contract(off)")
+constexpr int PREP_F = 26;  // floats per prepped box: 8 corners, 4 angles, area, bottom, height, [15] rejection-test domain flag,
+                            // [16..19] 4 hash-cell bounds (int bits), [20..23] bounding rectangle x0 y0 x1 y1, [24] edge direction mod 90 deg, pad
+
+// ---- rejection test: pairs whose clip is provably irrelevant are not clipped (round 4) -------------------------------------------
+// 99 % of the pairs the reference evaluates on a frame's candidates are boxes that do not touch.  The reference's half-plane clipper
+// has no empty-intersection test (nms.h:96-149): on disjoint boxes it returns 0, NaN, a negative number or a positive value below
+// 1e-8 -- none of which passes `ovr >= thresh` / `ovr > thresh_vote` (nms.h:509-516) -- EXCEPT when two edge directions tie within its
+// EPS = 1e-5 (nms.h:58-64,104-106: one of the two half-planes is dropped and the rest can enclose an area: "IoU" up to 1e4), when
+// the boxes are nearly parallel (lines meeting thousands of metres away: cancellation in nms.h:54-56,74-90; seen up to 3e-3 rad
+// for 40 m boxes, 2e-4 rad up to 20 m) or when the geometry is ill-conditioned (edges of centimetres, coordinates of kilometres).
+// Characterised on the reference itself, compiled as-is (oracle/ref_overlap_study.cpp, 1.1e10 disjoint pairs of nine families,
+// profiles/r04_nms_spurious_study.txt).  So a pair is skipped -- its overlap taken as 0, exactly what every comparison of the
+// reference's value would give -- only when ALL of this holds, with an order of magnitude of margin on each bound:
+//   * both boxes are rectangles (1e-3 relative) with edges of 0.2 .. 25 m and |coordinates| <= 200 m       (w_box_domain)
+//   * their bounding rectangles are more than 0.01 m apart (then the polygons are disjoint, whatever the rounding)
+//   * their edge directions mod 90 degrees differ by at least 0.01 rad
+//   * thresh >= 1e-3 and thresh_vote >= 1e-3 (the launcher's condition; the largest value seen inside the domain is 9e-9)
+// Zero violations on the 1.1e10 pairs; every other pair is clipped as before.  oracle/ and the golden vectors know nothing of this.
+__device__ __forceinline__ void w_box_domain(const float* c, float* o) {   // c: the 8 corner floats of a dets row, as given
+  RD_NOCONTRACT
+  float ex[4], ey[4], l2[4];
+  float x0 = c[0], x1 = c[0], y0 = c[1], y1 = c[1];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int k1 = (k + 1) & 3;
+    ex[k] = c[2 * k1] - c[2 * k]; ey[k] = c[2 * k1 + 1] - c[2 * k + 1];
+    l2[k] = ex[k] * ex[k] + ey[k] * ey[k];
+    ok = ok && l2[k] >= 0.04f && l2[k] <= 625.f && fabsf(c[2 * k]) <= 200.f && fabsf(c[2 * k + 1]) <= 200.f;
+    x0 = fminf(x0, c[2 * k]); x1 = fmaxf(x1, c[2 * k]); y0 = fminf(y0, c[2 * k + 1]); y1 = fmaxf(y1, c[2 * k + 1]);
+  }
+  const float t0 = 1e-3f * sqrtf(l2[0]), t1 = 1e-3f * sqrtf(l2[1]);
+  ok = ok && fabsf(ex[0] + ex[2]) <= t0 && fabsf(ey[0] + ey[2]) <= t0 && fabsf(ex[1] + ex[3]) <= t1 && fabsf(ey[1] + ey[3]) <= t1;
+  ok = ok && fabsf(ex[0] * ex[1] + ey[0] * ey[1]) <= 1e-3f * sqrtf(l2[0] * l2[1]);
+  float a = atan2f(ey[0], ex[0]);                        // direction of one edge, folded to [0, pi/2)
+  a = a < 0.f ? a + 3.14159265f : a;
+  a = a >= 1.57079633f ? a - 1.57079633f : a;
+  o[15] = (ok && a == a) ? 1.f : 0.f;
+  o[20] = x0; o[21] = y0; o[22] = x1; o[23] = y1; o[24] = a; o[25] = 0.f;
+}
+__device__ __forceinline__ bool w_pair_skippable(const float* a, const float* b) {   // a, b: prepped boxes (PREP_F floats)
+  RD_NOCONTRACT
+  const bool apart = a[22] + 0.01f < b[20] || b[22] + 0.01f < a[20] || a[23] + 0.01f < b[21] || b[23] + 0.01f < a[21];
+  float d = fabsf(a[24] - b[24]);
+  d = fminf(d, 1.57079633f - d);
+  return a[15] != 0.f && b[15] != 0.f && apart && d >= 0.01f;
+}
 
 // BBoxHash::getHash (nms.h:268-291): cells (i, j) with i in [c0, c2), j in [c1, c3), key i*100 + j (int).  Two boxes are
 // compared iff they share a key (createBBoxMap / getFilterResult, nms.h:256-267,292-303).  i1 - i2 takes every value of
@@ -35,7 +82,6 @@ __device__ __forceinline__ bool w_share_cell(const int* a, const int* b) {
   return max(dlo, dmin) <= min(dhi, dmax);
 }
 
-#define RD_NOCONTRACT _Pragma("clang fp contract(off)")
 
 __device__ __forceinline__ int w_sgn(float k) {  // nms.h:48-52, EPS = 1e-5
   RD_NOCONTRACT
@@ -278,7 +324,7 @@ __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict_
   o[12] = area / 2;
   o[13] = b[9];
   o[14] = b[10];
-  o[15] = 0.f;
+  w_box_domain(b, o);
 }
 
 // Pair tiles: 64 rows x WN_CT columns per wave -- row block rb (64 consecutive processing positions, or 64 consecutive entries
@@ -302,7 +348,7 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
                                                         unsigned long long* __restrict__ vote, int nwcap, WnmsBatch bs,
                                                         const int* __restrict__ rows, const int* __restrict__ nrows,
                                                         const unsigned long long* __restrict__ supp_state, int rb_begin,
-                                                        int rb_end) {
+                                                        int rb_end, int allow_skip) {
   // rows == nullptr: row blocks [rb_begin, rb_end) of the processing order (first round).  Otherwise (second round) the row
   // blocks are 64 consecutive entries of the compacted, ascending list of rows that survived the first round.
   prep += blockIdx.z * bs.prep; thr += blockIdx.z * bs.words; vote += blockIdx.z * bs.words;
@@ -368,7 +414,8 @@ __global__ __launch_bounds__(64) void wnms_pairs_kernel(const float* __restrict_
         int oc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) oc[k] = __float_as_int(colp[c * PREP_F + 16 + k]);
-        if (!w_share_cell(mc, oc)) cand &= ~(1u << c);
+        // (round 4) ... and not a pair whose clip cannot pass either threshold (w_pair_skippable above): far apart, well conditioned
+        if (!w_share_cell(mc, oc) || (allow_skip && w_pair_skippable(mine, &colp[c * PREP_F]))) cand &= ~(1u << c);
       }
     }
     if constexpr (BAL) {
@@ -1055,6 +1102,18 @@ __global__ __launch_bounds__(64) void single_overlap_kernel(const float* __restr
   w_prep_box(a + i * 12, pa);
   w_prep_box(b + i * 12, pb + t * 16);
   out[i] = w_overlap(pa, pb + t * 16, is3d != 0, EL);
+}
+
+// the rejection test of the pair kernel on n independent row pairs (tests / characterisation only): out[i] = 1 if the pair kernel
+// would not clip (a[i], b[i])
+__global__ __launch_bounds__(64) void pair_skippable_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                            unsigned char* __restrict__ out) {
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float pa[PREP_F], pb[PREP_F];
+  w_box_domain(a + i * 12, pa);
+  w_box_domain(b + i * 12, pb);
+  out[i] = w_pair_skippable(pa, pb) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void iota_order_kernel(int* order, int n) {

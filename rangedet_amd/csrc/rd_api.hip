@@ -676,11 +676,14 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   // (1 - 2 k rows: <= 2048 tiles per round), grid-strided beyond that -- so the launch size does not grow with the capacity
   const int ct = dev_switches().wnms_ct == 32 ? 32 : dev_switches().wnms_ct == 16 ? 16 : 8;   // columns per pair tile
   const int pgrid = std::min(2048, std::max(64, nb * (64 / ct) * std::min(nb, 16)));
+  // the rejection test of the pair kernel (k_wnms.h w_pair_skippable) is only sound for thresholds far above the noise the
+  // reference's clipper returns on disjoint boxes (<= 9e-9 inside the test's domain); RD_WNMS_NO_SKIP: every pair clipped (A/B)
+  const int allow_skip = thresh >= 1e-3f && thresh_vote >= 1e-3f && !dev_switches().wnms_no_skip;
   auto pairs = [&](const int* rows, const int* nrows, const unsigned long long* supp, int rb_end) {
     auto k = dev_switches().wnms_bal ? (ct == 8 ? wnms_pairs_kernel<8, true> : ct == 16 ? wnms_pairs_kernel<16, true> : wnms_pairs_kernel<32, true>)
                                      : (ct == 8 ? wnms_pairs_kernel<8, false> : ct == 16 ? wnms_pairs_kernel<16, false> : wnms_pairs_kernel<32, false>);
     hipLaunchKernelGGL(k, dim3(pgrid, 1, B), dim3(64), 0, st, w.prep, Kcap, d_count, thresh, thresh_vote, is3d, w.thr, w.vote,
-                       w.nwcap, bs, rows, nrows, supp, 0, rb_end);
+                       w.nwcap, bs, rows, nrows, supp, 0, rb_end, allow_skip);
   };
   pairs(nullptr, nullptr, nullptr, two ? nb1 : nb);
   // capacities up to 8 192 rows: the four-wave scan with grouped staging (RD_WNMS_SCAN1 / a forced tile width: the single-wave form)
@@ -727,6 +730,12 @@ int rd_single_overlap(const float* dets_a, const float* dets_b, long n, int is3d
   hipLaunchKernelGGL(single_overlap_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dets_a, dets_b, n,
                      is3d, out);
   return check_launch("single_overlap");
+}
+int rd_wnms_pair_skippable(const float* dets_a, const float* dets_b, long n, unsigned char* out, void* stream) {
+  RD_REQUIRE(dets_a && dets_b && out && n >= 0, RD_EINVAL, "wnms_pair_skippable: null pointer");
+  if (n == 0) return RD_OK;
+  hipLaunchKernelGGL(pair_skippable_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dets_a, dets_b, n, out);
+  return check_launch("wnms_pair_skippable");
 }
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
   RD_REQUIRE(K >= 0 && (K == 0 || (dets_host && order_host)), RD_EINVAL, "wnms_order_host: bad arguments");

@@ -52,6 +52,7 @@ struct DevSwitches {
   int wnms_bal;            // RD_WNMS_BAL (default 0; measured slower): the candidate pairs of a pair tile are dealt out evenly over the wave's lanes
   bool wnms_scan1;         // RD_WNMS_SCAN1: the single-wave scan at every capacity (default: four waves with grouped staging up to 8 192 rows)
   int wnms_ct;             // RD_WNMS_CT (8 default, 16, 32): columns per pair tile
+  bool wnms_no_skip;       // RD_WNMS_NO_SKIP: clip every pair the reference clips (no rejection test, k_wnms.h w_pair_skippable)
 };
 inline const DevSwitches& dev_switches() {
   static const DevSwitches s = [] {
@@ -67,6 +68,7 @@ inline const DevSwitches& dev_switches() {
     d.wnms_one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;
     d.wnms_ct = num("RD_WNMS_CT", 8);
     d.wnms_scan1 = getenv("RD_WNMS_SCAN1") != nullptr;
+    d.wnms_no_skip = getenv("RD_WNMS_NO_SKIP") != nullptr;
     d.wnms_bal = num("RD_WNMS_BAL", 0);
     return d;
   }();

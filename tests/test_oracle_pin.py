@@ -33,6 +33,18 @@ def test_pair_overlap_golden():
     assert _biteq(got3, g["iou3d"])
 
 
+def test_spurious_overlap_golden():
+    """pair_overlaps_spurious.npz: 1.6k pairs of DISJOINT boxes on which the reference's clipper returns a positive value (edge
+    directions tied within its EPS, nearly parallel boxes, ill-conditioned geometry; tests/golden/make_spurious_golden.py) -- the
+    restatement follows it bit for bit on its pathological path too (NaNs as NaNs)."""
+    g = np.load(os.path.join(GOLD, "pair_overlaps_spurious.npz"))
+    assert len(g["iou"]) > 1000 and (g["iou"] >= 0.1).sum() > 500
+    got = np.array([O.single_overlap(a, b, False) for a, b in zip(g["a"], g["b"])], np.float32)
+    assert _biteq(got, g["iou"])
+    got3 = np.array([O.single_overlap(a, b, True) for a, b in zip(g["a"], g["b"])], np.float32)
+    assert _biteq(got3, g["iou3d"])
+
+
 def test_golden_present():
     assert len(glob.glob(os.path.join(GOLD, "wnms_*.npz"))) >= 8
 
