@@ -722,11 +722,14 @@ def test_spurious_overlaps_and_the_rejection_test(be):
         L.call("rd_single_overlap", be.ptr(be.up(a)), be.ptr(be.up(b)), n, is3d, be.ptr(out), be.stream)
         got = be.down(out, np.float32, (n,))
         bad = got.view(np.uint32) != g[key].view(np.uint32)
-        # the device's atan2f differs from glibc's by an ulp on some edges, and these pairs sit ON the |angle difference| < 1e-5
-        # tie of nms.h:58-64: a pair within rounding of that threshold may fall on the other side of it (the CPU build of the same
-        # sources, which uses glibc, must be exact)
-        print("spurious golden (%s): %d of %d values differ from the reference" % (key, int(bad.sum()), n))
-        assert bad.sum() <= (0 if be.name == "emu" else n // 50)
+        # the device's atan2f differs from glibc's by an ulp or two on some edges, and many of these pairs sit ON the |angle
+        # difference| < 1e-5 tie of nms.h:58-64: a pair within rounding of that threshold (tie_margin, stored with the vectors) may
+        # fall on the other side of it.  Every pair at least 3e-6 rad away from the threshold must be bit-equal; the CPU build of
+        # the same sources, which calls glibc's atan2f, must be bit-equal on all of them
+        robust = g["tie_margin"] > 3e-6
+        print("spurious golden (%s): %d of %d values differ from the reference, %d of them among the %d pairs clear of the tie threshold" %
+              (key, int(bad.sum()), n, int((bad & robust).sum()), int(robust.sum())))
+        assert not (bad & robust).any() and (be.name != "emu" or not bad.any())
     skip = be.empty(n)
     L.call("rd_wnms_pair_skippable", be.ptr(be.up(a)), be.ptr(be.up(b)), n, be.ptr(skip), be.stream)
     s = be.down(skip, np.uint8, (n,))
