@@ -290,6 +290,14 @@ int rd_rotated_iou_8pt(const float* boxes1, const float* boxes2, float* ious, lo
  * argmax (B, N) int32, optional (NULL): index of the first GT box reaching that maximum (0 when every IoU is 0). */
 int rd_batch_rotated_iou(const float* proposal, int p_stride, const float* gt_bbox, float* iou_map, int* argmax, int B, long N,
                          int n_gt, void* stream);
+/* The same op with iou_type '3d' (operator_py/batch_rotated_iou.py:17-18,36-39,51-68; _contrib_RotatedIOU on 7-dim boxes,
+ * operator_cxx/contrib/rotated_iou-inl.h:495-522): proposal (B, N, p_stride >= 10: 8 BEV corners + z0, z1) is converted to
+ * [cx, cy, cz, length, width, height, yaw] (to_box_type_7), the yaw of proposals AND of gt_bbox7 (B, n_gt <= 256, 7) is negated, and
+ * iou_map (B, N) = max over the frame's GT boxes of the VOLUME IoU after the same cleaning.  argmax as above.
+ * rd_rotated_iou_7: the 7-dim IoU matrix itself, boxes [x, y, z, w, l, h, angle] as the reference op takes them. */
+int rd_batch_rotated_iou_3d(const float* proposal, int p_stride, const float* gt_bbox7, float* iou_map, int* argmax, int B, long N,
+                            int n_gt, void* stream);
+int rd_rotated_iou_7(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream);
 /* one frame of the above without argmax.  proposals (n, p_stride>=8) */
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt,
                      void* stream);

@@ -46,6 +46,8 @@ def lib():
                                   ctypes.c_int, fp, ip]
         L.orc_decode3d.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.orc_rotated_iou_8pt.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long]
+        L.orc_rotated_iou_7.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long]
+        L.orc_to_box_type_7.argtypes = [fp, fp, ctypes.c_long]
         L.orc_assign3d_v2.argtypes = [fp] * 6 + [ctypes.c_long, ctypes.c_int] + [ctypes.c_float] * 7 + [ip]
         L.orc_get_point_num.argtypes = [fp, ctypes.c_long, fp]
         L.orc_nms3d_overlap.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_long, ctypes.c_int]
@@ -181,6 +183,38 @@ def batch_max_iou(proposal8, gt8):
     m[m > 1.0] = 0
     m[m < 0] = 0
     return m.max(axis=1)
+
+
+def rotated_iou_7(b1, b2):
+    """_contrib_RotatedIOU on 7-dim boxes [x, y, z, w, l, h, angle] (rotated_iou-inl.h:495-522): volume IoU matrix."""
+    a, pa = _f(b1)
+    b, pb = _f(b2)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().orc_rotated_iou_7(pa, pb, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.shape[0], b.shape[0])
+    return out
+
+
+def to_box_type_7(p10):
+    """BatchRotatedIOU.to_box_type_7 (operator_py/batch_rotated_iou.py:51-68): (n,10) corner boxes -> (n,7)."""
+    a, pa = _f(p10)
+    out = np.empty((a.shape[0], 7), dtype=np.float32)
+    lib().orc_to_box_type_7(pa, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.shape[0])
+    return out
+
+
+def batch_max_iou_3d(proposal10, gt7):
+    """operator_py/batch_rotated_iou.py:17-18,36-49 ('3d'): proposals to 7-dim, the yaw of BOTH sides negated (:37-38), volume IoU,
+    clean NaN/Inf/>1/<0 to 0, max over GT.  Returns (max, full matrix)."""
+    r = to_box_type_7(proposal10)
+    g = np.array(gt7, dtype=np.float32)
+    r[:, 6] = -1 * r[:, 6]
+    g[:, 6] = -1 * g[:, 6]
+    m = rotated_iou_7(r, g)
+    m[np.isnan(m)] = 0
+    m[np.isinf(m)] = 0
+    m[m > 1.0] = 0
+    m[m < 0] = 0
+    return m.max(axis=1), m
 
 
 def bbox3d_10dim_to_11dim(b10):

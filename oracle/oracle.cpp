@@ -459,6 +459,99 @@ void orc_decode3d(const float* delta, const float* pc, float* out, long n, int b
   }
 }
 
+// ---- 7-dim boxes [x, y, z, w, l, h, angle] (rotated_iou-inl.h:96-110,174-184,284-386,495-507): volume IoU ----------------------
+static int inside_xyzwlh(const float* box, Pt p) {  // check_in_box2d_xyzwlh :96-110
+  float angle_cos = cosf(-box[6]), angle_sin = sinf(-box[6]);
+  float rot_x = (p.x - box[0]) * angle_cos + (p.y - box[1]) * angle_sin + box[0];
+  float rot_y = -(p.x - box[0]) * angle_sin + (p.y - box[1]) * angle_cos + box[1];
+  return (rot_x >= box[0] - box[3] / 2 && rot_x <= box[0] + box[3] / 2 && rot_y >= box[1] - box[4] / 2 && rot_y <= box[1] + box[4] / 2);
+}
+static void corners_xyzwlh(const float* box, Pt* c) {  // :294-323 (rotate_around_center :174-184: a rotation by -angle)
+  float x = box[0], y = box[1], w = box[3], l = box[4];
+  c[0] = {x - w / 2, y - l / 2};
+  c[1] = {x + w / 2, y - l / 2};
+  c[2] = {x + w / 2, y + l / 2};
+  c[3] = {x - w / 2, y + l / 2};
+  float ac = cosf(box[6]), as = sinf(box[6]);
+  for (int k = 0; k < 4; ++k) {
+    float nx = (c[k].x - x) * ac + (c[k].y - y) * as + x;
+    float ny = -(c[k].x - x) * as + (c[k].y - y) * ac + y;
+    c[k] = {nx, ny};
+  }
+  c[4] = c[0];
+}
+static float overlap_xyzwlh(const float* A, const float* B) {  // box_overlap_xyzwlh :284-386
+  Pt ac[5], bc[5];
+  corners_xyzwlh(A, ac);
+  corners_xyzwlh(B, bc);
+  Pt cp[16];
+  Pt ctr = {0, 0};
+  int cnt = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      if (seg_meet(ac[i + 1], ac[i], bc[j + 1], bc[j], cp[cnt])) {
+        ctr.x = ctr.x + cp[cnt].x;
+        ctr.y = ctr.y + cp[cnt].y;
+        cnt++;
+      }
+  for (int k = 0; k < 4; k++) {
+    if (inside_xyzwlh(A, bc[k])) {
+      ctr.x = ctr.x + bc[k].x;
+      ctr.y = ctr.y + bc[k].y;
+      cp[cnt++] = bc[k];
+    }
+    if (inside_xyzwlh(B, ac[k])) {
+      ctr.x = ctr.x + ac[k].x;
+      ctr.y = ctr.y + ac[k].y;
+      cp[cnt++] = ac[k];
+    }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; j++)
+    for (int i = 0; i < cnt - j - 1; i++)
+      if (angle_after(cp[i], cp[i + 1], ctr)) std::swap(cp[i], cp[i + 1]);
+  float area = 0;
+  for (int k = 0; k < cnt - 1; k++) {
+    Pt u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+    Pt v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+    area += crs(u, v);
+  }
+  return (float)(fabsf(area) / 2.0);
+}
+static float iou_3d_7(const float* a, const float* b) {  // iou_3d :495-507
+  float sa = a[3] * a[4] * a[5];
+  float sb = b[3] * b[4] * b[5];
+  if (sa < kEpsR || sb < kEpsR) return 0.0f;
+  float s = overlap_xyzwlh(a, b);
+  float top = std::min(a[2] + a[5] / 2.0f, b[2] + b[5] / 2.0f), bot = std::max(a[2] - a[5] / 2.0f, b[2] - b[5] / 2.0f);
+  float h = std::max(0.0f, top - bot);
+  return s * h / fmaxf(sa + sb - s * h, kEpsR);
+}
+
+extern "C" {
+// _contrib_RotatedIOU with 7-dim boxes (rotated_iou-inl.h:509-522, box_type 7); ious (n1,n2)
+void orc_rotated_iou_7(const float* b1, const float* b2, float* ious, long n1, long n2) {
+  for (long i = 0; i < n1; ++i)
+    for (long j = 0; j < n2; ++j) ious[i * n2 + j] = iou_3d_7(b1 + i * 7, b2 + j * 7);
+}
+// BatchRotatedIOU.to_box_type_7 (operator_py/batch_rotated_iou.py:51-68) for n (.., 10) rows -> (.., 7) rows, float32 numpy
+// arithmetic: means as sequential sums divided by the count, `** 0.5` as sqrtf.  (mx.numpy's reduction order is third party.)
+void orc_to_box_type_7(const float* p10, float* p7, long n) {
+  for (long i = 0; i < n; ++i) {
+    const float* p = p10 + i * 10;
+    float* o = p7 + i * 7;
+    o[0] = (((p[0] + p[2]) + p[4]) + p[6]) / 4.0f;
+    o[1] = (((p[1] + p[3]) + p[5]) + p[7]) / 4.0f;
+    o[2] = (p[8] + p[9]) / 2.0f;
+    o[3] = sqrtf((p[0] - p[2]) * (p[0] - p[2]) + (p[1] - p[3]) * (p[1] - p[3]));
+    o[4] = sqrtf((p[2] - p[4]) * (p[2] - p[4]) + (p[3] - p[5]) * (p[3] - p[5]));
+    o[5] = p[9] - p[8];
+    o[6] = atan2f(p[1] - p[3], p[0] - p[2]);
+  }
+}
+}
+
 // rotated_iou-inl.h:509-522, box_type 8 only; ious (n1,n2), pre-filled -1 then overwritten (:541).
 void orc_rotated_iou_8pt(const float* b1, const float* b2, float* ious, long n1, long n2) {
   for (long i = 0; i < n1; ++i)

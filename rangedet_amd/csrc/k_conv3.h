@@ -62,7 +62,6 @@ struct Conv3Args {
   // shared 80-channel buffer gives the agg3 producer a 160-byte pixel pitch (every 128-byte row it stores straddles two cache
   // lines).  Chunk c >= nchunk1 is chunk c - nchunk1 of x2 (same H, W; its own channel stride / offset / slot count).
   const bf16_t* x2; int x2_cs, x2_co, nchunk1, nslots2; long x2_bs;
-  int pf_res;                // (8 x 32 tiles) touch the residual lines through the halo image's padding pieces (dev switch RD_CONV_PFRES, default 1)
 };
 
 // Tile = 8 output rows x 62 columns (halo 10 x 64 pixels): wave w owns rows 2w, 2w+1, each as two 32-pixel fragments, so
@@ -311,7 +310,6 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   const unsigned char* hbase = nullptr;                   // uniform: halo pixel (0, 0), channel slot 4*hc
   bool hsok = false;
   int hcur = 0;                                           // chunk of the unit being fetched (WD: the slot test is per piece)
-  int hpf_ph = 0;
   // Tile t = wg + k*G of the list -> (column tile, row block, image).  Decoded ONCE for the workgroup's first tile; every later
   // tile is the previous one plus G in mixed radix (ncol, nrow) -- a few scalar adds and selects instead of the three software
   // integer divisions (~60 dependent scalar instructions in front of a wave's MFMAs, once per unit) a decode from t costs.
@@ -331,13 +329,6 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   const unsigned char* htile = nullptr;                   // uniform: halo pixel (0, 0) of the fetch tile, channel 0
   const unsigned char* htile2 = nullptr;                  // (two-tensor input) the same pixel of x2
   int hpxb = a.x_cs * 2, hns = 0;                         // bytes per pixel and valid 16-byte slots of the chunk being fetched
-  // (WD) residual prefetch: the wide tile's halo image is 340 pixels in 24 one-KB pieces -- the last two pieces of wave 3 only pad
-  // the DMA count and fetched the zero page.  They now TOUCH the tile's residual rows instead (one 16-byte load per 128-byte line,
-  // 128 lines per unit, the data lands in the unused tail of the halo buffer): the lines are in L2 when the epilogue reads them,
-  // instead of an HBM round trip behind the whole DMA queue at every tile end (conv2 + residual: 689 vs 878 TFLOP/s without, r03c).
-  const unsigned char* pfres = nullptr;                   // uniform: residual pixel (tile row 0, tile column 0), phase of the fetch unit
-  int pfrow0 = 0, pfcol0 = 0;
-  const bool pf_on = WD && !GRP && a.res != nullptr && (a.flags & RD_ADD) && a.pf_res;
   auto halo_tile = [&]() {                                // per fetch TILE: geometry and base address
     const int hw0 = f_ct * C3_TW - 1;
     hh0 = f_rb * C3_TH - 1;
@@ -348,10 +339,6 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             ((long)hh0 * a.W + hw0) * (long)a.x_cs * 2;
     if constexpr (WD) {
       if (a.x2) htile2 = (const unsigned char*)(a.x2 + (size_t)f_b * a.x2_bs + a.x2_co) + ((long)hh0 * a.W + hw0) * (long)a.x2_cs * 2;
-      if (pf_on) {
-        pfrow0 = f_rb * C3_TH; pfcol0 = f_ct * C3_TW;
-        pfres = (const unsigned char*)(a.res + (size_t)f_b * a.r_bs + a.r_co) + ((long)pfrow0 * a.Wo + pfcol0) * (long)a.r_cs * 2;
-      }
     }
   };
   bool hnew = true;                                       // the fetch cursor moved to a new tile: geometry not yet derived
@@ -360,7 +347,6 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     hbase = htile + hc * 64;
     hsok = hc * 4 + hs < a.nslots;
     hcur = hc;
-    if constexpr (PH) hpf_ph = f_ph * a.r_pc * 2;         // (byte offset of the fetch unit's phase in the residual)
     if constexpr (WD) {
       hpxb = a.x_cs * 2; hns = a.nslots - 4 * hc;
       if (a.x2 && hc >= a.nchunk1) { hbase = htile2 + (hc - a.nchunk1) * 64; hpxb = a.x2_cs * 2; hns = a.nslots2 - 4 * (hc - a.nchunk1); }
@@ -391,12 +377,6 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       const int hsp = (ol & 3) ^ ((cc >> 2) & 3);
       ok = hsp < hns && (unsigned)(hh0 + r) < (unsigned)a.H && cc >= hlo && cc < hlim && pp < Cfg::NPX && !(DBG & 16);
       src = hbase + (long)((r * a.W + cc) * hpxb + hsp * 16);
-      if (q >= 22 && pf_on) {   // pieces 22, 23 hold no halo pixel (16 * 22 >= 340): residual line hcur * 128 + (q - 22) * 64 + lane of the tile
-        constexpr int LPP = COUT / 64;                     // 128-byte lines per residual pixel
-        const int line = hcur * 128 + (q - 22) * 64 + ol, px = line / LPP, prow = px >> 5, pcol = px & 31;
-        ok = px < C3_TH * 32 && pfrow0 + prow < a.H && pfcol0 + pcol < a.Wo;
-        src = pfres + hpf_ph + (long)((prow * a.Wo + pcol) * a.r_cs * 2 + (line % LPP) * 128);
-      }
     } else {
     const int r = q / (2 * FC), c16 = (q % (2 * FC)) * 16;
     const int cc = c16 + l4;
@@ -991,7 +971,6 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
     a.x2 = (const bf16_t*)s2->x; a.x2_cs = s2->cs; a.x2_co = s2->co; a.x2_bs = (long)H * W * s2->cs;
     a.nchunk1 = s2->cin1 / 32; a.nslots2 = cin_slots(s2->cin2, RD_BF16); a.nslots = a.nchunk1 * 4;
   }
-  a.pf_res = sw_.conv_pfres;
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);

@@ -86,6 +86,147 @@ __device__ float r_iou8(const float* a, const float* b) {  // :388-464, :477-493
   float s = (float)((double)fabsf(area) / 2.0);
   return s / fmaxf(sa + sb - s, 1e-8f);
 }
+// ---- 7-dim boxes [x, y, z, w, l, h, angle]: volume IoU (rotated_iou-inl.h:96-110,174-184,284-386,495-507) ----------------------
+__device__ __forceinline__ int r_inside7(const float* box, RPt p) {  // check_in_box2d_xyzwlh :96-110
+  RD_NOCONTRACT_R
+  float ac = cosf(-box[6]), as = sinf(-box[6]);
+  float rx = (p.x - box[0]) * ac + (p.y - box[1]) * as + box[0];
+  float ry = -(p.x - box[0]) * as + (p.y - box[1]) * ac + box[1];
+  return rx >= box[0] - box[3] / 2 && rx <= box[0] + box[3] / 2 && ry >= box[1] - box[4] / 2 && ry <= box[1] + box[4] / 2;
+}
+__device__ __forceinline__ void r_corners7(const float* box, RPt* c) {  // :294-323, rotate_around_center :174-184
+  RD_NOCONTRACT_R
+  const float x = box[0], y = box[1], w = box[3], l = box[4];
+  c[0] = {x - w / 2, y - l / 2};
+  c[1] = {x + w / 2, y - l / 2};
+  c[2] = {x + w / 2, y + l / 2};
+  c[3] = {x - w / 2, y + l / 2};
+  const float ac = cosf(box[6]), as = sinf(box[6]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float nx = (c[k].x - x) * ac + (c[k].y - y) * as + x;
+    const float ny = -(c[k].x - x) * as + (c[k].y - y) * ac + y;
+    c[k] = {nx, ny};
+  }
+  c[4] = c[0];
+}
+// volume IoU of two 7-dim boxes whose rotated corners ac / bc (5 points, closed) are already known
+__device__ float r_iou7c(const float* a, const float* b, const RPt* ac, const RPt* bc) {  // :284-386, :495-507
+  RD_NOCONTRACT_R
+  const float sa = a[3] * a[4] * a[5], sb = b[3] * b[4] * b[5];
+  if (sa < 1e-8f || sb < 1e-8f) return 0.0f;
+  RPt cp[16];
+  RPt ctr = {0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      RPt t;
+      if (r_meet(ac[i + 1], ac[i], bc[j + 1], bc[j], t)) { cp[cnt] = t; ctr.x = ctr.x + t.x; ctr.y = ctr.y + t.y; cnt++; }
+    }
+  for (int k = 0; k < 4; k++) {
+    if (r_inside7(a, bc[k])) { ctr.x = ctr.x + bc[k].x; ctr.y = ctr.y + bc[k].y; cp[cnt++] = bc[k]; }
+    if (r_inside7(b, ac[k])) { ctr.x = ctr.x + ac[k].x; ctr.y = ctr.y + ac[k].y; cp[cnt++] = ac[k]; }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; j++)
+    for (int i = 0; i < cnt - j - 1; i++)
+      if (atan2f(cp[i].y - ctr.y, cp[i].x - ctr.x) > atan2f(cp[i + 1].y - ctr.y, cp[i + 1].x - ctr.x)) {
+        RPt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; k++) {
+    RPt u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+    RPt v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+    area += u.x * v.y - u.y * v.x;
+  }
+  const float s = (float)((double)fabsf(area) / 2.0);
+  const float top = fminf(a[2] + a[5] / 2.0f, b[2] + b[5] / 2.0f), bot = fmaxf(a[2] - a[5] / 2.0f, b[2] - b[5] / 2.0f);
+  const float h = fmaxf(0.0f, top - bot);
+  return s * h / fmaxf(sa + sb - s * h, 1e-8f);
+}
+__global__ __launch_bounds__(256) void riou7_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
+                                                    float* __restrict__ out, long n1, long n2) {
+  long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n1 * n2) return;
+  long r = i / n2, c = i - r * n2;
+  RPt ac[5], bc[5];
+  r_corners7(b1 + r * 7, ac);
+  r_corners7(b2 + c * 7, bc);
+  out[i] = r_iou7c(b1 + r * 7, b2 + c * 7, ac, bc);
+}
+// Custom op 'batch_rotated_iou' with iou_type '3d' (operator_py/batch_rotated_iou.py:17-18,36-39,51-68): proposals (B,N,10) are
+// converted to [cx, cy, cz, length, width, height, yaw] (to_box_type_7), the yaw of proposals AND ground truth (B,n_gt,7) is negated,
+// volume IoU, cleaned, maximum over the frame's ground-truth boxes.  Same structure as the 'bev' kernel below: the frame's GT boxes,
+// their rotated corners and bounds in LDS, one thread per proposal.  A pair whose corner bounds are apart by more than a rounding
+// margin has no edge crossing (every rectangle test of :131-136 fails) and no corner inside the other box, so the reference gets
+// cnt = 0, area 0 and returns exactly 0: not clipped.
+__global__ __launch_bounds__(256) void batch_riou3d_kernel(const float* __restrict__ prop, int pstride, long prop_bs,
+                                                           const float* __restrict__ gt, long gt_bs, float* __restrict__ out,
+                                                           int* __restrict__ out_arg, long n, int ngt) {
+  RD_NOCONTRACT_R
+  __shared__ float g[256 * 7];
+  __shared__ float gc[256 * 8];   // rotated corners
+  __shared__ float gb[256 * 4];   // min x, max x, min y, max y
+  const int b = blockIdx.y;
+  gt += b * gt_bs;
+  for (int i = threadIdx.x; i < ngt * 7; i += 256) g[i] = (i % 7 == 6) ? -1 * gt[i] : gt[i];   // gt_batch[:, -1] = -1 * gt_batch[:, -1]
+  __syncthreads();
+  for (int j = threadIdx.x; j < ngt; j += 256) {
+    RPt c[5];
+    r_corners7(g + j * 7, c);
+    float lx = c[0].x, hx = c[0].x, ly = c[0].y, hy = c[0].y;
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gc[8 * j + 2 * k] = c[k].x; gc[8 * j + 2 * k + 1] = c[k].y;
+      lx = fminf(lx, c[k].x); hx = fmaxf(hx, c[k].x); ly = fminf(ly, c[k].y); hy = fmaxf(hy, c[k].y);
+      nan |= !(c[k].x == c[k].x) || !(c[k].y == c[k].y);
+    }
+    if (nan) { lx = -INFINITY; hx = INFINITY; ly = -INFINITY; hy = INFINITY; }
+    gb[4 * j] = lx; gb[4 * j + 1] = hx; gb[4 * j + 2] = ly; gb[4 * j + 3] = hy;
+  }
+  __syncthreads();
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  const float* p = prop + b * prop_bs + i * pstride;
+  float box[7];   // to_box_type_7 (:51-68), then roi_batch[:, -1] = -1 * roi_batch[:, -1]
+  box[0] = (((p[0] + p[2]) + p[4]) + p[6]) / 4.0f;
+  box[1] = (((p[1] + p[3]) + p[5]) + p[7]) / 4.0f;
+  box[2] = (p[8] + p[9]) / 2.0f;
+  box[3] = sqrtf((p[0] - p[2]) * (p[0] - p[2]) + (p[1] - p[3]) * (p[1] - p[3]));
+  box[4] = sqrtf((p[2] - p[4]) * (p[2] - p[4]) + (p[3] - p[5]) * (p[3] - p[5]));
+  box[5] = p[9] - p[8];
+  box[6] = -1 * atan2f(p[1] - p[3], p[0] - p[2]);
+  RPt ac[5];
+  r_corners7(box, ac);
+  float lx = ac[0].x, hx = ac[0].x, ly = ac[0].y, hy = ac[0].y;
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lx = fminf(lx, ac[k].x); hx = fmaxf(hx, ac[k].x); ly = fminf(ly, ac[k].y); hy = fmaxf(hy, ac[k].y);
+    finite &= ac[k].x == ac[k].x && ac[k].y == ac[k].y;
+  }
+  // rounding margin: the in-box test (:96-110) rotates the POINT back instead of comparing with the rotated corners
+  const float mg = 1e-4f * (1.f + fabsf(lx) + fabsf(hx) + fabsf(ly) + fabsf(hy));
+  float best = -1.f;
+  int arg = 0;
+  for (int j = 0; j < ngt; ++j) {
+    float v = 0.f;
+    const bool apart = hx + mg < gb[4 * j] || gb[4 * j + 1] + mg < lx || hy + mg < gb[4 * j + 2] || gb[4 * j + 3] + mg < ly;
+    if (!(finite && apart)) {
+      RPt bc[5];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bc[k] = {gc[8 * j + 2 * k], gc[8 * j + 2 * k + 1]};
+      bc[4] = bc[0];
+      v = r_iou7c(box, g + j * 7, ac, bc);
+      if (!(v == v) || isinf(v) || v > 1.0f || v < 0.f) v = 0.f;
+    }
+    if (v > best) { best = v; arg = j; }
+  }
+  out[b * n + i] = best;
+  if (out_arg) out_arg[b * n + i] = arg;
+}
 __global__ __launch_bounds__(256) void riou8_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
                                                     float* __restrict__ out, long n1, long n2) {
   long i = blockIdx.x * 256L + threadIdx.x;

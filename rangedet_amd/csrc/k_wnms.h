@@ -31,14 +31,14 @@ constexpr int PREP_F = 26;  // floats per prepped box: 8 corners, 4 angles, area
 // EPS = 1e-5 (nms.h:58-64,104-106: one of the two half-planes is dropped and the rest can enclose an area: "IoU" up to 1e4), when
 // the boxes are nearly parallel (lines meeting thousands of metres away: cancellation in nms.h:54-56,74-90; seen up to 3e-3 rad
 // for 40 m boxes, 2e-4 rad up to 20 m) or when the geometry is ill-conditioned (edges of centimetres, coordinates of kilometres).
-// Characterised on the reference itself, compiled as-is (oracle/ref_overlap_study.cpp, 1.1e10 disjoint pairs of nine families,
+// Characterised on the reference itself, compiled as-is (oracle/ref_overlap_study.cpp, 8.1e9 disjoint pairs of nine families,
 // profiles/r04_nms_spurious_study.txt).  So a pair is skipped -- its overlap taken as 0, exactly what every comparison of the
 // reference's value would give -- only when ALL of this holds, with an order of magnitude of margin on each bound:
 //   * both boxes are rectangles (1e-3 relative) with edges of 0.2 .. 25 m and |coordinates| <= 200 m       (w_box_domain)
 //   * their bounding rectangles are more than 0.01 m apart (then the polygons are disjoint, whatever the rounding)
 //   * their edge directions mod 90 degrees differ by at least 0.01 rad
 //   * thresh >= 1e-3 and thresh_vote >= 1e-3 (the launcher's condition; the largest value seen inside the domain is 9e-9)
-// Zero violations on the 1.1e10 pairs; every other pair is clipped as before.  oracle/ and the golden vectors know nothing of this.
+// Zero violations on the 8.1e9 pairs; every other pair is clipped as before.  oracle/ and the golden vectors know nothing of this.
 __device__ __forceinline__ void w_box_domain(const float* c, float* o) {   // c: the 8 corner floats of a dets row, as given
   RD_NOCONTRACT
   float ex[4], ey[4], l2[4];

@@ -782,6 +782,22 @@ int rd_batch_rotated_iou(const float* proposal, int p_stride, const float* gt_bb
                      N * (long)p_stride, gt_bbox, (long)n_gt * 8, iou_map, argmax, N, n_gt);
   return check_launch("batch_rotated_iou");
 }
+int rd_rotated_iou_7(const float* boxes1, const float* boxes2, float* ious, long n1, long n2, void* stream) {
+  RD_REQUIRE(boxes1 && boxes2 && ious, RD_EINVAL, "rotated_iou_7: null pointer");
+  if (n1 * n2 == 0) return RD_OK;
+  hipLaunchKernelGGL(riou7_kernel, dim3((unsigned)((n1 * n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, ious, n1, n2);
+  return check_launch("rotated_iou_7");
+}
+int rd_batch_rotated_iou_3d(const float* proposal, int p_stride, const float* gt_bbox7, float* iou_map, int* argmax, int B, long N,
+                            int n_gt, void* stream) {
+  RD_REQUIRE(proposal && gt_bbox7 && iou_map, RD_EINVAL, "batch_rotated_iou_3d: null pointer");
+  RD_REQUIRE(B > 0 && N > 0 && p_stride >= 10, RD_ESHAPE, "batch_rotated_iou_3d: proposal rows need the 8 corners + z0, z1 (stride %d)", p_stride);
+  RD_REQUIRE(n_gt >= 1 && n_gt <= 256, RD_ESHAPE, "batch_rotated_iou_3d: n_gt %d (1..256; the config pads to 200)", n_gt);
+  ProfScope ps(RD_PROF_DECODE, (hipStream_t)stream);
+  hipLaunchKernelGGL(batch_riou3d_kernel, dim3((unsigned)((N + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, proposal, p_stride,
+                     (long)N * p_stride, gt_bbox7, (long)n_gt * 7, iou_map, argmax, N, n_gt);
+  return check_launch("batch_rotated_iou_3d");
+}
 int rd_batch_max_iou(const float* proposals, int p_stride, const float* gt8, float* out, long n, int n_gt, void* stream) {
   return rd_batch_rotated_iou(proposals, p_stride, gt8, out, nullptr, 1, n, n_gt, stream);
 }

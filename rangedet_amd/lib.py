@@ -88,6 +88,8 @@ SIGNATURES = {
     "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "rd_batch_rotated_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "rd_batch_rotated_iou_3d": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "rd_rotated_iou_7": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "rd_batch_max_iou": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rd_gather_keep_scores": (c_int, [c_void_p, c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "rd_nms3d_workspace_bytes": (c_size_t, [c_long, c_int]),

@@ -15,7 +15,7 @@ Fusions (each replaces an MXNet op chain of the reference by one kernel):
   sigmoid + Custom(get_sorted_foreground)          -> rd_sorted_foreground(apply_sigmoid=1)     (builder.py:459-461,512-521)
   contrib.Decode3DBbox                             -> rd_decode3d_bbox                          (builder.py:522-525)
   contrib.NMS3D (wnms=False)                       -> rd_nms3d                                  (builder.py:530-534)
-  Custom(batch_rotated_iou, iou_type='bev')        -> rd_batch_rotated_iou                      (builder.py:176-182)
+  Custom(batch_rotated_iou, iou_type='bev' | '3d') -> rd_batch_rotated_iou / rd_batch_rotated_iou_3d  (builder.py:176-182)
 Anything that does not match raises NotImplementedError at lowering time -- there is no slow generic path.
 """
 import os
@@ -599,18 +599,20 @@ class Lowering:
         key = ("briou", s.uid)
         if key in self.memo:
             return self.memo[key]
-        if s.attrs.get("iou_type", "bev") != "bev":
-            raise NotImplementedError("batch_rotated_iou: iou_type %r (only 'bev', the config's loss.iou_type)" % s.attrs.get("iou_type"))
+        iou_type = s.attrs.get("iou_type", "bev")
+        if iou_type not in ("bev", "3d"):
+            raise ValueError("batch_rotated_iou: iou_type %r ('bev' or '3d')" % iou_type)           # batch_rotated_iou.py:40-41,91-92
+        gdim = 8 if iou_type == "bev" else 7                                                      # :86-89
         prop, gt = s.inputs
         kind, boxes = self.emit_value(prop)
         gt = _strip_cast(gt)
         if kind != "flat" or len(boxes.shape) != 2 or boxes.shape[1] != 10 or gt.op != "var":
             raise NotImplementedError("batch_rotated_iou: proposal must be a (B,N,10) box tensor, gt_bbox an input variable")
         gshape = self.want_input(gt.name)
-        if len(gshape) != 2 or gshape[1] != 8 or gshape[0] > 256:
-            raise ValueError("batch_rotated_iou: gt_bbox shape %s (need (n_gt <= 256, 8))" % (gshape,))   # batch_rotated_iou.py:78-85
+        if len(gshape) != 2 or gshape[1] != gdim or gshape[0] > 256:
+            raise ValueError("batch_rotated_iou (%s): gt_bbox shape %s (need (n_gt <= 256, %d))" % (iou_type, gshape, gdim))   # batch_rotated_iou.py:78-89
         out = FlatRef(self.new_buf(self.B * boxes.shape[0] * 4, persistent=True), (boxes.shape[0],))
-        self.step("batch_riou", boxes=boxes, gt=gt.name, N=boxes.shape[0], n_gt=gshape[0], out=out)
+        self.step("batch_riou", boxes=boxes, gt=gt.name, N=boxes.shape[0], n_gt=gshape[0], out=out, iou_type=iou_type)
         self.memo[key] = out
         return out
 

@@ -325,8 +325,10 @@ class Executor:
                        b["box_type"], b["is_bin"], st_)
             elif k == "batch_riou":
                 g = din(b["gt"])
-                assert tuple(g.shape) == (B, b["n_gt"], 8), (b["gt"], tuple(g.shape))
-                L.call("rd_batch_rotated_iou", self.p(b["boxes"]), 10, A.ptr(g), self.p(b["out"]), None, B, b["N"], b["n_gt"], st_)
+                three_d = b.get("iou_type", "bev") == "3d"
+                assert tuple(g.shape) == (B, b["n_gt"], 7 if three_d else 8), (b["gt"], tuple(g.shape))
+                L.call("rd_batch_rotated_iou_3d" if three_d else "rd_batch_rotated_iou", self.p(b["boxes"]), 10, A.ptr(g), self.p(b["out"]),
+                       None, B, b["N"], b["n_gt"], st_)
             elif k == "nms3d":
                 L.call("rd_nms3d", self.p(b["boxes"]), B, b["N"], b["thr"], b["max_keep"], b["normal_iou"], self.p(b["keep"]),
                        self.p(b["out"]), A.ptr(b["ws"]), b["ws_bytes"], st_)

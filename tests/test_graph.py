@@ -741,6 +741,25 @@ def test_batch_rotated_iou_through_the_symbol_api(be):
     got = np.array(be.alloc.to_numpy(outs[-1]))[0]
     ref = O.batch_max_iou(bx[:, :8], gt)
     assert got.shape == (k,) and np.abs(got - ref).max() < 1e-5 and (ref > 0.3).sum() >= 20
-    with pytest.raises(NotImplementedError):
+    # iou_type '3d' (batch_rotated_iou.py:17-18,36-39): gt_bbox is (200, 7), the proposals are converted on the device
+    iou3 = mx.sym.Custom(proposal=boxes_sym, gt_bbox=mx.var("gt7"), op_type="batch_rotated_iou", iou_type="3d", name="batch_rotated_iou_3d_veh")
+    plan3 = lower(mx.sym.Group(list(sym.inputs) + [iou3]), dict(small_shapes(H, W), gt7=(200, 7)), R.RD_F32, 1)
+    assert plan3.steps[-1]["kind"] == "batch_riou" and plan3.steps[-1]["iou_type"] == "3d"
+    gt7 = np.zeros((200, 7), np.float32)
+    gt7[:, 3:6] = 1e-3
+    p10 = rb[::k // 20][:20].copy()
+    p10[:, :8] += 0.2
+    gt7[:20] = O.to_box_type_7(p10)
+    ex3 = Executor(plan3, P, lib=be.lib, alloc=be.alloc)
+    outs3 = ex3.forward(dict(fr, gt7=gt7[None]))
+    be.alloc.sync()
+    bx3 = np.array(be.alloc.to_numpy(outs3[2]))[0]
+    got3 = np.array(be.alloc.to_numpy(outs3[-1]))[0]
+    ref3 = O.batch_max_iou_3d(bx3, gt7)[0]
+    assert got3.shape == (k,) and np.abs(got3 - ref3).max() < 1e-5 and (ref3 > 0.2).sum() >= 20
+    with pytest.raises(ValueError):
         lower(mx.sym.Group([mx.sym.Custom(proposal=boxes_sym, gt_bbox=mx.var("g"), op_type="batch_rotated_iou", iou_type="3d")]),
-              dict(shapes, g=(200, 7)), R.RD_F32, 1)
+              dict(shapes, g=(200, 8)), R.RD_F32, 1)                     # the '3d' op takes 7-dim ground truth (batch_rotated_iou.py:88-89)
+    with pytest.raises(ValueError):
+        lower(mx.sym.Group([mx.sym.Custom(proposal=boxes_sym, gt_bbox=mx.var("g"), op_type="batch_rotated_iou", iou_type="giou")]),
+              dict(shapes, g=(200, 8)), R.RD_F32, 1)

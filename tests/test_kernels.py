@@ -1041,6 +1041,58 @@ def test_batch_rotated_iou(be):
         be.lib.call("rd_batch_rotated_iou", be.ptr(be.up(prop)), 10, be.ptr(be.up(gt)), be.ptr(be.empty(64)), None, 2, 10, 300, be.stream)
 
 
+def _gt7_from_corners(g8, z0, z1):
+    """(n,8) BEV corners + z range -> (n,7) [cx, cy, cz, length, width, height, yaw]: what the '3d' op is fed as gt_bbox
+    (batch_rotated_iou.py:86-89), made the way to_box_type_7 makes the proposals' 7-dim rows."""
+    p = np.concatenate([g8, np.full((len(g8), 1), z0, np.float32), np.full((len(g8), 1), z1, np.float32)], 1).astype(np.float32)
+    return O.to_box_type_7(p)
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_batch_rotated_iou_3d(be):
+    """Custom op 'batch_rotated_iou' with iou_type '3d' (operator_py/batch_rotated_iou.py:17-18,36-39,51-68; the 7-dim volume IoU of
+    rotated_iou-inl.h:495-522): (B,N,10) proposals x (B,200,7) GT -> (B,N) max cleaned volume IoU + argmax, against the oracle's full
+    matrix -- proposals converted by to_box_type_7, the yaw of both sides negated; GT padding rows (zero volume), jittered and
+    identical copies of GT boxes, boxes on the origin, partial height overlap.  And rd_rotated_iou_7 = the op's 7-dim matrix."""
+    B, N, n_real = 2, 600 if be.name == "emu" else 4000, 12
+    prop, gt8 = _riou_case(B, N, n_real, seed=15)
+    rng = np.random.default_rng(3)
+    prop[:, :, 8] = rng.uniform(-1.5, -0.5, (B, N)).astype(np.float32)
+    prop[:, :, 9] = prop[:, :, 8] + rng.uniform(1.2, 2.2, (B, N)).astype(np.float32)
+    gt7 = np.zeros((B, 200, 7), np.float32)
+    gt7[:, :, 3:6] = 1e-3                                              # padding rows: volume 1e-9 < EPS -> IoU 0 (rotated_iou-inl.h:499)
+    for b in range(B):
+        gt7[b, :n_real] = _gt7_from_corners(gt8[b, :n_real], -1.2, 0.7)
+    L = be.lib
+    out, arg = be.empty(B * N * 4), be.empty(B * N * 4)
+    L.call("rd_batch_rotated_iou_3d", be.ptr(be.up(prop)), 10, be.ptr(be.up(gt7)), be.ptr(out), be.ptr(arg), B, N, 200, be.stream)
+    got, ga = be.down(out, np.float32, (B, N)), be.down(arg, np.int32, (B, N))
+    hits = 0
+    for b in range(B):
+        ref, m = O.batch_max_iou_3d(prop[b], gt7[b])
+        assert np.abs(got[b] - ref).max() < 1e-5, np.abs(got[b] - ref).max()
+        top2 = np.sort(m, axis=1)[:, -2:]
+        clear = top2[:, 1] - top2[:, 0] > 1e-4
+        assert np.array_equal(ga[b][clear], m.argmax(axis=1)[clear])
+        assert np.array_equal(ga[b][ref == 0], np.zeros((ref == 0).sum(), np.int32))
+        hits += int((ref > 0).sum())
+        # the volume IoU really is the BEV overlap times the height overlap: below the BEV IoU wherever the heights differ
+        bev = O.batch_max_iou(prop[b, :, :8], gt8[b])
+        assert (ref <= bev + 1e-5).all() and (ref[bev > 0.2] < bev[bev > 0.2]).mean() > 0.9
+    assert hits > 100
+    # the z-sign flip matters (batch_rotated_iou.py:37-38): without it the boxes would be mirrored
+    r7 = O.to_box_type_7(prop[0])
+    a7, g7 = r7.copy(), gt7[0].copy()
+    a7[:, 6] *= -1
+    g7[:, 6] *= -1
+    mo = be.empty(N * 200 * 4)
+    L.call("rd_rotated_iou_7", be.ptr(be.up(a7)), be.ptr(be.up(g7)), be.ptr(mo), N, 200, be.stream)
+    assert np.allclose(be.down(mo, np.float32, (N, 200)), O.rotated_iou_7(a7, g7), atol=1e-5, equal_nan=True)
+    assert np.abs(O.rotated_iou_7(r7, gt7[0]) - O.rotated_iou_7(a7, g7)).max() > 0.1
+    with pytest.raises(R.RangeDetError):
+        L.call("rd_batch_rotated_iou_3d", be.ptr(be.up(prop)), 8, be.ptr(be.up(gt7)), be.ptr(be.empty(64)), None, 2, 10, 200, be.stream)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
 def test_batch_rotated_iou_full_level(be):
