@@ -164,8 +164,11 @@ int rd_conv2d_bn_act_head_out_pair(const void* x0, int x0_coff, const void* w0_p
 /* 3x3 stride-1 conv + BatchNorm (+ReLU) over the channel concatenation [x1 (cin1, a multiple of 32) | x2 (cin2, a multiple of 8)]
  * of two tensors of the same B x H x W -- the concat itself (mx.sym.concat of the range image with the agg3 feature map,
  * dla_backbone.py:153-154, consumed by the level-0 tower convs head/builder.py:221-240) is never written: each tensor keeps its own
- * channel stride.  16-bit types, RD_SCALE_FOLDED weights: w_packed = rd_pack_conv3x3_ex_host of the (cout, cin1 + cin2, 3, 3) weight
- * in that channel order, stride 1.  No residual. */
+ * channel stride.  16-bit types, RD_SCALE_FOLDED weights: w_packed = rd_pack_conv3x3_cat_host (HOST) of the (cout, cin1 + cin2, 3, 3)
+ * weight in that channel order, rd_conv3x3_cat_packed_bytes long (with cin1 = 64, cin2 <= 16 the x2 chunk runs as five two-tap
+ * steps on its one 16-channel slot instead of nine steps of two slots).  No residual. */
+size_t rd_conv3x3_cat_packed_bytes(int cin1, int cin2, int cout);
+int rd_pack_conv3x3_cat_host(const float* w, const float* fold_scale, int cout, int cin1, int cin2, int dtype, void* out_host);
 int rd_conv3x3_bn_act_cat(const void* x1, int x1_cstride, int x1_coff, int cin1, const void* x2, int x2_cstride, int x2_coff, int cin2,
                           const void* w_packed, const float* shift, void* y, int y_cstride, int y_coff, int B, int H, int W, int cout,
                           int flags, int dtype, void* stream);

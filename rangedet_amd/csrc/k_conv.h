@@ -413,7 +413,7 @@ inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const 
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
                         int cout, int flags, int sw, hipStream_t st, int ts, const struct Conv3Args* head, int dt,
                         const struct Conv3Second* g1 = nullptr, const struct Conv3Phases* ph = nullptr,
-                        const struct Conv3Src2* s2 = nullptr);
+                        const struct Conv3Src2* s2 = nullptr, int body = 0);
 
 inline int launch_conv(const TapList& tl, const void* x, int x_cs, int x_co, const void* w, const float* scale,
                        const float* shift, const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co,

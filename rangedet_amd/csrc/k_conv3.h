@@ -195,6 +195,97 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
   if (NHB == 2 && s == NS - 2 && n > cap) n = cap;
   return n;
 }
+// ---- tile bodies with units of DIFFERENT step counts (round 4, 8 x 32 tiles only) --------------------------------------------------
+// A tile is normally nchunk units of the same kind (9 or 6 steps).  Three layer classes carry structural zeros in that form:
+//   stride (1,2) on the pixel-pair view (rd_api.hip): the even pixel's 32-channel chunks only meet the three taps dw = 0, but ran
+//     all six pair-view taps (three of them on zero weights: 25 % of the layer's MFMAs);
+//   the 72-channel input of the level-0 tower convs / the 8-channel first layer: a chunk with <= 16 real channels ran two 16-channel
+//     k-steps per tap, one of them on zeros.
+// A BODY is a fixed cyclic sequence of up to four units of possibly different kinds; the tile runs it a.nchunk / NU times.  Every
+// compile-time table of the homogeneous form (tap of a step, halo pieces per step, counted waits) becomes a function of the GLOBAL
+// step index g within the body, evaluated cyclically (the step before step 0 is the body's last step: of the previous repetition
+// or of the previous tile).
+//   UK_T9 / UK_T6A / UK_T6B: the 9-tap and the two 6-tap units of the homogeneous forms (TS 0 / 1 / 2)
+//   UK_T3: 3 steps -- the three taps (dh, dw = 0) of the pair view (index 1 of the TS 1 column numbering): an even-pixel chunk
+//   UK_P5: 5 steps -- k-step 0 of step s is tap 2s, k-step 1 tap 2s + 1 (tap 9: zero weights), both on the chunk's FIRST 16
+//          channels: a chunk with at most 16 real channels in 10 instead of 18 k-steps
+// BODY 1 (stride 2), per 128-byte line of the view pixel: [T6A odd chunk | T3 even | T3 even | T6A odd] -- the chunk whose lines
+//   are new to L2 is always fetched during a 6-step unit, the 3-step units fetch the second half of a line that is already there;
+// BODY 2: [T9, T9, P5] (64 + <= 16 channels: the level-0 tower convs on [agg3 | range image]);  BODY 3: [P5] (the first layer).
+enum { UK_T9 = 0, UK_T6A = 1, UK_T6B = 2, UK_T6R = 3, UK_T3 = 4, UK_P5 = 5 };
+constexpr int uk_nsteps(int k) { return k == UK_T9 ? 9 : k == UK_T3 ? 3 : k == UK_P5 ? 5 : 6; }
+struct C3KStep { int dh, dw, slot; };   // tap row, column index into the per-lane column offsets, 16-channel slot of the chunk
+constexpr C3KStep uk_kstep(int k, int s, int ks) {
+  if (k == UK_P5) { const int t = 2 * s + ks > 8 ? 8 : 2 * s + ks; return C3KStep{t / 3, t % 3, 0}; }
+  const int T = k == UK_T9 ? s : k == UK_T3 ? 3 * s + 1 : 3 * (s / 2) + (s % 2) + (k == UK_T6B ? 1 : 0);
+  return C3KStep{T / 3, T % 3, ks};
+}
+struct C3Body { int nu; int kind[4]; };
+constexpr C3Body c3_body(int BODY) {
+  return BODY == 1 ? C3Body{4, {UK_T6A, UK_T3, UK_T3, UK_T6A}} : BODY == 2 ? C3Body{3, {UK_T9, UK_T9, UK_P5, 0}} : C3Body{1, {UK_P5, 0, 0, 0}};
+}
+constexpr int c3b_steps(int BODY) { int n = 0; for (int u = 0; u < c3_body(BODY).nu; ++u) n += uk_nsteps(c3_body(BODY).kind[u]); return n; }
+constexpr int c3b_unit(int BODY, int g) { int u = 0; while (g >= uk_nsteps(c3_body(BODY).kind[u])) { g -= uk_nsteps(c3_body(BODY).kind[u]); ++u; } return u; }
+constexpr int c3b_ord(int BODY, int g) { int u = 0; while (g >= uk_nsteps(c3_body(BODY).kind[u])) { g -= uk_nsteps(c3_body(BODY).kind[u]); ++u; } return g; }
+// halo pieces (wide tile: 6 per wave and unit) issued in step s of a unit with NS steps -- all of them early enough for the wait at
+// ordinal NS - 2 to cover them
+constexpr int uk_halo_pieces(int NS, int s) {
+  return NS == 9 ? (s == 0 ? 2 : s <= 4 ? 1 : 0) : NS == 6 ? (s <= 2 ? 2 : 0) : NS == 5 ? (s <= 1 ? 3 : 0) : (s == 0 ? 6 : 0);
+}
+constexpr int uk_halo_last(int NS) { return NS == 9 ? 4 : NS == 6 ? 2 : NS == 5 ? 1 : 0; }
+constexpr int c3b_pieces(int BODY, int g) { return uk_halo_pieces(uk_nsteps(c3_body(BODY).kind[c3b_unit(BODY, g)]), c3b_ord(BODY, g)); }
+constexpr int c3b_first(int BODY, int g) { int n = 0; for (int t = g - c3b_ord(BODY, g); t < g; ++t) n += c3b_pieces(BODY, t); return n; }
+// counted wait of global step g (c3_younger above, with the look-back running cyclically over the body)
+constexpr int c3b_younger(int BODY, int R, int IPW, int g) {
+  const int G = c3b_steps(BODY);
+  int n = (R - 3) * IPW;
+  for (int d = 1; d <= R - 2; ++d) n += c3b_pieces(BODY, ((g - d) % G + G) % G);
+  const int NS = uk_nsteps(c3_body(BODY).kind[c3b_unit(BODY, g)]), s = c3b_ord(BODY, g);
+  const int cap = (NS - 3 - uk_halo_last(NS)) * IPW;
+  return (s == NS - 2 && n > cap) ? cap : n;
+}
+// unit i of a tile (i = 0 .. nchunk - 1 in program order) -> 32-channel chunk of the (view) input it reads
+__host__ __device__ inline int c3b_chunk(int BODY, int i, int nchunk) {
+  if (BODY != 1) return i;
+  const int r2 = (i >> 2) * 2, j = i & 3, ne = nchunk >> 1;
+  return j == 0 ? ne + r2 : j == 1 ? r2 : j == 2 ? r2 + 1 : ne + r2 + 1;
+}
+// packed weights of a heterogeneous body: one slab per step in PROGRAM order, slab = [ks (2)][Cout/32][64 lanes][8] like
+// pack_taps_frag; k-step ks of step s of a unit reads channels 32*chunk + 16*slot + 8*hi + j of tap (dh, dw) (uk_kstep).
+// get(co, ci, dh, dw) -> float with dh, dw in 0..2 (dw: the unit kind's column index).  cin = channels of the (view) input.
+template <class F>
+inline void pack_body_frag(int BODY, int cin, int cout, void* out, F get, int dt = RD_BF16) {
+  const C3Body bd = c3_body(BODY);
+  const int nchunk = (cin + 31) / 32, ncb = cout / 32;
+  bf16_t* o = (bf16_t*)out;
+  for (int i = 0; i < nchunk; ++i) {
+    const int kind = bd.kind[i % bd.nu], chunk = c3b_chunk(BODY, i, nchunk);
+    for (int s = 0; s < uk_nsteps(kind); ++s)
+      for (int ks = 0; ks < 2; ++ks) {
+        const C3KStep k = uk_kstep(kind, s, ks);
+        const bool zero_tap = kind == UK_P5 && 2 * s + ks > 8;
+        for (int cb = 0; cb < ncb; ++cb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = cb * 32 + conv_row_perm(lane & 31);
+            for (int j = 0; j < 8; ++j) {
+              const int ci = chunk * 32 + k.slot * 16 + (lane >> 5) * 8 + j;
+              *o++ = h16_from_f32(dt, (ci < cin && !zero_tap) ? get(co, ci, k.dh, k.dw) : 0.f);
+            }
+          }
+      }
+  }
+}
+// Which body a folded-scale launch on the 8 x 32 tiles takes (the host packers and the launcher must agree): 1 = stride (1,2) on the
+// pixel-pair view whose even / odd halves are whole 128-byte lines (x_cstride a multiple of 64, all of them convolved),
+// 2 = [64 channels | <= 16 channels] (rd_conv3x3_bn_act_cat), 3 = at most 16 input channels, 0 = homogeneous units.
+// RD_CONV_BODY=0 (dev switch, A/B): always 0.
+inline bool conv3_bodies_on() {
+  const DevSwitches& sw_ = dev_switches();
+  return sw_.conv_body && sw_.conv_wide && sw_.conv_w30 == 2 && sw_.conv_th4 == 1 && !sw_.conv_v1;
+}
+inline int conv3_body_s2(int cin, int x_cstride, bool folded) { return folded && conv3_bodies_on() && x_cstride % 64 == 0 && cin == x_cstride ? 1 : 0; }
+inline int conv3_body_small(int cin, bool folded) { return folded && conv3_bodies_on() && cin <= 16 ? 3 : 0; }
+inline int conv3_body_cat(int cin1, int cin2, bool folded) { return folded && conv3_bodies_on() && cin1 == 64 && cin2 <= 16 ? 2 : 0; }
 // s_waitcnt immediate (gfx9): vmcnt <= vm and lgkmcnt <= lgkm, expcnt untouched
 #define C3_WAIT_IMM(vm, lgkm) (((vm) & 15) | (((vm) >> 4) << 14) | (7 << 4) | ((lgkm) << 8))
 
@@ -212,8 +303,9 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
 // weight image, shift, residual, output (and fused output conv) -- the launch then has twice the tiles per resident workgroup
 // slot (half the tail round) and one prologue / drain instead of two.  Only for the forms the lowering pairs: FOLD, no SC.
 template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2,
-          int DT = RD_BF16, bool WD = false, bool GRP = false>
+          int DT = RD_BF16, bool WD = false, bool GRP = false, int BODY = 0>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(BODY == 0 || (WD && FOLD && !GRP && !HEAD && (TS == 0 || TS == 1)), "heterogeneous tile bodies: 8 x 32 tiles, folded scales");
   static_assert(!GRP || (FOLD && !SC && !(HEAD && FPW == 4)), "two problems per launch: folded scales, no shortcut, output-conv weights from L2");
   static_assert((NHB == 2 && !WD) || FOLD, "three halo buffers / wide tile: no room for the scale / shift array");
   static_assert(!HEAD || (NCT == 4 && TS == 0 && (FPW == 4 || FC == 1)), "fused output conv: cout 128, all nine taps, 8-row tiles");
@@ -229,7 +321,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   constexpr int C3_TW = Cfg::TW, C3_ROWB = Cfg::ROWB, RW = Cfg::RW;
   constexpr int NR = FPW + NCT;                  // fragment reads per k-step
   constexpr int NM = FPW * NCT;                  // MFMAs per k-step
-  constexpr int NS = c3_nsteps(TS);              // steps (taps) per unit
+  constexpr int NS = c3_nsteps(TS);              // steps (taps) per unit (BODY 0)
+  constexpr int BG = BODY ? c3b_steps(BODY) : NS;          // steps of one repetition of the tile body
+  constexpr int BNU = BODY ? c3_body(BODY).nu : 1;         // units of one repetition
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
@@ -284,7 +378,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   auto dma_s = [&](const unsigned char* sbase, unsigned voff, int lds_off) {   // uniform base + 32-bit lane offset
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(sbase), "s"(lds0 + (unsigned)lds_off) : "memory");
+                 :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)lds_off)) : "memory");   // (uniform by construction; the intrinsic keeps it in an SGPR whatever the allocator made of the buffer cursor)
 #else
     __builtin_amdgcn_global_load_lds(sbase + voff, smem + lds_off, 16, 0, 0);
 #endif
@@ -292,7 +386,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   auto dma_v = [&](const void* vptr, int lds_off) {                            // per-lane 64-bit address
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(vptr), "s"(lds0 + (unsigned)lds_off) : "memory");
+                 :: "v"(vptr), "s"(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)lds_off)) : "memory");
 #else
     __builtin_amdgcn_global_load_lds(vptr, smem + lds_off, 16, 0, 0);
 #endif
@@ -344,12 +438,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   bool hnew = true;                                       // the fetch cursor moved to a new tile: geometry not yet derived
   auto halo_begin = [&]() {                               // per fetch UNIT: the chunk's slice of the tile; advance the cursor
     if (hnew) { halo_tile(); hnew = false; }              // (the pieces of this unit are issued AFTER this call and use the geometry)
-    hbase = htile + hc * 64;
-    hsok = hc * 4 + hs < a.nslots;
-    hcur = hc;
+    // BODY 1: unit hc of the tile -> 32-channel chunk of the view pixel ([odd | even | even | odd] per 128-byte line, see c3_body)
+    const int hcm = c3b_chunk(BODY, hc, a.nchunk);
+    hbase = htile + hcm * 64;
+    hsok = hcm * 4 + hs < a.nslots;
+    hcur = hcm;
     if constexpr (WD) {
-      hpxb = a.x_cs * 2; hns = a.nslots - 4 * hc;
-      if (a.x2 && hc >= a.nchunk1) { hbase = htile2 + (hc - a.nchunk1) * 64; hpxb = a.x2_cs * 2; hns = a.nslots2 - 4 * (hc - a.nchunk1); }
+      hpxb = a.x_cs * 2; hns = a.nslots - 4 * hcm;
+      if (a.x2 && hcm >= a.nchunk1) { hbase = htile2 + (hcm - a.nchunk1) * 64; hpxb = a.x2_cs * 2; hns = a.nslots2 - 4 * (hcm - a.nchunk1); }
     }
     // past the end of the list re-fetch the last unit (keeps the DMA count per step constant)
     if (hc + 1 < a.nchunk) ++hc;
@@ -389,7 +485,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     dma_v(ok ? (const void*)src : (const void*)a.zero16, buf + q * 1024);   // (buf = byte offset of the halo buffer)
   };
   int fslot = 0, fslab = 0;                               // ring slot / slab-within-tile of the NEXT slab to fetch
-  const int nslab_tile = a.nchunk * NS;
+  const int nslab_tile = BODY ? (a.nchunk / BNU) * BG : a.nchunk * NS;
   // GRP: the slab stream runs R steps ahead of the MFMAs, so it has its own tile cursor -- the weight image is the one of the
   // problem that tile belongs to (past the end of the list the dummy fetches read whichever image the cursor has reached)
   // (n0 = how many of this workgroup's tiles wg, wg + G, ... belong to problem 0, i.e. lie below tiles_img * B: one division per
@@ -500,11 +596,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   }
   C3_SYNC(0, 0)
   C3_TRACE()
+  // tap of the very first k-step (compile-time constants: a run-time evaluation of the body tables would put them on the stack)
+  constexpr C3KStep K00 = BODY ? uk_kstep(c3_body(BODY ? BODY : 3).kind[0], 0, 0) : C3KStep{c3_tap(TS, 0) / 3, c3_tap(TS, 0) % 3, 0};
+  constexpr int K00DW = K00.dw, K00DH = K00.dh;
   int rslot = 0;        // ring slot of the slab being consumed
   int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
 #pragma unroll
   for (int k = 0; k < NR; ++k)   // fragments of (unit 0, first tap, ks 0)
-    C3_RD(0, k, C3_AO(c3_tap(TS, 0) % 3) + abuf + (c3_tap(TS, 0) / 3) * C3_ROWB, boff + rslot * SLAB, 0)
+    C3_RD(0, k, C3_AO(K00DW) + abuf + K00DH * C3_ROWB, boff + rslot * SLAB, 0)
 
   // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
   //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
@@ -548,6 +647,52 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     rslot = rnext_;                                                                                                  \
   }
 
+  // Global step g of a heterogeneous body: the same software pipeline as C3_STEP, with the tap / slot of each k-step, the halo
+  // pieces and the counted wait taken from the body's tables, and the halo buffer switched after a unit's last step.
+#define C3_GSTEP(G_, MM0)                                                                                            \
+  if constexpr (BODY != 0 && (G_) < BG) {                                                                            \
+    constexpr int U_ = c3b_unit(BODY, (G_)), S_ = c3b_ord(BODY, (G_)), K_ = c3_body(BODY).kind[U_], NSU_ = uk_nsteps(K_); \
+    constexpr int GN_ = ((G_) + 1) % BG, KN_ = c3_body(BODY).kind[c3b_unit(BODY, GN_)];                              \
+    constexpr C3KStep k1_ = uk_kstep(K_, S_, 1), kn_ = uk_kstep(KN_, c3b_ord(BODY, GN_), 0);                         \
+    constexpr bool lastS_ = S_ == NSU_ - 1;                                                                          \
+    constexpr int NH_ = c3b_pieces(BODY, (G_)), NP_ = IPW + NH_, HF_ = c3b_first(BODY, (G_)), YG_ = c3b_younger(BODY, R, IPW, (G_)); \
+    const int acur_ = (aoff[k1_.dw] + abuf + k1_.dh * C3_ROWB) ^ (k1_.slot << 5);                                    \
+    const int bcur_ = boff + rslot * SLAB;                                                                           \
+    const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
+    const int anext_ = (aoff[kn_.dw] + (lastS_ ? hnext(abuf) : abuf) + kn_.dh * C3_ROWB) ^ (kn_.slot << 5);          \
+    const int bnext_ = boff + rnext_ * SLAB;                                                                         \
+    const int hbuf_ = hprev(abuf);                                                                                   \
+    C3_FENCE();                                                                                                      \
+    _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                                 \
+      MM0(0, n)                                                                                                      \
+      if (n < NR) C3_RDX(1, n, acur_, bcur_, 1)                                                                      \
+    }                                                                                                                \
+    _Pragma("unroll") for (int n = 0; n < NM / 2; ++n) {                                                             \
+      C3_MM(1, n)                                                                                                    \
+      if (n < NR) C3_RDX(0, n, anext_, bnext_, 0)                                                                    \
+    }                                                                                                                \
+    if (NR > NM / 2) { _Pragma("unroll") for (int n = NM / 2; n < NR; ++n) C3_RDX(0, n, anext_, bnext_, 0) }         \
+    C3_SYNC(YG_, NR)                                                                                                 \
+    if (S_ == 0) halo_begin();                                                                                       \
+    _Pragma("unroll") for (int n = NM / 2; n < NM; ++n) {                                                            \
+      C3_MM(1, n)                                                                                                    \
+      _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                                \
+        if (p * (NM / 2) / NP_ == n - NM / 2) {                                                                      \
+          if (p < IPW) slab_piece(p); else halo_piece(hbuf_, HF_ + p - IPW);                                         \
+          C3_FENCE();                                                                                                \
+        }                                                                                                            \
+    }                                                                                                                \
+    slab_advance();                                                                                                  \
+    rslot = rnext_;                                                                                                  \
+    if (lastS_) abuf = hnext(abuf);                                                                                  \
+  }
+  // (fragment read with an address that already carries the k-step's slot bit: C3_RD adds nothing for the pixel operand)
+#define C3_RDX(BUF, K, AADDR, BADDR, KS) C3_RD(BUF, K, AADDR, BADDR, KS)
+#define C3_GBODY_FROM1(MM) C3_GSTEP(1, MM) C3_GSTEP(2, MM) C3_GSTEP(3, MM) C3_GSTEP(4, MM) C3_GSTEP(5, MM) C3_GSTEP(6, MM) C3_GSTEP(7, MM) \
+  C3_GSTEP(8, MM) C3_GSTEP(9, MM) C3_GSTEP(10, MM) C3_GSTEP(11, MM) C3_GSTEP(12, MM) C3_GSTEP(13, MM) C3_GSTEP(14, MM) C3_GSTEP(15, MM)      \
+  C3_GSTEP(16, MM) C3_GSTEP(17, MM) C3_GSTEP(18, MM) C3_GSTEP(19, MM) C3_GSTEP(20, MM) C3_GSTEP(21, MM) C3_GSTEP(22, MM)
+  static_assert(BG <= 23, "C3_GBODY_FROM1 unrolls 23 steps");
+
   for (int k = 0; k < ntl; ++k) {
     if constexpr (PH) lastc = a.nchunk == 1;
     {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
@@ -569,20 +714,29 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
         }
         C3_FENCE();
+        if constexpr (BODY != 0) { C3_GSTEP(0, C3_MM) } else {
         C3_STEP(0)
+        }
       } else {
         C3_STEP_(0, C3_MMZ)
       }
+      if constexpr (BODY != 0) { C3_GBODY_FROM1(C3_MM) } else {
       C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
       abuf = hnext(abuf);
+      }
     }
+    if constexpr (BODY != 0) {
+#pragma unroll 1
+      for (int c = BNU; c < a.nchunk; c += BNU) { C3_GSTEP(0, C3_MM) C3_GBODY_FROM1(C3_MM) }
+    } else {
 #pragma unroll 1
     for (int c = 1; c < a.nchunk; ++c) {
       if constexpr (PH) lastc = c == a.nchunk - 1;
       C3_STEP(0) C3_STEP(1) C3_STEP(2) C3_STEP(3) C3_STEP(4) C3_STEP(5)
       if constexpr (NS == 9) { C3_STEP(6) C3_STEP(7) C3_STEP(8) }
       abuf = hnext(abuf);
+    }
     }
     if (k == 0) C3_TRACE()
 
@@ -814,6 +968,9 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
   C3_TRACE()
   if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - clk0;   // shader-clock ticks of the whole life
+#undef C3_GBODY_FROM1
+#undef C3_RDX
+#undef C3_GSTEP
 #undef C3_AO
 #undef C3_STEP
 #undef C3_STEP_
@@ -836,9 +993,9 @@ inline int conv_num_cus() {
 }
 
 // One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
-template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false>
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false, int BODY = 0>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
-  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP>;
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP, BODY>;
   static const bool once = (allow_big_lds(k), true);
   (void)once;
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
@@ -894,21 +1051,21 @@ template <int DT>
 inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                            const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
                            int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1,
-                           const Conv3Phases* ph, const Conv3Src2* s2);
+                           const Conv3Phases* ph, const Conv3Src2* s2, int body);
 inline int launch_conv3(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                         const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
                         int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, int dt,
-                        const Conv3Second* g1, const Conv3Phases* ph, const Conv3Src2* s2) {
+                        const Conv3Second* g1, const Conv3Phases* ph, const Conv3Src2* s2, int body) {
   RD_REQUIRE(is_h16(dt), RD_EINVAL, "conv3: dtype %d (the persistent 3x3 kernel takes RD_BF16 or RD_F16)", dt);
-  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2);
-  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2);
+  if (dt == RD_F16) return launch_conv3_dt<RD_F16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2, body);
+  return launch_conv3_dt<RD_BF16>(x, x_cs, x_co, w, scale, shift, res, r_cs, r_co, y, y_cs, y_co, B, H, W, cin, cout, flags, sw, st, ts, head, g1, ph, s2, body);
 }
 
 template <int DT>
 inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, const float* scale, const float* shift,
                            const void* res, int r_cs, int r_co, void* y, int y_cs, int y_co, int B, int H, int W, int cin,
                            int cout, int flags, int sw, hipStream_t st, int ts, const Conv3Args* head, const Conv3Second* g1,
-                           const Conv3Phases* ph, const Conv3Src2* s2) {
+                           const Conv3Phases* ph, const Conv3Src2* s2, int body) {
   Conv3Args a;
   memset(&a, 0, sizeof(a));
   a.ngrp = g1 ? 2 : 1;
@@ -1022,6 +1179,20 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
                    : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);              \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
+  if (body) {   // heterogeneous tile body (c3_body): the packer made the matching weight image
+    RD_REQUIRE(wd && fold && !headfuse && !g1 && !ph && sw == 1 && a.nchunk % c3_body(body).nu == 0, RD_ESHAPE,
+               "conv3: tile body %d needs the 8 x 32 tile form with folded scales (%d chunks)", body, a.nchunk);
+    if (body == 1) {
+      RD_REQUIRE(ts == 1 && !s2, RD_ESHAPE, "conv3: body 1 is the stride-2 pair view");
+      if (sc) { if (cout == 128) return c3_go<4, 1, false, true, true, 2, 1, 2, DT, true, false, 1>(grid, st, a); return c3_go<2, 1, false, true, true, 2, 1, 2, DT, true, false, 1>(grid, st, a); }
+      if (cout == 128) return c3_go<4, 1, false, false, true, 2, 1, 2, DT, true, false, 1>(grid, st, a);
+      return c3_go<2, 1, false, false, true, 2, 1, 2, DT, true, false, 1>(grid, st, a);
+    }
+    RD_REQUIRE(ts == 0 && !sc, RD_ESHAPE, "conv3: tile body %d takes all nine taps, no shortcut", body);
+    if (body == 2) { if (cout == 128) return c3_go<4, 0, false, false, true, 2, 1, 2, DT, true, false, 2>(grid, st, a); return c3_go<2, 0, false, false, true, 2, 1, 2, DT, true, false, 2>(grid, st, a); }
+    if (cout == 128) return c3_go<4, 0, false, false, true, 2, 1, 2, DT, true, false, 3>(grid, st, a);
+    return c3_go<2, 0, false, false, true, 2, 1, 2, DT, true, false, 3>(grid, st, a);
+  }
   if (ph) {
     RD_REQUIRE(wd && fold && !sc && !head && !g1 && ts == 3 && sw == 1 && ph->nph >= 1 && ph->nph <= 8, RD_ESHAPE,
                "conv3: all phases per launch need the 8 x 32 tile form (folded scales, no shortcut / output conv)");

@@ -241,15 +241,22 @@ int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, i
     return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)co * cin + ci) * 3 + (dh + 1)) * 3 + (dw + 1)];
   };
   memset(out, 0, rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride));
+  // pair view (stride 2): channel c2 < cin is the even pixel (only dw2 = 0 meets it), c2 >= x_cstride the odd one (dw = -1 / +1)
+  auto wv2 = [&](int co, int c2, int dh, int dw2) -> float {
+    if (c2 < cin) return dw2 == 0 ? wv(co, c2, dh, 0) : 0.f;
+    if (c2 >= x_cstride && c2 - x_cstride < cin) return wv(co, c2 - x_cstride, dh, dw2 == -1 ? -1 : 1);
+    return 0.f;
+  };
   if (stride_w == 1) {
-    pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); }, dtype);
+    if (conv3_body_small(cin, fold_scale != nullptr))   // <= 16 input channels: five two-tap steps instead of nine (k_conv3.h c3_body 3)
+      pack_body_frag(3, cin, cout, out, [&](int co, int ci, int dh, int dw) { return wv(co, ci, dh - 1, dw - 1); }, dtype);
+    else
+      pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); }, dtype);
+  } else if (conv3_body_s2(cin, x_cstride, fold_scale != nullptr)) {
+    // the even pixel's chunks as 3-tap units (no MFMAs on their structurally-zero dw2 = -1 weights): k_conv3.h c3_body 1
+    pack_body_frag(1, x_cstride + cin, cout, out, [&](int co, int c2, int dh, int dw) { return wv2(co, c2, dh - 1, dw - 1); }, dtype);
   } else {
-    pack_taps_frag(6, x_cstride + cin, cout, out, [&](int co, int c2, int s) -> float {
-      const int dh = s / 2 - 1, dw2 = s % 2 - 1;
-      if (c2 < cin) return dw2 == 0 ? wv(co, c2, dh, 0) : 0.f;                               // even pixel
-      if (c2 >= x_cstride && c2 - x_cstride < cin) return wv(co, c2 - x_cstride, dh, dw2 == -1 ? -1 : 1);   // odd pixel
-      return 0.f;
-    }, dtype);
+    pack_taps_frag(6, x_cstride + cin, cout, out, [&](int co, int c2, int s) -> float { return wv2(co, c2, s / 2 - 1, s % 2 - 1); }, dtype);
   }
   return RD_OK;
 }
@@ -290,14 +297,33 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
     fl |= RD_SCALE_FOLDED;                     // (both scales are in the two weight sets)
   }
   RD_REQUIRE(!(fl & RD_SCALE_FOLDED) || !scale, RD_EINVAL, "conv3x3_ex: folded weights take no scale array");
+  const bool folded = (fl & RD_SCALE_FOLDED) != 0;
+  const int body = stride_w == 2 ? conv3_body_s2(cin, x_cstride, folded) : (sc_x ? 0 : conv3_body_small(cin, folded));
+  RD_REQUIRE(!(stride_w == 1 && sc_x && conv3_body_small(cin, folded)), RD_ESHAPE, "conv3x3_ex: at most 16 input channels together with a fused shortcut is not a launch form");
   return launch_conv3(x, x_cstride * v, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride, y_coff, B, H,
                       Wv, ex_view_cin(cin, x_cstride, stride_w), cout, fl, 1, (hipStream_t)stream, stride_w == 2 ? 1 : 0,
-                      sc_x ? &e : nullptr, dtype);
+                      sc_x ? &e : nullptr, dtype, nullptr, nullptr, nullptr, body);
 }
 
 // ---- 3x3 conv over the channel concatenation [x1 | x2] of two tensors that is never materialised (16-bit, folded scales) -----------
 // dla_backbone.py:153-154 (concat of the range image with the agg3 feature map) feeding head/builder.py:221-240: w_packed is
-// rd_pack_conv3x3_ex_host of the weight whose input channels are laid out [cin1 channels of x1 | cin2 channels of x2] (stride 1).
+// rd_pack_conv3x3_cat_host of the weight whose input channels are laid out [cin1 channels of x1 | cin2 channels of x2].
+size_t rd_conv3x3_cat_packed_bytes(int cin1, int cin2, int cout) { return conv_packed_bytes(9, cin1 + cin2, cout, RD_BF16); }
+int rd_pack_conv3x3_cat_host(const float* w, const float* fold_scale, int cout, int cin1, int cin2, int dtype, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv3x3_cat: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_conv3x3_cat: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE((cout == 64 || cout == 128) && cin1 > 0 && cin1 % 32 == 0 && cin2 > 0 && cin2 % 8 == 0, RD_ESHAPE,
+             "pack_conv3x3_cat: cout %d, cin1 %d (multiple of 32), cin2 %d (multiple of 8)", cout, cin1, cin2);
+  const int cin = cin1 + cin2;
+  auto wv = [&](int co, int ci, int dh, int dw) {
+    return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)co * cin + ci) * 3 + (dh + 1)) * 3 + (dw + 1)];
+  };
+  memset(out, 0, rd_conv3x3_cat_packed_bytes(cin1, cin2, cout));
+  const int body = conv3_body_cat(cin1, cin2, fold_scale != nullptr);
+  if (body) pack_body_frag(body, cin, cout, out, [&](int co, int ci, int dh, int dw) { return wv(co, ci, dh - 1, dw - 1); }, dtype);
+  else pack_taps_frag(9, cin, cout, out, [&](int co, int ci, int t) { return wv(co, ci, t / 3 - 1, t % 3 - 1); }, dtype);
+  return RD_OK;
+}
 int rd_conv3x3_bn_act_cat(const void* x1, int x1_cstride, int x1_coff, int cin1, const void* x2, int x2_cstride, int x2_coff, int cin2,
                           const void* w_packed, const float* shift, void* y, int y_cstride, int y_coff, int B, int H, int W, int cout,
                           int flags, int dtype, void* stream) {
@@ -316,7 +342,7 @@ int rd_conv3x3_bn_act_cat(const void* x1, int x1_cstride, int x1_coff, int cin1,
   Conv3Src2 s2;
   s2.x = x2; s2.cs = x2_cstride; s2.co = x2_coff; s2.cin1 = cin1; s2.cin2 = cin2;
   return launch_conv3(x1, x1_cstride, x1_coff, w_packed, nullptr, shift, nullptr, 0, 0, y, y_cstride, y_coff, B, H, W, cin1 + cin2, cout, flags,
-                      1, (hipStream_t)stream, 0, nullptr, dtype, nullptr, nullptr, &s2);
+                      1, (hipStream_t)stream, 0, nullptr, dtype, nullptr, nullptr, &s2, conv3_body_cat(cin1, cin2, true));
 }
 
 // ---- last tower conv + the tower's 1x1 output conv in one launch (bf16) ---------------------------------------------
@@ -339,6 +365,7 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
   RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE,
              "conv2d_head_out: x channel stride/offset");
   RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "conv2d_head_out: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
+  RD_REQUIRE(!conv3_body_small(cin, (flags & RD_SCALE_FOLDED) != 0), RD_ESHAPE, "conv2d_head_out: cin %d (the packed image of a conv with <= 16 input channels is not this launch form's)", cin);
   allow_conv_lds();
   Conv3Args h;
   memset(&h, 0, sizeof(h));
@@ -358,6 +385,7 @@ static int pair_checks(const char* fn, const void* x0, const void* x1, const voi
   RD_REQUIRE(x_cstride % 8 == 0 && x0_coff % 8 == 0 && x1_coff % 8 == 0 && x0_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride &&
              x1_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "%s: x channel stride/offset", fn);
   RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "%s: needs the persistent 3x3 kernel (RD_CONV_V1 is set)", fn);
+  RD_REQUIRE(cin > 16, RD_ESHAPE, "%s: cin %d (more than 16 input channels)", fn, cin);
   return RD_OK;
 }
 int rd_conv3x3_bn_act_pair(const void* x0, int x0_coff, const void* w0_packed, const float* shift0, void* y0, int y0_coff,

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rd_deconv2d_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p]),
+    "rd_conv3x3_cat_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rd_pack_conv3x3_cat_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_bn_act_cat": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_deconv2d_all_phases_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -171,6 +173,16 @@ class Lib:
         out = np.zeros(self.cdll.rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride), dtype=np.uint8)
         self.call("rd_pack_conv3x3_ex_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, stride_w,
                   x_cstride, dtype, out.ctypes.data)
+        return out
+
+    def pack_conv3x3_cat(self, w_oihw, cin1, cin2, fold_scale=None, dtype=RD_BF16):
+        """weights of rd_conv3x3_bn_act_cat: input channels [cin1 of x1 | cin2 of x2]"""
+        w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+        cout = w.shape[0]
+        assert w.shape[1:] == (cin1 + cin2, 3, 3)
+        fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_conv3x3_cat_packed_bytes(cin1, cin2, cout), dtype=np.uint8)
+        self.call("rd_pack_conv3x3_cat_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin1, cin2, dtype, out.ctypes.data)
         return out
 
     def pack_conv1x1_sc(self, w_oi, fold_scale=None, dtype=RD_BF16):

@@ -167,6 +167,10 @@ class Executor:
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
                 b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload((t.astype(np.float64) + ts).astype(np.float32))
+            elif st.get("x2") is not None:          # conv over the virtual concat [x | x2] (lower._concat)
+                b["w"] = A.upload(L.pack_conv3x3_cat(w, st["x"].C, st["x2"].cs, fold_scale=s, dtype=dt))
+                b["scale"], b["shift"] = None, A.upload(t)
+                b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
             elif st.get("ex") and st.get("fold"):   # scale folded into the weights, the shift enters through the accumulators
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload(t)

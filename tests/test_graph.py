@@ -709,9 +709,12 @@ def test_e2e_bf16_tolerance(be, dt, monkeypatch):
     assert np.array_equal(outs[2][0][0], logit[0])            # (and frame 0 of the batch equals the single-frame run)
     # the never-materialised concat against the shared buffer: the same numbers in another channel order ([agg3 | range image]
     # instead of [range image | agg3]), i.e. another fp32 summation order in the level-0 tower convs -- a 128-channel activation
-    # that sits on a rounding boundary may round the other way (one 16-bit unit of it times its output-conv weight); the reduced
-    # graph's level 0 also applies its 1x1 output convs in a separate launch
-    assert np.abs(outs[2][0] - outs[0][0]).max() < 2e-3 and np.abs(outs[2][1] - outs[0][1]).max() < 2e-3
+    # that sits on a rounding boundary may round the other way, and in the full graph that unit travels through three more tower
+    # convs: differences of the size of the 16-bit error model itself (`model` above), nothing systematic; the reduced graph's
+    # level 0 also applies its 1x1 output convs in a separate launch
+    for i_ in (0, 1):
+        d_ = np.abs(outs[2][i_] - outs[0][i_])
+        assert d_.max() < 6 * model * outs[0][i_].std() and d_.mean() < 0.1 * model * outs[0][i_].std(), (d_.max(), d_.mean())
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

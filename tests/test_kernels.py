@@ -633,7 +633,7 @@ def test_conv3x3_cat_two_tensor_input(be, case):
     L = be.lib
     fl = R.RD_RELU_POST | R.RD_SCALE_FOLDED
     d1, d2 = be.up(to_nhwc(x1, dt)), be.up(to_nhwc(x2, dt, cstride=cs2))
-    wp, dsh = be.up(L.pack_conv3x3_ex(w, 1, c1 + cin2, fold_scale=sc, dtype=dt)), be.up(sh)
+    wp, dsh = be.up(L.pack_conv3x3_cat(w, c1, cin2, fold_scale=sc, dtype=dt)), be.up(sh)
     y = be.empty(B * H * W * cout * 2)
     L.call("rd_conv3x3_bn_act_cat", be.ptr(d1), c1, 0, c1, be.ptr(d2), cs2, 0, cin2, be.ptr(wp), be.ptr(dsh), be.ptr(y), cout, 0, B, H, W, cout,
            fl, dt, be.stream)
@@ -642,11 +642,18 @@ def test_conv3x3_cat_two_tensor_input(be, case):
     ref = F.conv2d(torch.from_numpy(xc), torch.from_numpy(w), padding=1).numpy() * sc[None, :, None, None] + sh[None, :, None, None]
     ref = np.maximum(ref, 0)
     assert np.abs(from_nhwc(got, dt, cout) - ref).max() <= 1.5 * _tol(dt, ref)
+    # against the single-tensor launch on a shared buffer that holds the same channels: the same numbers (with cin1 = 64, cin2 <= 16
+    # the two-tensor launch sums the x2 chunk in another order -- five two-tap steps -- so equal to one output rounding, else bit-equal)
     cs = -(-(c1 + cin2) // 16) * 16
     y2 = be.empty(B * H * W * cout * 2)
-    L.call("rd_conv3x3_bn_act_ex", be.ptr(be.up(to_nhwc(xc, dt, cstride=cs))), cs, 0, be.ptr(wp), None, be.ptr(dsh), None, 0, 0, None, 0, 0, 0, None,
+    wp1 = be.up(L.pack_conv3x3_ex(w, 1, cs, fold_scale=sc, dtype=dt))
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(be.up(to_nhwc(xc, dt, cstride=cs))), cs, 0, be.ptr(wp1), None, be.ptr(dsh), None, 0, 0, None, 0, 0, 0, None,
            be.ptr(y2), cout, 0, B, H, W, c1 + cin2, cout, 1, fl, dt, be.stream)
-    assert np.array_equal(got, be.down(y2, np.uint16, (B, H, W, cout)))
+    got2 = be.down(y2, np.uint16, (B, H, W, cout))
+    if c1 == 64 and cin2 <= 16:
+        assert np.abs(from_nhwc(got, dt, cout) - from_nhwc(got2, dt, cout)).max() <= 2 * _ulp(dt) * max(1.0, float(np.abs(ref).max()))
+    else:
+        assert np.array_equal(got, got2)
     buf = be.ptr(be.empty(1 << 16))
     f = L.raw("rd_conv3x3_bn_act_cat")
     assert f(buf, 64, 0, 48, buf, 16, 0, 16, buf, buf, buf, 128, 0, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_ESHAPE        # cin1 not a multiple of 32
