@@ -200,17 +200,47 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from rangedet_amd import dist as rdist
     rdist.init_process_group("gloo")
+    cpus = rdist.bind_cpus(rank, world)
     shard = rdist.FrameSharding(rank, world)
     mine = torch.tensor([rank] + shard.frames_of_step(0, args.batch), dtype=torch.int64)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
+    # the SHIPPING gather (rangedet_amd.dist.DetectionGather: pack + one all_gather + unpack) on host buffers: every rank fills a
+    # post-processor-shaped result whose rows encode (rank, frame, row), all ranks must find every frame of the step intact
+    B_, cap = args.batch, 256
+
+    class _Post:      # the fields of pipeline.BatchPostProcessor the gather reads
+        pass
+    post = _Post()
+    post.B, post.cap = B_, cap
+    rows = np.zeros((B_, cap, 12), np.float32)
+    nk = np.zeros(B_, np.int32)
+    for j, f in enumerate(shard.frames_of_step(3, B_)):
+        nk[j] = 1 + (f * 7) % rdist.MAX_DET
+        rows[j, :nk[j]] = (1000.0 * f + np.arange(nk[j], dtype=np.float32))[:, None] + 0.01 * np.arange(12, dtype=np.float32)[None, :]
+    post.out, post.nkeep = rows.view(np.uint8).reshape(-1), nk.view(np.uint8)
+    g = rdist.DetectionGather(post, shard, rdist.HostAlloc, rdist.HostCopyLib)
+    g.enqueue()
+    got = g.unpack(step=3)
+    ok = sorted(got) == sorted(f for r in range(world) for f in shard.frames_of_step(3, B_, rank=r))
+    for f, (rw, M) in got.items():
+        m = 1 + (f * 7) % rdist.MAX_DET
+        want = (1000.0 * f + np.arange(m, dtype=np.float32))[:, None] + 0.01 * np.arange(12, dtype=np.float32)[None, :]
+        ok = ok and M == m and np.array_equal(rw, want)
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    ident = torch.tensor(list(bytes([rank]) * 16), dtype=torch.uint8)      # (dry run: one fictitious device per rank)
+    ids = [torch.zeros_like(ident) for _ in range(world)]
+    dist.all_gather(ids, ident)
+    rdist.check_ranks([int(a[0]) for a in allr], [bytes(i.tolist()) for i in ids], world)
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": [int(a[0]) for a in allr],
-                          "frames_step0": sorted(int(f) for a in allr for f in a[1:]), "max_over_ranks": float(t.item())}), flush=True)
+                          "frames_step0": sorted(int(f) for a in allr for f in a[1:]), "max_over_ranks": float(t.item()),
+                          "gather_ok": bool(okt.item()), "gathered_frames": len(got), "cpus_rank0": len(cpus) if cpus else None}), flush=True)
 
 
 def main(argv=None):
@@ -251,17 +281,22 @@ def main(argv=None):
     from rangedet_amd.pipeline import InterleavedPipelines
 
     gather = world > 1 or bool(os.environ.get("RD_BENCH_GATHER"))   # the env switch exercises the collective path on one GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = rdist.bind_cpus(local, local_world)                      # per-rank CPU slice (reference: utils/cpu_affinity.py)
+    dev = rdist.select_device(local, local_world)                   # HIP_VISIBLE_DEVICES-safe; raises instead of sharing a GPU
     if gather:
         rdist.init_process_group("nccl", dev)
     ranks_seen, rccl_version = [rank], None
     if gather:
-        # every rank reports in through the communicator the data path uses (RCCL): proves N distinct ranks on N devices
-        me = torch.tensor([rank, local], device=dev, dtype=torch.int32)
-        seen = torch.zeros((world, 2), device=dev, dtype=torch.int32)
+        # every rank reports in through the communicator the data path uses (RCCL) with its rank and the identity of its GPU:
+        # N distinct ranks on N distinct devices, or the run stops here
+        ident = np.frombuffer(rdist.device_identity(dev), dtype=np.int32)
+        me = torch.tensor([rank, local] + [int(v) for v in ident], device=dev, dtype=torch.int32)
+        seen = torch.zeros((world, 6), device=dev, dtype=torch.int32)
         dist.all_gather_into_tensor(seen.view(-1), me)
-        ranks_seen = [int(r) for r in seen[:, 0].cpu()]
+        seen = seen.cpu().numpy()
+        ranks_seen = [int(r) for r in seen[:, 0]]
+        rdist.check_ranks(ranks_seen, [seen[r, 2:].tobytes() for r in range(world)] if world > 1 else [b"0"], world)
         try:
             rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:      # noqa: BLE001  (reporting only)
@@ -295,7 +330,8 @@ def main(argv=None):
         frames = [synth.make_batch(shard.frames_of_step(i, Bf), lib=pipe.lib, alloc=pipe.alloc) for i in range(args.frames)]
     L = pipe.lib
     A = pipe.alloc
-    gathers = [rdist.DetectionGather(p.bpost, shard, A, L) for p in multi.pipes] if gather else None
+    # one gather per pipeline and class (the two-class KITTI variant has two post-processors per pipeline)
+    gathers = [[rdist.DetectionGather(p.bposts[c], shard, A, L) for c in p.class_names] for p in multi.pipes] if gather else None
     # every step's results go to the host like the reference's loop materialises every frame (tools/test.py:151-153):
     # per pipeline, pinned host buffers for the (B, 200, 8) boxes, the keep counts and the candidate counts, filled by async
     # copies on the batch's post-processing stream
@@ -343,7 +379,8 @@ def main(argv=None):
             if gather:
                 # the ONE collective of the path, enqueued behind this batch's post-processing on its side stream: the next
                 # batch's forward overlaps it, nothing on a launch stream waits for it
-                gathers[j].enqueue(pj._post_stream)
+                for g_ in gathers[j]:
+                    g_.enqueue(pj._post_stream)
             h["done"] = torch.cuda.Event()
             h["done"].record(pj._post_stream)
             h["step"] = i
@@ -373,7 +410,7 @@ def main(argv=None):
         elapsed = float(t.item())
     last = (args.warmup + args.steps - 1) % len(multi.pipes)
     res = multi.pipes[last].collect()[0]
-    gathered_frames = len(gathers[last].unpack((args.warmup + args.steps - 1))) if gather else None
+    gathered_frames = len(gathers[last][0].unpack((args.warmup + args.steps - 1))) if gather else None
 
     # ---- per-kernel timing with HIP events on the launch stream, over a replay of the same steps ------------------
     roof = meta_info = prof = backbone_info = None
@@ -487,6 +524,7 @@ def main(argv=None):
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
+                       "cpus_per_rank": len(cpus) if cpus else None,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("self (mp.spawn)" if world > 1 else "single process")},
             "roofline": roof, "meta_kernel": meta_info, "meta_dla_forward": backbone_info,

@@ -22,7 +22,7 @@ def build(with_ref=True):
     """(Re)build liboracle.so and, when /root/reference is present, oracle/_ref (the reference's own wnms)."""
     targets = ["all"]
     if with_ref and os.path.exists("/root/reference/operator_cxx/src_cxx/nms.h"):
-        targets.append("ref")
+        targets += ["ref", "study"]      # (study: the bulk characterisation tool of tools/nms_spurious_study.py)
     subprocess.check_call(["make", "-s", "-C", _HERE] + targets)
 
 

@@ -387,20 +387,14 @@ inline void pack_taps(int ntaps, int cin, int cout, int dt, void* out, F get) {
         }
 }
 
-// dev tracing: RD_CONV_TRACE=1 allocates a device buffer the kernels stamp with s_memrealtime (100 MHz) per phase
+// dev tracing (tools/conv_trace.py): the CALLER registers a device buffer of CONV_TRACE_CAP 64-bit words (rd_dev_conv_trace_set) that
+// the conv kernels stamp with s_memrealtime (100 MHz) per phase; nullptr = off.  The library itself never allocates device memory.
 constexpr size_t CONV_TRACE_CAP = 1 << 20;
-inline unsigned long long* conv_trace_buf() {
-#ifdef HIPEMU
-  return nullptr;
-#else
-  static unsigned long long* buf = [] {
-    unsigned long long* p = nullptr;
-    if (getenv("RD_CONV_TRACE") && hipMalloc((void**)&p, CONV_TRACE_CAP * 8) == hipSuccess) (void)hipMemset(p, 0, CONV_TRACE_CAP * 8);
-    return p;
-  }();
+inline unsigned long long*& conv_trace_slot() {
+  static unsigned long long* buf = nullptr;
   return buf;
-#endif
 }
+inline unsigned long long* conv_trace_buf() { return conv_trace_slot(); }
 
 // k_conv1.h: streaming 1x1 bf16 kernel
 inline bool conv1_eligible(const TapList& tl, int in_stride, int out_stride, int cin, int cout, int dt, int Win, int Wq, int Wout);

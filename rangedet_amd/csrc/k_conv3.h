@@ -982,9 +982,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #undef C3_TRACE
 }
 
+// Build options (none is set by rangedet_amd.build; tests/emu/build_emu.sh passes both to keep the CPU emulation of the persistent
+// kernels small and its compile time in minutes):
+//   -DRD_BUILD_NUM_CUS=n                     workgroup slots are sized for n compute units instead of asking the device
+//   -DRD_BUILD_F16_PRODUCTION_FORMS_ONLY     fp16: only the launch forms the lowering emits (folded scales on the two-workgroup
+//                                            tiles, fused output conv); other fp16 shapes take the generic tap kernel
 inline int conv_num_cus() {
-#ifdef HIPEMU
-  return 4;
+#ifdef RD_BUILD_NUM_CUS
+  return RD_BUILD_NUM_CUS;
 #else
   int dev = 0, v = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
@@ -996,24 +1001,20 @@ inline int conv_num_cus() {
 template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false, int BODY = 0>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
   auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP, BODY>;
-  static const bool once = (allow_big_lds(k), true);
-  (void)once;
+  static unsigned long long seen = 0;   // (benign race: two threads may both set the attribute)
+  if (first_use_on_device(seen)) allow_big_lds(k);
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
   return check_launch("conv3x3_stream_kernel");
 }
 
-// The CPU emulator build (tests/emu, test infrastructure) instantiates the fp16 persistent kernel for the PRODUCTION launch forms
-// only -- folded scales on the 8 x 30 tiles, fused output conv -- to keep its compile time in minutes; other fp16 forms run on the
-// generic tap kernel there.  The GPU library has every form in both 16-bit types.
-inline bool conv3_has_form(int dt, bool fold) {
-#ifdef HIPEMU
-  return dt == RD_BF16 || fold;
+// (RD_BUILD_F16_PRODUCTION_FORMS_ONLY, see above; the GPU library has every form in both 16-bit types)
+#ifdef RD_BUILD_F16_PRODUCTION_FORMS_ONLY
+constexpr bool kF16AllForms = false;
 #else
-  (void)dt; (void)fold;
-  return true;
+constexpr bool kF16AllForms = true;
 #endif
-}
+inline bool conv3_has_form(int dt, bool fold) { return kF16AllForms || dt == RD_BF16 || fold; }
 
 inline bool conv3_eligible(const TapList& tl, int in_stride, int out_stride, int cout, int dt, int Win, int Wq, int Wout) {
   if (!is_h16(dt) || !conv3_has_form(dt, false) || tl.n != 9 || (in_stride != 1 && in_stride != 2) || out_stride != 1) return false;
@@ -1042,9 +1043,10 @@ inline bool conv3_phases_eligible(int cout, int flags) {
   return (cout == 64 || cout == 128) && (flags & RD_SCALE_FOLDED) && sw_.conv_w30 && sw_.conv_wide && !sw_.conv_v1 &&
          ((cout == 64 && sw_.conv_th4 != 3) || (cout == 128 && sw_.conv_th4 && sw_.conv_w30 == 2));
 }
-inline bool conv3_pair_eligible(int cout, int flags, int W) {
+inline bool conv3_pair_eligible(int cout, int flags, int W, bool headfuse = false) {
   const DevSwitches& sw_ = dev_switches();
-  return cout == 128 && (flags & RD_SCALE_FOLDED) && sw_.conv_th4 && sw_.conv_w30 == 2 && sw_.conv_wide && (sw_.conv_th4 != 2 || W >= 600);
+  return cout == 128 && (flags & RD_SCALE_FOLDED) && sw_.conv_th4 && sw_.conv_w30 == 2 && sw_.conv_wide && (sw_.conv_th4 != 2 || W >= 600) &&
+         (!headfuse || sw_.conv_head30 != 0);   // (RD_CONV_HEAD30=0: no fused output conv on the two-workgroup tiles -> two launches)
 }
 
 template <int DT>
@@ -1157,11 +1159,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   C3_DBG128(4) C3_DBG128(8) C3_DBG128(16) C3_DBG128(2) C3_DBG128(32) C3_DBG128(256) C3_DBG128(257)
 #undef C3_DBG128
 #endif
-#ifdef HIPEMU
-  constexpr bool kAllForms = DT == RD_BF16;
-#else
-  constexpr bool kAllForms = true;
-#endif
+  constexpr bool kAllForms = kF16AllForms || DT == RD_BF16;
   RD_REQUIRE(kAllForms || (fold && w30 && (cout == 128 || hb3 || sw_.conv_wide)) || (headfuse && fold), RD_ESHAPE,
              "conv3: this fp16 launch form is not instantiated in the emulator build (conv3_has_form)");
   if (sc) {

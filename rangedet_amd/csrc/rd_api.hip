@@ -44,10 +44,11 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   return w;
 }
 inline void allow_conv_lds() {   // the generic tap kernel (the persistent 3x3 kernel does this per instantiation, k_conv3.h c3_go)
-  static const bool once = (allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>), allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>),
-                            allow_big_lds(conv_taps_kernel<RD_F16, 4, 3>), allow_big_lds(conv_taps_kernel<RD_F16, 4, 8>),
-                            allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>), allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>), true);
-  (void)once;
+  static unsigned long long seen = 0;
+  if (!first_use_on_device(seen)) return;
+  allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
+  allow_big_lds(conv_taps_kernel<RD_F16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_F16, 4, 8>);
+  allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>); allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
 }
 }  // namespace rd
 
@@ -419,7 +420,7 @@ int rd_conv2d_bn_act_head_out_pair(const void* x0, int x0_coff, const void* w0_p
   Conv3Args h;
   memset(&h, 0, sizeof(h));
   h.hw = (const unsigned char*)head_w0_packed; h.hb = head_bias0; h.ho = out0; h.ho_bs = out0_batch_stride; h.ho_off = n_off; h.hn = nout0;
-  if (!conv3_pair_eligible(128, flags, W)) {
+  if (!conv3_pair_eligible(128, flags, W, true)) {
     if (int rc = launch_conv3(x0, x_cstride, x0_coff, w0_packed, nullptr, shift0, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
                               (hipStream_t)stream, 0, &h, dtype)) return rc;
     h.hw = (const unsigned char*)head_w1_packed; h.hb = head_bias1; h.ho = out1; h.ho_bs = out1_batch_stride; h.hn = nout1;
@@ -556,12 +557,11 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   ProfScope ps(RD_PROF_META, st);
   if (is_h16(dtype)) {
     const size_t lds = meta_layout(dtype).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
-    static const bool once = (allow_big_lds(meta16_kernel<WAVES, RD_BF16>), allow_big_lds(meta16_kernel<WAVES, RD_F16>), true);
-    (void)once;
-    if (dtype == RD_F16)
-      hipLaunchKernelGGL((meta16_kernel<WAVES, RD_F16>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
-    else
-      hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), dim3(std::min(a.ntiles, conv_num_cus())), dim3(WAVES * 64), lds, st, a);
+    static unsigned long long seen = 0;
+    if (first_use_on_device(seen)) { allow_big_lds(meta16_kernel<WAVES, RD_BF16>); allow_big_lds(meta16_kernel<WAVES, RD_F16>); }
+    const dim3 mgrid(std::min(a.ntiles, conv_num_cus())), mblock(WAVES * 64);
+    if (dtype == RD_F16) hipLaunchKernelGGL((meta16_kernel<WAVES, RD_F16>), mgrid, mblock, lds, st, a);
+    else hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), mgrid, mblock, lds, st, a);
   } else {
     const size_t lds = consts + (size_t)(WAVES + 2) * 34 * 256;
     allow_big_lds(meta_kernel<RD_F32, WAVES>);
@@ -907,7 +907,14 @@ int rd_input_transform(const float* range_image, const float* pc_vehicle_frame, 
 }
 
 // ---- profiling -------------------------------------------------------------------------------------------------
-// dev only (not part of include/rangedet_hip.h): copy the conv phase trace of the last traced launch to the host
+// dev only (not part of include/rangedet_hip.h): the phase trace of the conv kernels.  rd_dev_conv_trace_set registers a
+// caller-owned, zeroed device buffer of at least 2^20 64-bit words (nullptr: tracing off); rd_dev_conv_trace_read copies the first n
+// words of it to the host.
+int rd_dev_conv_trace_set(unsigned long long* device_buf, long nwords) {
+  if (device_buf && nwords < (long)CONV_TRACE_CAP) return RD_EINVAL;
+  conv_trace_slot() = device_buf;
+  return RD_OK;
+}
 int rd_dev_conv_trace_read(unsigned long long* out, long n) {
   if (!conv_trace_buf() || n > (long)CONV_TRACE_CAP) return RD_EINVAL;
   return hipMemcpy(out, conv_trace_buf(), n * 8, hipMemcpyDeviceToHost) == hipSuccess ? RD_OK : RD_EHIP;

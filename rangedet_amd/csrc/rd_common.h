@@ -85,6 +85,16 @@ inline void allow_big_lds(K kernel) {
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     (void)hipGetLastError();
 }
+// The attribute is a property of the function ON A DEVICE: "once" means once per (kernel, device), so that a process which
+// launches on a second GPU raises the limit there too (one process per GPU never sees more than one bit set).
+inline bool first_use_on_device(unsigned long long& seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
 
 // ---- per-kind event profiling ------------------------------------------------------------------------
 struct Prof {

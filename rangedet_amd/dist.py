@@ -65,6 +65,95 @@ def init_process_group(backend=None, device=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def bind_cpus(local_rank, local_world, max_threads=8):
+    """Per-rank CPU affinity, the counterpart of the reference's utils/cpu_affinity.py (bind_cpus_on_ecos :38-47, simple_bind_cpus
+    :7-15): the CPUs this process is ALLOWED to run on (cgroup / taskset aware) are cut into local_world contiguous slices and rank r
+    keeps slice r -- contiguous CPU numbers share a socket / NUMA node on the usual two-socket GPU hosts, so a rank's host threads
+    (enqueue thread, torch's intra-op pool, pinned-buffer copies) stay next to the memory they touch and the 8 ranks of a node do not
+    migrate over each other.  RD_NO_AFFINITY=1 leaves the affinity alone.  Returns the CPU list (or None)."""
+    if local_world <= 1 or os.environ.get("RD_NO_AFFINITY") or not hasattr(os, "sched_getaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    per = len(allowed) // local_world
+    if per < 1:
+        return None
+    mine = allowed[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(max_threads, len(mine))))
+    except ImportError:
+        pass
+    return mine
+
+
+def select_device(local_rank, local_world):
+    """The GPU of this rank, safe under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: a launcher that gives every process ONE visible
+    device (index 0 everywhere) and one that shows every process all of them (index = local rank) both work; anything in between
+    is an error, not a silent sharing of GPUs."""
+    import torch
+    n = torch.cuda.device_count()
+    if n >= local_world:
+        idx = local_rank
+    elif n == 1:
+        idx = 0
+    else:
+        raise RuntimeError("rank %d of %d local ranks sees %d GPUs (HIP_VISIBLE_DEVICES=%r): need one per rank or all of them" %
+                           (local_rank, local_world, n, os.environ.get("HIP_VISIBLE_DEVICES")))
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
+def device_identity(device):
+    """16 bytes that identify the physical GPU behind `device` (its UUID; the PCI bus id where the runtime has no UUID)."""
+    import hashlib
+    import torch
+    p = torch.cuda.get_device_properties(device)
+    ident = str(getattr(p, "uuid", "")) or str(getattr(p, "pci_bus_id", "")) or "%s/%d" % (p.name, device.index or 0)
+    return hashlib.sha256((ident + "@" + os.uname().nodename).encode()).digest()[:16]
+
+
+def check_ranks(ranks_seen, identities, world):
+    """Loud failure when the job is not `world` distinct ranks on `world` distinct GPUs: ranks_seen must be 0 .. world-1 exactly and
+    no two ranks may report the same device identity (two processes time-slicing one GPU would still print a throughput)."""
+    if list(ranks_seen) != list(range(world)):
+        raise RuntimeError("multi-GPU run: the communicator reports ranks %s, expected 0..%d" % (list(ranks_seen), world - 1))
+    ids = [bytes(i) for i in identities]
+    if len(set(ids)) != len(ids):
+        dup = sorted(r for r, i in enumerate(ids) if ids.count(i) > 1)
+        raise RuntimeError("multi-GPU run: ranks %s share a GPU (one process per GPU is the contract)" % dup)
+
+
+class HostCopyLib:
+    """rd_copy_rows for host memory: what DetectionGather's pack needs when the process group is gloo and the buffers are numpy
+    arrays (CPU test tier, `RD_BENCH_DRYRUN`).  Same arguments as the C ABI entry point (include/rangedet_hip.h)."""
+
+    @staticmethod
+    def call(name, src, src_row_bytes, dst, dst_row_bytes, dst_offset_bytes, nbytes, rows, stream=None):
+        import ctypes
+        assert name == "rd_copy_rows"
+        for r in range(rows):
+            ctypes.memmove(dst + r * dst_row_bytes + dst_offset_bytes, src + r * src_row_bytes, nbytes)
+        return 0
+
+
+class HostAlloc:
+    """numpy-backed stand-in for runtime.TorchAllocator on the gloo path (no GPU)."""
+    stream = None
+
+    @staticmethod
+    def alloc(nbytes, zero=False):
+        return np.zeros(max(int(nbytes), 16) + 64, dtype=np.uint8)
+
+    @staticmethod
+    def ptr(buf):
+        return buf.ctypes.data
+
+    @staticmethod
+    def sync():
+        pass
+
+
 class DetectionGather:
     """Padded per-frame records of one BatchPostProcessor (B frames) gathered from every rank.
 

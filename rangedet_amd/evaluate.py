@@ -56,7 +56,10 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
         return annotation_dict, output_dict
     H, W = np.asarray(load_record(roidb[mine[0]])['range_image']).shape[:2]
     Wp = -(-W // 32) * 32
-    cap = min(wnms_cap or 8192, pre_nms_top_n)
+    from .config import rangedet_veh_wo_aug_4_18e as cfgmod
+    # pre_nms_top_n: an int (the first class) or {class: k} (two-class variant); capacities are sized for the largest class
+    topn = dict(pre_nms_top_n) if isinstance(pre_nms_top_n, dict) else {cfgmod.variant_classes(variant)[0]: int(pre_nms_top_n)}
+    cap = min(wnms_cap or 8192, max(topn.values()))
     kw = dict(batch=batch, feat_size=(H, W), pad_field=(H, Wp), variant=variant, wnms=wnms, pre_nms_top_n=pre_nms_top_n)
     multi = InterleavedPipelines(params, n=max(1, inflight), wnms_cap=cap, **kw)
     pipe0 = multi.pipes[0]
@@ -65,7 +68,7 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
     big = {}                                                   # capacity -> single-frame pipeline for overflowing frames
 
     def rerun(rec):
-        K = min(pre_nms_top_n, rdlib.RD_WNMS_MAX_K)
+        K = min(max(topn.values()), rdlib.RD_WNMS_MAX_K)
         if K not in big:
             big[K] = RangeDetPipeline(params, wnms_cap=K, **dict(kw, batch=1))
         return big[K].run(to_inputs([rec]))
@@ -159,8 +162,10 @@ def main(argv=None, _spawned=False):
         import torch
         from . import dist as rdist
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        rdist.init_process_group("nccl", torch.device("cuda", local))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        rdist.bind_cpus(local, local_world)                     # per-rank CPU slice (reference: utils/cpu_affinity.py)
+        dev = rdist.select_device(local, local_world)           # raises instead of letting two ranks share a GPU
+        rdist.init_process_group("nccl", dev)
         shard = rdist.FrameSharding()
     from . import synth
     if a.synthetic:

@@ -58,8 +58,8 @@ class Plan:
 
 def conv_steps(steps):
     """The conv / deconv steps of a plan one by one: the two members of a "conv_pair" (one launch) as two entries.
-    Yields (step, launches): launches = what the step adds to the launch count (1, 0.5 + 0.5 for a pair, stride_w for the phases
-    of a transposed conv)."""
+    Yields (step, launches): launches = what the step adds to the launch count (1, 0.5 + 0.5 for a pair; a transposed conv: 1 when
+    all its phases run in one launch, else stride_w)."""
     for st in steps:
         if st["kind"] == "conv_pair":
             yield st["a"], 0.5
@@ -67,7 +67,7 @@ def conv_steps(steps):
         elif st["kind"] == "conv":
             yield st, 1
         elif st["kind"] == "deconv":
-            yield st, st["stride_w"]
+            yield st, 1 if st.get("one_launch") else st["stride_w"]
 
 
 def _strip_cast(s):
@@ -135,7 +135,7 @@ class Lowering:
             if k is not None:
                 # the tensor it reads was written before place j, and nothing from place j on touches what it writes
                 ready = written.get(st["x"].buf, -1)
-                clear = max(touched.get(v.buf, -1) for v in (st["out"], st.get("head_out")) if v is not None)
+                clear = max((touched.get(v.buf, -1) for v in (st["out"], st.get("head_out")) if v is not None), default=-1)
                 j = next((j for j in open_.get(k, []) if ready < j and clear < j), None)
                 if j is not None:
                     open_[k].remove(j)
@@ -152,11 +152,22 @@ class Lowering:
                     touched[st["x"].buf] = max(touched.get(st["x"].buf, -1), j)
                     continue
                 open_.setdefault(k, []).append(len(out))
-            for key, v in st.items():
+            def refs(key, v):   # every buffer reference of a step value, also inside lists / tuples / nested dicts
                 if isinstance(v, (TRef, FlatRef)):
-                    touched[v.buf] = len(out)
-                    if is_write(key):
-                        written[v.buf] = len(out)
+                    yield key, v
+                    if isinstance(v, TRef) and v.tail is not None:
+                        yield key, v.tail
+                elif isinstance(v, dict):
+                    for k2, v2 in v.items():
+                        yield from refs(k2 if isinstance(k2, str) else key, v2)
+                elif isinstance(v, (list, tuple)):
+                    for v2 in v:
+                        yield from refs(key, v2)
+            for key, v in st.items():
+                for k2, r in refs(key, v):
+                    touched[r.buf] = len(out)
+                    if is_write(k2):
+                        written[r.buf] = len(out)
             out.append(st)
         self.plan.steps = out
 
@@ -357,9 +368,12 @@ class Lowering:
                 out = self._out(cout, x.H, Wout, dest)
                 if (res.C, res.H, res.W) != (cout, x.H, Wout):
                     raise ValueError("agg add shape mismatch at %s" % add.name)
+                fold = self.h16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD")
+                # every phase a 3 x 2 tap set (kw = 2 sw, pad = sw / 2: k(3,8) s4 p2, k(3,4) s2 p1): all phases in ONE launch
+                # (rd_deconv2d_bn_act_all; the executor checks this against rd_deconv2d_all_phases_ok)
+                one = bool(fold and kw == 2 * sw and 2 * pw == sw and not os.environ.get("RD_DECONV_PER_PHASE"))
                 self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
-                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD,
-                          fold=self.h16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD"))
+                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD, fold=fold, one_launch=one)
                 return out
         raise NotImplementedError("elemwise_add %s is not skip + relu(BN(Deconvolution))" % add.name)
 

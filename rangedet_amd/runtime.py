@@ -188,8 +188,10 @@ class Executor:
             imgs = [L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt, fold_scale=fs) for ph in range(st["stride_w"])]
             # all phases in ONE launch when the library has that form for this layer (16-bit, folded scale, 3 x 2 phases):
             # the phase images back to back in one buffer (RD_DECONV_PER_PHASE=1: one launch per phase, for A/B runs)
-            b["all_phases"] = bool(st.get("fold")) and not os.environ.get("RD_DECONV_PER_PHASE") and len({len(i) for i in imgs}) == 1 and \
+            b["all_phases"] = bool(st.get("one_launch")) and len({len(i) for i in imgs}) == 1 and \
                 L.raw("rd_deconv2d_all_phases_ok")(st["k"][0], st["k"][1], st["stride_w"], st["pad_w"], st["cout"], dt) == 1
+            if st.get("one_launch") and not b["all_phases"] and not L.raw("rd_deconv2d_all_phases_ok")(st["k"][0], st["k"][1], st["stride_w"], st["pad_w"], st["cout"], dt):
+                b["one_launch"] = False      # (a development switch turned the library's form off: per-phase launches)
             if b["all_phases"]:
                 b["w_all"], b["w_pb"] = A.upload(np.concatenate(imgs)), len(imgs[0])
             b["w"] = [A.upload(i) for i in imgs]

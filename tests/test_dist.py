@@ -129,6 +129,34 @@ def test_bench_launches_itself(launcher):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["ranks_seen"] == [0, 1] and d["n_gpus"] == 2 and d["frames_step0"] == list(range(16))
+    # ... and the dry run drives the SHIPPING gather (dist.DetectionGather: pack, one all_gather, unpack) on host buffers: every rank
+    # found all 16 frames of a step with the rows their owners wrote
+    assert d["gather_ok"] is True and d["gathered_frames"] == 16
+
+
+def test_rank_and_device_checks():
+    """dist.check_ranks: anything but `world` distinct ranks on `world` distinct GPUs stops the run; dist.bind_cpus cuts the allowed
+    CPU list into per-rank slices (reference: utils/cpu_affinity.py:38-47) and restores nothing it did not change."""
+    from rangedet_amd import dist as rdist
+    ids = [bytes([i]) * 16 for i in range(4)]
+    rdist.check_ranks([0, 1, 2, 3], ids, 4)
+    with pytest.raises(RuntimeError, match="ranks"):
+        rdist.check_ranks([0, 1, 1, 3], ids, 4)
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        rdist.check_ranks([0, 1, 2, 3], [ids[0], ids[1], ids[1], ids[3]], 4)
+    before = os.sched_getaffinity(0)
+    try:
+        assert rdist.bind_cpus(0, 1) is None and os.sched_getaffinity(0) == before          # a single rank is left alone
+        if len(before) >= 2:
+            a = rdist.bind_cpus(1, 2)
+            assert a == sorted(before)[len(before) // 2: 2 * (len(before) // 2)] and os.sched_getaffinity(0) == set(a)
+    finally:
+        os.sched_setaffinity(0, before)
+    os.environ["RD_NO_AFFINITY"] = "1"
+    try:
+        assert rdist.bind_cpus(0, 2) is None
+    finally:
+        del os.environ["RD_NO_AFFINITY"]
 
 
 def test_bench_world_mismatch_is_an_error_not_an_assert():

@@ -54,7 +54,9 @@ def test_config_and_full_graph_lowering(monkeypatch):
     order = [s["name"] for s in pplan.steps if s["kind"] == "conv_pair"]
     assert order[:4] == ["rpn_cls_conv_%d_lvl_0 + rpn_reg_conv_%d_lvl_0" % (i, i) for i in range(4)]
     assert sorted(s["name"] for s, _ in conv_steps(pplan.steps)) == sorted(s["name"] for s, _ in conv_steps(plan.steps))
-    assert sum(n for _, n in conv_steps(pplan.steps)) == 49 + 12 + 12 and sum(n for _, n in conv_steps(plan.steps)) == 73 + 12
+    # (launch counts: a transposed conv is ONE launch -- all its phases, rd_deconv2d_bn_act_all)
+    assert sum(n for _, n in conv_steps(pplan.steps)) == 49 + 12 + 4 and sum(n for _, n in conv_steps(plan.steps)) == 73 + 4
+    assert all(s["one_launch"] for s in plan.steps if s["kind"] == "deconv")
     scs = [s for s in plan.steps if s.get("sc")]
     assert sorted(s["sc"]["name"] for s in scs) == sorted(n + "_unit1_sc" for n in (
         "res1", "res2a", "res2", "res3a", "res3", "agg2_res", "agg2a_res", "agg1_res", "agg3_res"))

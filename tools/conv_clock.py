@@ -1,6 +1,6 @@
 """Shader clock and launch time of the PRODUCTION 3x3 conv forms (rd_conv3x3_bn_act_ex, folded scales, 8 x 30 tiles) against the
 statistics of the input: random bf16, post-ReLU random (half zeros, like real activations), all zero.  The in-kernel trace
-(RD_CONV_TRACE) stamps s_memrealtime (100 MHz) at the start / end of every workgroup and its life in shader cycles (s_memtime).
+(rd_dev_conv_trace_set) stamps s_memrealtime (100 MHz) at the start / end of every workgroup and its life in shader cycles (s_memtime).
     python tools/conv_clock.py [W cin cout B]"""
 import ctypes
 import os
@@ -11,10 +11,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("RD_CONV_TRACE", "1")
 from rangedet_amd import lib as R  # noqa: E402
 
 L = R.get_lib()
+trace = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")       # the caller owns the trace buffer (the library never allocates)
+L.cdll.rd_dev_conv_trace_set.argtypes = [ctypes.c_void_p, ctypes.c_long]
+assert L.cdll.rd_dev_conv_trace_set(trace.data_ptr(), trace.numel()) == 0
 W, cin, cout, B = [int(v) for v in (sys.argv[1:5] + ["2656", "128", "128", "8"][len(sys.argv) - 1:])]
 H = 64
 st = torch.cuda.current_stream().cuda_stream

@@ -9,10 +9,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("RD_CONV_TRACE", "1")
 from rangedet_amd import lib as R  # noqa: E402
 
 L = R.get_lib()
+trace = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")       # the caller owns the trace buffer (the library never allocates)
+L.cdll.rd_dev_conv_trace_set.argtypes = [ctypes.c_void_p, ctypes.c_long]
+assert L.cdll.rd_dev_conv_trace_set(trace.data_ptr(), trace.numel()) == 0
 W, cin, cout, B = [int(v) for v in (sys.argv[1:5] + ["2656", "128", "128", "8"][len(sys.argv) - 1:])]
 H, dt = 64, R.RD_BF16
 cs = -(-cin // 16) * 16
