@@ -120,16 +120,28 @@ def _check(name, got, ref, dt, report, extra_abs=0.0):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("be", HIP_ONLY, indirect=True)
-@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "f16"])
-def test_every_production_launch_tight_at_full_geometry(be, dt):
+@pytest.mark.parametrize("dt,variant", [(BF16, "veh"), (F16, "veh"), (F16, "kitti")], ids=["bf16", "f16", "kitti-f16"])
+def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
+    """variant "veh": rangedet_veh_wo_aug_4_18e at 64 x 2656 (BASELINE configs[1]); "kitti": the two-class configuration of BASELINE
+    configs[4] at 64 x 2048 x 5 in fp16 -- W = 2048 / 1024 / 512 / 256 / 128 tile lists, a 5-channel first layer, 128-channel tower
+    outputs written for the separate two-class output convs."""
     from rangedet_amd.pipeline import RangeDetPipeline
+    from rangedet_amd.config import rangedet_veh_wo_aug_4_18e as cfgmod
     torch.set_num_threads(min(64, torch.get_num_threads()))
     t00 = time.time()
     B = 8
-    P = synth.make_weights(seed=18)
-    pipe = RangeDetPipeline(P, dtype=dt, batch=B, wnms_cap=4096, lib=be.lib, alloc=be.alloc)
+    if variant == "kitti":
+        Wk = 2048
+        P = synth.make_weights(seed=18, width=Wk, in_ch=cfgmod.KITTI_INPUT_CHANNELS, num_classes=2)
+        pipe = RangeDetPipeline(P, dtype=dt, batch=B, wnms_cap=4096, lib=be.lib, alloc=be.alloc, variant="kitti", feat_size=(64, Wk),
+                                pad_field=(64, Wk), pre_nms_top_n={'veh': 50000, 'ped': 5000})
+        fr = IR.make_batch(list(range(B)), W=Wk, pad_W=Wk, H=64)
+        fr['input_data'] = np.ascontiguousarray(fr['input_data'][:, [0, 3, 4, 5, 1]])     # KITTI channel order: range, x, y, z, intensity
+    else:
+        P = synth.make_weights(seed=18)
+        pipe = RangeDetPipeline(P, dtype=dt, batch=B, wnms_cap=4096, lib=be.lib, alloc=be.alloc)
+        fr = IR.make_batch(list(range(B)))
     plan, exe = pipe.plan, pipe.exe
-    fr = IR.make_batch(list(range(B)))
     dev = {}
     host = _Host(exe, plan)
     report, failed = [], []
@@ -245,7 +257,7 @@ def test_every_production_launch_tight_at_full_geometry(be, dt):
             failed.append(name)
         host.retire(i)
     dtn = "bf16" if dt == BF16 else "fp16"
-    print("\nper-step tight parity at B = 8, 64 x 2656, %s (worst |err| / tolerance, elements over):" % dtn)
+    print("\nper-step tight parity at B = 8, %s, %s (worst |err| / tolerance, elements over):" % ("64 x 2048 x 5 two-class" if variant == "kitti" else "64 x 2656", dtn))
     for name, shape, worst, nbad in report:
         print("  %-44s %-22s %.3f  %d" % (name, "x".join(str(v) for v in shape), worst, nbad))
     print("%d distinct launch forms, %d steps checked, %.0f s" % (len(seen_forms), len(report), time.time() - t00))
