@@ -32,6 +32,12 @@ struct Conv3Args {
   const unsigned char* zero16;  // 16 zero bytes in device memory: DMA source of padding pixels / channels
   int H, W, B, nslots, nchunk, flags, ncol, nrow, ntiles;
   int sw, Wo;   // column stride (1 or 2) and output width: a stride-2 conv is the stride-1 conv with only the even columns stored
+  // XCD-aware tile order (xcd = 1; launch_conv3 sets it when the column strips divide by 8): workgroups are dealt round-robin to the
+  // 8 XCDs, each with its own L2.  In the plain order (column tile fastest) the tile above / below / beside a tile runs on another
+  // XCD, so the 2 shared halo rows of every 10 cross the fabric twice.  Here list position v = wg + k*G is read as
+  // (XCD x = v % 8, position j = v / 8 on that XCD) and the XCD walks its own column strips (strip s = column tile x image, s % 8 == x)
+  // top to bottom: tile = (strip 8*(j / nrow) + x, row block j % nrow).  The 64 workgroups of an XCD work on 8 whole strips at a time.
+  int xcd;
   unsigned long long* trace;
   // HEAD variant: the 1x1 output conv that consumes this conv's result is applied in the epilogue and y is never written
   const unsigned char* hw;   // packed head weights: [hi | lo][ks 0..7][64 lanes][8 bf16] = 16 KB (pack_head_frag)
@@ -407,17 +413,27 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   // Tile t = wg + k*G of the list -> (column tile, row block, image).  Decoded ONCE for the workgroup's first tile; every later
   // tile is the previous one plus G in mixed radix (ncol, nrow) -- a few scalar adds and selects instead of the three software
   // integer divisions (~60 dependent scalar instructions in front of a wave's MFMAs, once per unit) a decode from t costs.
-  const int g_ct = G % a.ncol, g_rb = (G / a.ncol) % a.nrow, g_b = G / tiles_img;
-  auto tile_advance = [&](int& ct, int& rb, int& b) {
-    ct += g_ct;
-    const int c1 = ct >= a.ncol ? 1 : 0;
-    ct -= c1 ? a.ncol : 0;
-    rb += g_rb + c1;
-    const int c2 = rb >= a.nrow ? 1 : 0;
-    rb -= c2 ? a.nrow : 0;
-    b += g_b + c2;
+  // (XCD-aware order: j advances by G/8 per list step -> row block by (G/8) % nrow, strip by 8*dq or 8*(dq + 1))
+  const int xdq = (G >> 3) / a.nrow;
+  const int g_ct = a.xcd ? (8 * xdq) % a.ncol : G % a.ncol, g_rb = a.xcd ? (G >> 3) % a.nrow : (G / a.ncol) % a.nrow,
+            g_b = a.xcd ? (8 * xdq) / a.ncol : G / tiles_img;
+  const int g_ct1 = (8 * xdq + 8) % a.ncol, g_b1 = (8 * xdq + 8) / a.ncol;          // strip step with the row-block carry
+  auto tile_advance = [&](int& ct, int& rb, int& b) __attribute__((always_inline)) {
+    // one select-only form for both orders: digit 0 (radix r0) carries into digit 1 (radix r1) carries into the image index
+    int& d0 = a.xcd ? rb : ct;
+    int& d1 = a.xcd ? ct : rb;
+    const int r0 = a.xcd ? a.nrow : a.ncol, r1 = a.xcd ? a.ncol : a.nrow;
+    d0 += a.xcd ? g_rb : g_ct;
+    const int c1 = d0 >= r0 ? 1 : 0;
+    d0 -= c1 ? r0 : 0;
+    d1 += a.xcd ? (c1 ? g_ct1 : g_ct) : g_rb + c1;
+    const int c2 = d1 >= r1 ? 1 : 0;
+    d1 -= c2 ? r1 : 0;
+    b += (a.xcd && c1 ? g_b1 : g_b) + c2;
   };
-  int f_ct = wg % a.ncol, f_rb = (wg / a.ncol) % a.nrow, f_b = wg / tiles_img;   // tile of the NEXT halo to fetch
+  const int xs0 = ((wg >> 3) / a.nrow) * 8 + (wg & 7);                             // (XCD-aware order) first strip of this workgroup
+  int f_ct = a.xcd ? xs0 % a.ncol : wg % a.ncol, f_rb = a.xcd ? (wg >> 3) % a.nrow : (wg / a.ncol) % a.nrow,
+      f_b = a.xcd ? xs0 / a.ncol : wg / tiles_img;                                  // tile of the NEXT halo to fetch
   int c_ct = f_ct, c_rb = f_rb, c_b = f_b;                                        // tile being computed
   int f_ph = 0, c_ph = 0, s_ph = 0;                                               // (PH) phase of the fetch / compute / slab cursor
   const unsigned char* htile = nullptr;                   // uniform: halo pixel (0, 0) of the fetch tile, channel 0
@@ -1131,6 +1147,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
     a.nchunk1 = s2->cin1 / 32; a.nslots2 = cin_slots(s2->cin2, RD_BF16); a.nslots = a.nchunk1 * 4;
   }
   const int grid = std::min(a.ntiles, conv_num_cus() * (th4 || w30 ? 2 : 1));
+  a.xcd = sw_.conv_xcd && !g1 && (a.ncol * B) % 8 == 0 && grid % 8 == 0;   // (a pure permutation of the tile list under these conditions)
   if (conv_trace_buf() && (size_t)grid * 8 <= (1u << 20)) a.trace = conv_trace_buf();
   ProfScope ps(RD_PROF_CONV3, st);
 #ifdef RD_CONV3_DEV   // ablation variants (DBG bits: 2 no barrier, 4 no DMA after the prologue, 16 halo from the zero page, 32 no vmcnt wait)

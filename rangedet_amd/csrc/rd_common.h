@@ -47,6 +47,7 @@ struct DevSwitches {
   int conv_w30, conv_head30;
   int conv_hb3;            // RD_CONV_HB3 (default 1): cout 64 on 8 x 30 tiles fetches its halo two units ahead (three buffers)
   int conv_wide;           // RD_CONV_WIDE (default 1): 8 x 32 tiles (34-pixel halo pitch, every MFMA column live) instead of 8 x 30
+  int conv_xcd;            // RD_CONV_XCD (default 1): XCD-aware tile order of the persistent 3x3 kernel (k_conv3.h Conv3Args::xcd)
   int conv_body;           // RD_CONV_BODY (default 1): heterogeneous tile bodies (k_conv3.h c3_body) for stride 2 / <= 16-channel chunks
   bool sort_no_select;     // RD_SORT_NO_SELECT
   bool wnms_one_round;     // RD_WNMS_ONE_ROUND
@@ -66,6 +67,7 @@ inline const DevSwitches& dev_switches() {
     d.conv_hb3 = num("RD_CONV_HB3", 1);
     d.conv_wide = num("RD_CONV_WIDE", 1);
     d.conv_body = num("RD_CONV_BODY", 1);
+    d.conv_xcd = num("RD_CONV_XCD", 1);
     d.sort_no_select = getenv("RD_SORT_NO_SELECT") != nullptr;
     d.wnms_one_round = getenv("RD_WNMS_ONE_ROUND") != nullptr;
     d.wnms_ct = num("RD_WNMS_CT", 8);
