@@ -553,6 +553,7 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   a.tiles_h = (H + WAVES - 1) / WAVES;
   a.tiles_w = (W + 31) / 32;
   a.ntiles = B * a.tiles_h * a.tiles_w;
+  a.r0 = 0; a.m0 = a.m1 = a.m2 = 0;
   const size_t consts = 9 * 64 * 4 * 2 + 1024;
   ProfScope ps(RD_PROF_META, st);
   if (is_h16(dtype)) {
@@ -560,6 +561,11 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
     static unsigned long long seen = 0;
     if (first_use_on_device(seen)) { allow_big_lds(meta16_kernel<WAVES, RD_BF16>); allow_big_lds(meta16_kernel<WAVES, RD_F16>); }
     const dim3 mgrid(std::min(a.ntiles, conv_num_cus())), mblock(WAVES * 64);
+    const int strips = a.tiles_w * B;
+    a.r0 = dev_switches().conv_xcd && strips % 8 == 0 ? 8 : strips;   // (MetaArgs::r0: XCD-aware tile order; a permutation for any grid)
+    RD_REQUIRE((unsigned long long)a.ntiles * (unsigned)std::max(a.r0, std::max(a.tiles_h, a.tiles_w)) < (1ull << 32), RD_ESHAPE,
+               "meta_kernel: %d tiles exceed the range of the tile decode", a.ntiles);
+    a.m0 = meta_magic(a.r0); a.m1 = meta_magic(a.tiles_h); a.m2 = meta_magic(a.tiles_w);
     if (dtype == RD_F16) hipLaunchKernelGGL((meta16_kernel<WAVES, RD_F16>), mgrid, mblock, lds, st, a);
     else hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), mgrid, mblock, lds, st, a);
   } else {

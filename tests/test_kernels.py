@@ -304,9 +304,11 @@ def test_deconv2d_all_phases_in_one_launch(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-@pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40)])
+@pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40), (BF16, 8, 17, 70), (BF16, 4, 8, 33)])
 def test_meta_kernel_unit(be, case):
-    """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97."""
+    """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97.  (8 images x 3 column
+    tiles: the strips divide by 8 -> the XCD-aware tile order, MetaArgs::r0 = 8, several tiles per workgroup on the emulator; 4 x 8 x
+    33: one row tile -- the decode's divide-by-one case.)"""
     dt, B, H, W = case
     rng = np.random.default_rng(0)
     P = synth.make_weights(seed=18, width=W)
