@@ -230,6 +230,8 @@ extern "C" int mx_launch(int variant, const void* data, int d_cs, int d_co, cons
   a.data = data; a.d_cs = d_cs; a.d_co = d_co; a.coord = coord; a.packed = (const unsigned char*)packed;
   a.y = y; a.y_cs = y_cs; a.y_co = y_co; a.B = B; a.H = H; a.W = W;
   a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 31) / 32; a.ntiles = B * a.tiles_h * a.tiles_w;
+  a.r0 = (a.tiles_w * B) % 8 == 0 ? 8 : a.tiles_w * B;   // (MetaArgs::r0: tile order of meta16_kernel, as rd_meta_kernel_fwd sets it)
+  a.m0 = meta_magic(a.r0); a.m1 = meta_magic(a.tiles_h); a.m2 = meta_magic(a.tiles_w);
   const size_t lds = meta_layout(RD_BF16).wbytes + 9 * 64 * 4 * 2 + 1024 + (size_t)10 * 34 * 128 + 4096;
   int cus = 256;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
