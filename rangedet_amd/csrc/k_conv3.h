@@ -954,9 +954,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
           const int tcs = 32 * (i % FC) + em, ows = ct * C3_TW + tcs, ohs = oh0 + i / FC;
           if (jp == NPASS - 1 && tcs < C3_TW && ows < a.W && ohs < a.H) {
             float* o = e_ho + (size_t)b * e_ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * e_hn + 4 * ehi;
+            if (e_hn == 8 && !((size_t)o & 15)) {   // (the box regression head: one 16-byte store per lane instead of four 4-byte ones)
+              const f32x4 bv = *(const f32x4*)(e_hb + 4 * ehi);
+              *(f32x4*)o = f32x4{(h0[0] + h1[0]) + bv[0], (h0[1] + h1[1]) + bv[1], (h0[2] + h1[2]) + bv[2], (h0[3] + h1[3]) + bv[3]};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (4 * ehi + r < e_hn) o[r] = (h0[r] + h1[r]) + e_hb[4 * ehi + r];
+              for (int r = 0; r < 4; ++r)
+                if (4 * ehi + r < e_hn) o[r] = (h0[r] + h1[r]) + e_hb[4 * ehi + r];
+            }
           }
         } else {
           // read back pixel-major and store: lane -> (pixel it*RPI + el / SPR, slot el % SPR)
