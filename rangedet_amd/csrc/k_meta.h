@@ -330,7 +330,24 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 //   * the next tile's data / coordinate halo is fetched into registers while the current tile is computed.
 // LDS: weights 108 KiB + constants 5.5 KiB + data halo 42.5 KiB + coordinate halo 4 KiB = 160 KiB, one workgroup per CU.
 // DT = RD_BF16 or RD_F16 (same structure; the high / low split of MFMA #0 then carries 2^-18 resp. 2^-24 relative error).
-template <int WAVES, int DT = RD_BF16>
+// V: form of the tap loop (bit flags; every combination computes bit-identical results -- tools/micro/meta_v_bench.py checks that on
+// the GPU and times them side by side, profiles/EXPERIMENTS.md round 4).  V = 0 is the plain loop of rounds 2 - 4a:
+//   1   explicit software pipeline: the two MFMA #1 of (tap, block) step n + 1 are issued before the element-wise stage of step n
+//   2   ... and the hidden layer (MFMA #0 + ReLU + pack) of tap k + 2 during block 1 of tap k
+//   4   ... with a scheduling fence (vector / matrix instructions may not cross) between the look-ahead group and the current step
+//   8   halo fetch addresses as 32-bit offsets from 24-bit multiplies (no 64-bit / quarter-rate integer multiplies per tile)
+//   16  both fragments of a block are converted first, then its four MFMA #2 are issued together
+//   32  MFMA #1 two steps ahead (three dynamic-weight buffers)
+//   64  the epilogue's ReLU as a packed 16-bit integer max after the conversion (16 instead of 32 instructions)
+//   128 hidden-layer operand without the two per-tap selects of the upper lane half (its k-slots 12 .. 15 meet zero weights)
+//   1024 the neighbour's 16-bit channels are converted to fp32 by an MFMA with a 0 / 1 permutation matrix (exact) instead of 32 shift / mask
+//        instructions per tap: vector work moves to the matrix pipe, which is 30 % busy
+//   256 / 512: timing ablations (WRONG results: no per-tap constant reads / two vector instructions per pair) -- harness only
+// META_FORM = 219 (1 + 2 + 8 + 16 + 64 + 128) is what rd_meta_kernel_fwd launches: 210 - 215 us against 225 - 227 us for V = 0 on the same
+// boxes (gpurun_out/r4m4, r4m5).  What did NOT pay: the fence (4), two steps of look-ahead (32), the conversion MFMA (1024: 240 us --
+// every added MFMA sits in a step's dependent chain and costs ~80 wave cycles, 2.5 x its pipe time).
+constexpr int META_FORM = 219;
+template <int WAVES, int DT = RD_BF16, int V = META_FORM>
 __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
   using HT = H16<DT>;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -389,15 +406,19 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
     for (int u = 0; u < DU; ++u) {
       const int ih = h0 + drow[u], iw = w0 + dcol[u];
       dreg[u] = Slot16{0u, 0u, 0u, 0u};
-      if (dlds[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-        dreg[u] = *(const Slot16*)(dbase + ((size_t)ih * a.W + iw) * a.d_cs + dsrc[u]);
+      if (dlds[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+        if constexpr (V & 8) dreg[u] = *(const Slot16*)(dbase + (size_t)(unsigned)(__mul24(__mul24(ih, a.W) + iw, a.d_cs) + dsrc[u]));
+        else dreg[u] = *(const Slot16*)(dbase + ((size_t)ih * a.W + iw) * a.d_cs + dsrc[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u) {
       const int ih = h0 + crow[u], iw = w0 + ccol[u];
       creg[u] = 0.f;                              // im2col zero padding: outside the image the coordinate is 0
-      if (cch[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-        creg[u] = cbase[(size_t)cch[u] * HW + (long)ih * a.W + iw];
+      if (cch[u] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+        if constexpr (V & 8) creg[u] = cbase[(size_t)(unsigned)(__mul24(cch[u], (int)HW) + __mul24(ih, a.W) + iw)];
+        else creg[u] = cbase[(size_t)cch[u] * HW + (long)ih * a.W + iw];
+      }
     }
   };
   auto commit = [&]() {
@@ -411,6 +432,17 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
 
   // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
   const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(DT).w0f + lane * 16);
+  // (1024) 16-bit -> fp32 conversion of the neighbour's channels ON THE MATRIX CORES: x_f32[ch][px] = sum_k P[ch][k] * x[k][px] with P a 0 / 1
+  // permutation matrix, so the product is exact; its D layout is the dynamic weight's (lane (px, hi), register r = channel 16*hi + r of the
+  // block).  A operand of k-step s2: lane (m, h) element j is 1 iff m = 16*s2 + 8*(j >> 2) + 4*h + (j & 3).  The matrix pipe is 30 % busy,
+  // the vector ALU is what binds: 4 MFMAs per tap replace 32 shift / mask instructions per wave.
+  s16x8 idf[2];
+  if constexpr (V & 1024) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) idf[s2][j] = (px == 16 * s2 + 8 * (j >> 2) + 4 * hi + (j & 3)) ? (short)HT::ONE : (short)0;
+  }
   // per-lane LDS addresses that do not depend on the tile: everything a tap adds to them is a compile-time constant
   const unsigned char* w1l = lw + lane * 16;                 // + ((k*2 + mt)*2 + ks) * 1024
   const unsigned char* a2l = lw + W1S_B + lane * 16;         // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
@@ -439,6 +471,143 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
 
+    if constexpr (V & 1) {
+      // the same arithmetic as the loop below (bit-identical results), as three stages of an explicit software pipeline
+      auto hidden = [&](int k, s16x8 (&hf)[2]) {
+        const int pl = pl0 + (k / 3 - 1) * HC + (k % 3 - 1);
+        const float r0 = chalo[pl] - c0, r1 = chalo[HR * HC + pl] - c1, r2 = chalo[2 * HR * HC + pl] - c2;
+        const unsigned hxy = HT::pk(r0, r1), hz1 = HT::pk(r2, 1.0f);
+        const f32x2 uxy = HT::unpk(hxy), uz1 = HT::unpk(hz1);
+        const float l0 = r0 - uxy[0], l1 = r1 - uxy[1];
+        const float l2 = r2 - uz1[0];
+        const unsigned lxy = HT::pk(l0, l1), lz0 = HT::pk(l2, 0.f);
+        // (128: no selects -- k-slots 12 .. 15 of the upper lane half meet zero weights in the A operand, pack_meta, so what they hold
+        //  does not matter as long as it is finite, and the low parts are)
+        unsigned pk0[4] = {hxy, hz1, (V & 128) || !hi ? lxy : 0u, (V & 128) || !hi ? lz0 : 0u};
+        s16x8 b0frag;
+        memcpy(&b0frag, pk0, 16);
+        const f32x16 pre = HT::mfma(w0frag, b0frag, f32x16{});
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          unsigned pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned v = HT::pk(pre[8 * ks + 2 * e], pre[8 * ks + 2 * e + 1]);
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+          }
+          memcpy(&hf[ks], pk, 16);
+        }
+      };
+      auto d1calc = [&](int k, int mt, const s16x8 (&hf)[2]) {
+        f32x16 d1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = (V & 256) ? f32x4{1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(cbl + k * 64 + 32 * mt + 4 * q);   // (256: timing ablation)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d1[4 * q + e] = bq[e];
+        }
+        if (k != META_CENTRE_TAP) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const s16x8 af = *(const s16x8*)(w1l + ((k * 2 + mt) * 2 + ks) * 1024);
+            d1 = HT::mfma(af, hf[ks], d1);
+          }
+        }
+        return d1;
+      };
+      auto elem = [&](int k, int mt, const f32x16& d1) {
+        const int pl = pl0 + (k / 3 - 1) * HC + (k % 3 - 1);
+        const unsigned char* hp = halo + pl * PXB;
+        const int swz = (pl >> 1) & 7;
+        s16x8 bfr[2];
+        f32x16 xf = f32x16{};
+        if constexpr (V & 1024) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const s16x8 xq = *(const s16x8*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+            xf = HT::mfma(idf[s2], xq, xf);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const Slot16 dv = (V & 1024) ? Slot16{0u, 0u, 0u, 0u} : *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+          const f32x4 t0 = (V & 256) ? f32x4{.5f, .5f, .5f, .5f} : *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2);
+          const f32x4 t1v = (V & 256) ? f32x4{.5f, .5f, .5f, .5f} : *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2 + 4);
+          unsigned pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (V & 512) {   // (timing ablation: two vector instructions per pair instead of five)
+              pk[e] = HT::pk(d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]) ^ dv[e] ^ __builtin_bit_cast(unsigned, e < 2 ? t0[2 * e] : t1v[2 * e - 4]);
+              continue;
+            }
+            const f32x2 x2 = (V & 1024) ? f32x2{xf[8 * s2 + 2 * e], xf[8 * s2 + 2 * e + 1]} : HT::unpk(dv[e]);
+            const f32x2 w2 = {d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]};
+            const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
+            const f32x2 v2 = x2 * w2 + b2;
+            const unsigned v = HT::pk(v2[0], v2[1]);
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+          }
+          memcpy(&bfr[s2], pk, 16);
+          if constexpr (!(V & 16)) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+              const s16x8 af = *(const s16x8*)(a2l + (((k * 2 + ot) * 2 + mt) * 2 + s2) * 1024);
+              acc2[ot] = HT::mfma(af, bfr[s2], acc2[ot]);
+            }
+          }
+        }
+        if constexpr (V & 16) {   // both fragments of the block first, then its four MFMA #2
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+              const s16x8 af = *(const s16x8*)(a2l + (((k * 2 + ot) * 2 + mt) * 2 + s2) * 1024);
+              acc2[ot] = HT::mfma(af, bfr[s2], acc2[ot]);
+            }
+        }
+      };
+      s16x8 hf[2][2] = {};
+      if constexpr (V & 32) {
+        // MFMA #1 TWO steps ahead (three dynamic-weight buffers), the hidden layer a whole tap ahead of that
+        f32x16 d1c[3];
+        hidden(0, hf[0]);
+        hidden(1, hf[1]);
+        d1c[0] = d1calc(0, 0, hf[0]);
+        d1c[1] = d1calc(0, 1, hf[0]);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+          const int k = st >> 1, mt = st & 1;
+          if (st + 2 < 18) {
+            const int k2 = (st + 2) >> 1;       // = k + 1, block mt
+            d1c[(st + 2) % 3] = d1calc(k2, mt, hf[k2 & 1]);
+          }
+          elem(k, mt, d1c[st % 3]);
+          // hf[k & 1] was last read by d1calc(k, 1), issued at step (k - 1, 1): free from step (k, 0) on; tap k + 2 goes in at (k, 1)
+          if (mt == 1 && k + 2 < 9 && k + 2 != META_CENTRE_TAP) hidden(k + 2, hf[k & 1]);
+        }
+      } else {
+      f32x16 d1b[2];
+      hidden(0, hf[0]);
+      if constexpr (V & 2) hidden(1, hf[1]);
+      d1b[0] = d1calc(0, 0, hf[0]);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int k = st >> 1, mt = st & 1;
+        if (st + 1 < 18) {
+          const int k2 = (st + 1) >> 1, mt2 = (st + 1) & 1;
+          if constexpr (V & 2) {   // hidden layer two steps ahead: tap k + 2's after the last use of the buffer (tap k, block 1)
+          } else if (mt2 == 0 && k2 != META_CENTRE_TAP) hidden(k2, hf[k2 & 1]);
+          d1b[(st + 1) & 1] = d1calc(k2, mt2, hf[k2 & 1]);
+          if constexpr (V & 4) __builtin_amdgcn_sched_barrier(0x94);   // scalar / memory instructions may cross, vector / matrix ones may not
+        }
+        elem(k, mt, d1b[st & 1]);
+        if constexpr (V & 2) {
+          // buffer hf[k & 1] is free once d1calc(k, 1) has been issued, i.e. after step (k, 0): tap k + 2 goes in during step (k, 1)
+          if (mt == 1 && k + 2 < 9 && k + 2 != META_CENTRE_TAP) hidden(k + 2, hf[k & 1]);
+        }
+      }
+      }
+    } else {
     // the nine taps, fully unrolled: tap offsets, weight / constant addresses are immediates of the LDS instructions
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -522,6 +691,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
         }
       }
     }
+    }
     // epilogue: BN + ReLU, 16 contiguous output channels per (lane, ot)
     if (live) {
       bf16_t* yp = yout + (((size_t)b * a.H + h) * a.W + w) * a.y_cs + a.y_co;
@@ -530,9 +700,14 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
         const int ob = 32 * ot + 16 * hi;
         unsigned pk[8];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2)
+        for (int r = 0; r < 16; r += 2) {
+          if constexpr (V & 64) {   // ReLU after the 16-bit conversion, as a packed integer max (same bits: a negative value converts to a negative pattern)
+            const unsigned v = HT::pk(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1]);
+            pk[r >> 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+          } else
           pk[r >> 1] = HT::pk(fmaxf(acc2[ot][r] * cs2[ob + r] + cs2[64 + ob + r], 0.f),
                                        fmaxf(acc2[ot][r + 1] * cs2[ob + r + 1] + cs2[64 + ob + r + 1], 0.f));
+        }
         *(Slot16*)(yp + ob) = Slot16{pk[0], pk[1], pk[2], pk[3]};
         *(Slot16*)(yp + ob + 8) = Slot16{pk[4], pk[5], pk[6], pk[7]};
       }

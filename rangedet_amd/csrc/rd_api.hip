@@ -566,6 +566,9 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
     RD_REQUIRE((unsigned long long)a.ntiles * (unsigned)std::max(a.r0, std::max(a.tiles_h, a.tiles_w)) < (1ull << 32), RD_ESHAPE,
                "meta_kernel: %d tiles exceed the range of the tile decode", a.ntiles);
     a.m0 = meta_magic(a.r0); a.m1 = meta_magic(a.tiles_h); a.m2 = meta_magic(a.tiles_w);
+    // (form 8 of the kernel: per-image halo offsets are 32-bit, built from 24-bit multiplies)
+    RD_REQUIRE((long)H * W < (1l << 23) && (long)H * W * d_cstride < (1l << 31) && W < (1 << 23) && d_cstride < (1 << 23), RD_ESHAPE,
+               "meta_kernel: image of %d x %d pixels x %d channels exceeds the 32-bit halo offsets", H, W, d_cstride);
     if (dtype == RD_F16) hipLaunchKernelGGL((meta16_kernel<WAVES, RD_F16>), mgrid, mblock, lds, st, a);
     else hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), mgrid, mblock, lds, st, a);
   } else {

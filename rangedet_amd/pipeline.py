@@ -2,6 +2,7 @@
 (tools/test.py:143-161 forward + :184-224 post-process): config -> test symbol -> lowered plan -> Executor, then
 score filter, 10->11 dim, weighted NMS and 12->8 dim on the device.
 """
+import os
 import numpy as np
 
 from . import lib as rdlib
@@ -16,6 +17,12 @@ def input_shapes(H, W, strides=(1, 2, 4), channels=8):
         shapes['pc_vehicle_frame_s%d' % s] = (H * W // s, 3)
         shapes['range_image_mask_s%d' % s] = (H * W // s,)
     return shapes
+
+
+
+def _stream_prio(var):
+    """Development switch: queue priority of the launch / post-processing streams, 0 = normal (default), -1 = high."""
+    return int(os.environ.get(var, "0"))
 
 
 class BatchPostProcessor:
@@ -207,7 +214,7 @@ class RangeDetPipeline:
         A = self.alloc
         side = hasattr(A, "new_stream")
         if side and self._post_stream is None:
-            self._post_stream = A.new_stream()
+            self._post_stream = A.new_stream(priority=_stream_prio("RD_POST_STREAM_PRIO"))
         if side and self._filter_done is not None:
             A.wait_event(self._filter_done)          # previous frame's filter has consumed the score / box buffers
         outs = self.exe.forward(inputs)
@@ -263,7 +270,7 @@ class InterleavedPipelines:
     def __init__(self, params, n=2, **kw):
         self.pipes = [RangeDetPipeline(params, **kw) for _ in range(n)]
         A = self.pipes[0].alloc
-        self.streams = [A.new_stream() for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
+        self.streams = [A.new_stream(priority=_stream_prio("RD_LAUNCH_STREAM_PRIO")) for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
         self._i = 0
 
     def stream_context(self, j):

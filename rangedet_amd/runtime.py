@@ -64,8 +64,9 @@ class TorchAllocator:
         dst_view.copy_(src.reshape(dst_view.shape))
 
     # ---- streams / events (the post-processing of frame i overlaps the forward of frame i+1) ----------------
-    def new_stream(self):
-        return self.torch.cuda.Stream(device=self.device)
+    def new_stream(self, priority=0):
+        """priority: 0 = normal, -1 = high (torch's convention; the HIP runtime maps it onto the hardware queue's priority)."""
+        return self.torch.cuda.Stream(device=self.device, priority=priority)
 
     def stream_ptr(self, stream):
         return stream.cuda_stream if stream is not None else self.stream

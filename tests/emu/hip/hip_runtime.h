@@ -281,6 +281,7 @@ template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; 
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline int __mul24(int a, int b) { return (int)((unsigned)(((a << 8) >> 8)) * (unsigned)(((b << 8) >> 8))); }   // low 32 bits of the signed 24-bit product
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __expf(float x) { return expf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
