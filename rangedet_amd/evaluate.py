@@ -29,6 +29,40 @@ def load_record(rec):
                     inclination=z['inclination'].astype(np.float32))
 
 
+class RecordPrefetcher:
+    """Batches of loaded records, read `depth` batches ahead of the consumer by `threads` worker threads (np.load of a frame's
+    npz is ~14 MB of zip inflate, which releases the GIL).  The reference overlaps loading with the forward through the worker
+    threads of its Loader (tools/test.py:120-137, rangedet/core/loader.py -- out of scope as a component); without this the
+    enqueue thread would load 8 frames between two enqueues, and the loop would be I/O bound far below the GPU's rate.
+    Order is preserved; a loading error surfaces at the batch that needed the record."""
+
+    def __init__(self, roidb, chunks, threads=4, depth=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.roidb, self.chunks, self.depth = roidb, chunks, max(1, depth)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, threads)) if threads > 0 else None
+        self.futs, self.next = [], 0
+
+    def _submit(self):
+        while self.next < len(self.chunks) and len(self.futs) < self.depth:
+            chunk = self.chunks[self.next]
+            self.futs.append([self.pool.submit(load_record, self.roidb[i]) for i in chunk])
+            self.next += 1
+
+    def __iter__(self):
+        try:
+            for k, chunk in enumerate(self.chunks):
+                if self.pool is None:
+                    yield chunk, [load_record(self.roidb[i]) for i in chunk]
+                    continue
+                self._submit()
+                futs = self.futs.pop(0)
+                self._submit()                                  # keep `depth` batches in flight while this one is consumed
+                yield chunk, [f.result() for f in futs]
+        finally:
+            if self.pool is not None:
+                self.pool.shutdown(wait=False, cancel_futures=True)
+
+
 def meta_info(rec, rid):
     url = rec.get('pc_url')
     if not url:
@@ -38,7 +72,7 @@ def meta_info(rec, rid):
 
 
 def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms_top_n=50000, shard=None, inflight=2,
-        wnms_cap=None):
+        wnms_cap=None, loader_threads=4):
     """-> (annotation_dict, output_dict) exactly as tools/test.py:166-233 builds them (frames without detections are absent).
 
     shard (rangedet_amd.dist.FrameSharding): this process handles the records shard.mine(len(roidb)) -- the reference runs one
@@ -93,9 +127,8 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
 
     pending = []                                               # (pipeline index, record indices, records, inputs kept alive)
     done = 0
-    for i0 in range(0, len(mine), batch):
-        chunk = mine[i0:i0 + batch]
-        recs = [load_record(roidb[i]) for i in chunk]
+    chunks = [mine[i0:i0 + batch] for i0 in range(0, len(mine), batch)]
+    for chunk, recs in RecordPrefetcher(roidb, chunks, threads=loader_threads, depth=max(2, inflight)):
         padded = recs + [recs[-1]] * (batch - len(recs))       # the last batch is padded with its last frame
         if len(pending) == len(multi.pipes):                   # the pipeline about to be reused must be read back first
             finish(*pending.pop(0))
@@ -137,6 +170,7 @@ def main(argv=None, _spawned=False):
     ap = argparse.ArgumentParser(description=__doc__.split('\n\n')[0])
     ap.add_argument('--gpus', type=int, default=1, help="one process per GPU; records are sharded rank = index % gpus "
                                                         "(under torch.distributed.run the launcher's world size is used)")
+    ap.add_argument('--loader-threads', type=int, default=4, help="threads reading record npz files ahead of the GPU (0: load on the enqueue thread)")
     ap.add_argument('--roidb', help="glob of .roidb pickles (lists of records)")
     ap.add_argument('--synthetic', type=int, default=0, help="use N synthetic records instead of --roidb")
     ap.add_argument('--prefix'), ap.add_argument('--epoch', type=int)
@@ -182,7 +216,7 @@ def main(argv=None, _spawned=False):
         from .load_model import load_params
         params = load_params(a.prefix, a.epoch)
     rank = shard.rank if shard else 0
-    ann, out = run(roidb, params, batch=a.batch, wnms=not a.nms3d, shard=shard,
+    ann, out = run(roidb, params, batch=a.batch, wnms=not a.nms3d, shard=shard, loader_threads=a.loader_threads,
                    progress=(lambda d, n: print('%d of %d records' % (d, n), flush=True)) if rank == 0 else None)
     ann, out = merge_across_ranks(ann, out)
     if rank == 0:

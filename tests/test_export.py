@@ -89,3 +89,29 @@ def test_bin_file_round_trip(tmp_path):
     assert o["score"] == float(b[7]) and o["type"] == 1 and o["id"] == "" and o["frame_timestamp_micros"] == 1510593600340003
     assert o["context_name"] == '1005081002024129653_5313_150_5333_150' and "score" not in objs[5]
     assert export._varint(-1) == b"\xff" * 9 + b"\x01"
+
+
+def test_record_prefetcher_order_errors_and_inline_mode(tmp_path):
+    """rangedet_amd.evaluate.RecordPrefetcher: batches come back in order with every record loaded (npz records through worker
+    threads, already-loaded records untouched), a failing record raises at ITS batch, threads=0 loads inline."""
+    import numpy as np
+    import pytest
+    from rangedet_amd.evaluate import RecordPrefetcher
+    roidb = []
+    for i in range(11):
+        f = tmp_path / ("%d.npz" % i)
+        np.savez(f, range_image=np.full((4, 8, 5), i, np.float64), pc_vehicle_frame=np.zeros((4, 8, 3)), inclination=np.arange(4.0))
+        roidb.append({'pc_url': str(f)})
+    roidb.append({'range_image': np.full((4, 8, 5), 99, np.float32)})          # a synthetic (already loaded) record
+    chunks = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]
+    for threads in (0, 1, 4):
+        got = list(RecordPrefetcher(roidb, chunks, threads=threads, depth=2))
+        assert [c for c, _ in got] == chunks
+        for chunk, recs in got:
+            for i, r in zip(chunk, recs):
+                assert r['range_image'].dtype == np.float32 and float(r['range_image'][0, 0, 0]) == (99 if i == 11 else i)
+    bad = roidb[:5] + [{'pc_url': str(tmp_path / "missing.npz")}] + roidb[6:]
+    it = iter(RecordPrefetcher(bad, chunks, threads=2, depth=3))
+    assert next(it)[0] == chunks[0]                                            # the first batch is fine although batch 2 is already failing
+    with pytest.raises(FileNotFoundError):
+        next(it)
