@@ -11,7 +11,8 @@
  *   rd_conv3x3_bn_act_pair,   the cls and the reg tower conv i of a head level in ONE launch (the last pair with the towers'
  *   rd_conv2d_bn_act_head_out_pair   1x1 output convs)                            head/builder.py:221-261
  *   rd_deconv2d_bn_act,       mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
- *   rd_deconv2d_bn_act_all    (one call per output phase / all phases in one launch)  dla_backbone.py:117-127
+ *   rd_deconv2d_bn_act_all,   (one call per output phase / all phases in one launch / phase pairs as 128-channel
+ *   rd_deconv2d_bn_act_pairs  problems)                                           dla_backbone.py:117-127
  *   rd_head_out               1x1 logit / delta convs + cast + per-class flatten  head/builder.py:242-261,99-154
  *   rd_sorted_foreground      Custom op 'get_sorted_foreground'                   operator_py/get_sorted_foreground.py:11-40
  *   rd_decode3d_bbox          _contrib_Decode3DBbox                               operator_cxx/contrib/decode_3d_bbox-inl.h:169-305
@@ -191,6 +192,20 @@ int rd_deconv2d_bn_act_all(const void* x, int x_cstride, int x_coff, const void*
                            const float* shift, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
                            int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
                            int flags, int dtype, void* stream);
+
+/* The same launch with output phases 2p and 2p+1 computed as ONE 128-channel problem (cout 64, even stride, both phases of a pair
+ * on the same two input columns -- k(3,8) s4 p2: dla_backbone.py:117-127 'agg1'): in the output seen as [H][Win][stride_w * cout] a
+ * pair's channels are neighbours, so it is a 3 x 2-tap conv with 128 outputs and runs the cout-128 form of the kernel (bit-identical
+ * to rd_deconv2d_bn_act_all).  y / residual: dense cout-channel tensors (cstride == cout, coff 0).
+ * w_packed_pairs: stride_w / 2 images of rd_pack_deconv_phase_pair_host (phase images 2p, 2p+1 of rd_pack_deconv_weight_folded_host
+ * interleaved; 2 x the bytes of one phase image each), pair p at byte offset p * w_pair_bytes.  shift2: the layer's shift twice
+ * (2 * cout values).  rd_deconv2d_phase_pairs_ok: 1 if (kernel, stride, pad, cout, dtype) has this form, else 0. */
+int rd_deconv2d_phase_pairs_ok(int kh, int kw, int stride_w, int pad_w, int cout, int dtype);
+int rd_pack_deconv_phase_pair_host(const void* phase_a, const void* phase_b, int cin, int dtype, void* out);
+int rd_deconv2d_bn_act_pairs(const void* x, int x_cstride, int x_coff, const void* w_packed_pairs, long w_pair_bytes,
+                             const float* shift2, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                             int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                             int flags, int dtype, void* stream);
 
 /* 1x1 conv with bias to nout <= 8 float32 outputs per pixel, written flattened: out[(n_off + h*W + w)*nout + o]
  * (== the (B, N, nout) tensor after sep_level_type's reshape/transpose/concat; nout == 1 gives (B, N)).

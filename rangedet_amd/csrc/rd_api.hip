@@ -501,6 +501,56 @@ int rd_deconv2d_bn_act_all(const void* x, int x_cstride, int x_coff, const void*
                       y_coff, B, H, Win, cin, cout, flags, 1, (hipStream_t)stream, 3, nullptr, dtype, nullptr, &ph);
 }
 
+// ---- phase PAIRS of a transposed conv (cout 64, stride 4: dla_backbone.py:117-127 agg1) ----------------------------------------
+// Output phases 2p and 2p+1 of a (3, 2*s) / stride s / pad s/2 transposed conv with s = 4 read the SAME two input columns (tap set 1
+// for the pair 0 | 1, tap set 2 for 2 | 3), and in the output seen as [H][Win][s * C] their channels are neighbours: a pair is ONE
+// 3 x 2-tap conv with 2 * cout = 128 output channels.  It runs the cout-128 form of the persistent kernel (every pixel fragment read
+// from LDS feeds four MFMAs instead of two, half as many tile passes and epilogues) with bit-identical results: the K order of every
+// output element is unchanged.  Needs a dense cout-channel output / residual (y_cstride == r_cstride == cout, offsets 0).
+int rd_deconv2d_phase_pairs_ok(int kh, int kw, int stride_w, int pad_w, int cout, int dtype) {
+  if (!rd_deconv2d_all_phases_ok(kh, kw, stride_w, pad_w, cout, dtype) || cout != 64 || stride_w % 2) return 0;
+  if (!rd_deconv2d_all_phases_ok(kh, kw, stride_w, pad_w, 128, dtype)) return 0;    // (the cout-128 form of the kernel is available)
+  for (int p = 0; p < stride_w; p += 2)
+    if (deconv_tap_set(deconv_taps_sorted(kh, kw, stride_w, pad_w, p)) != deconv_tap_set(deconv_taps_sorted(kh, kw, stride_w, pad_w, p + 1))) return 0;
+  return 1;
+}
+// pair image = the two phase images of rd_pack_deconv_weight_folded_host interleaved per (chunk, tap, k-step): [A: 2 KB | B: 2 KB]
+int rd_pack_deconv_phase_pair_host(const void* phase_a, const void* phase_b, int cin, int dtype, void* out) {
+  RD_REQUIRE(phase_a && phase_b && out, RD_EINVAL, "pack_deconv_pair: null pointer");
+  RD_REQUIRE(is_h16(dtype) && cin > 0, RD_EINVAL, "pack_deconv_pair: dtype %d / cin %d", dtype, cin);
+  const size_t body = conv_packed_body_bytes(6, cin, 64, RD_BF16), blocks = body / 2048;    // (chunk, tap, k-step) blocks of 2 x 1 KB
+  for (size_t i = 0; i < blocks; ++i) {
+    memcpy((unsigned char*)out + i * 4096, (const unsigned char*)phase_a + i * 2048, 2048);
+    memcpy((unsigned char*)out + i * 4096 + 2048, (const unsigned char*)phase_b + i * 2048, 2048);
+  }
+  memset((unsigned char*)out + 2 * body, 0, 2 * RD_CONV_TAIL);    // the zero tail the kernel's padding DMA reads (k_conv.h RD_CONV_TAIL)
+  return RD_OK;
+}
+// w_packed_pairs: stride_w / 2 pair images, w_pair_bytes apart; shift2: 2 * cout values (the layer's shift twice)
+int rd_deconv2d_bn_act_pairs(const void* x, int x_cstride, int x_coff, const void* w_packed_pairs, long w_pair_bytes,
+                             const float* shift2, const void* residual, int r_cstride, int r_coff, void* y, int y_cstride,
+                             int y_coff, int B, int H, int Win, int cin, int cout, int kh, int kw, int stride_w, int pad_w,
+                             int flags, int dtype, void* stream) {
+  RD_REQUIRE(x && w_packed_pairs && y && shift2, RD_EINVAL, "deconv2d_pairs: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "deconv2d_pairs: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE(flags & RD_SCALE_FOLDED, RD_EINVAL, "deconv2d_pairs: needs RD_SCALE_FOLDED weights (rd_pack_deconv_weight_folded_host)");
+  RD_REQUIRE(!((flags & RD_ADD) && !residual), RD_EINVAL, "deconv2d_pairs: RD_ADD without residual");
+  RD_REQUIRE(B > 0 && H > 0 && Win > 0 && cin > 0, RD_ESHAPE, "deconv2d_pairs: shape");
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "deconv2d_pairs: x channel stride/offset");
+  RD_REQUIRE(rd_deconv2d_phase_pairs_ok(kh, kw, stride_w, pad_w, cout, dtype), RD_ESHAPE,
+             "deconv2d_pairs: kernel (%d,%d) stride %d pad %d cout %d has no phase pairs (use rd_deconv2d_bn_act_all)", kh, kw, stride_w, pad_w, cout);
+  RD_REQUIRE(y_cstride == cout && y_coff == 0 && (!residual || (r_cstride == cout && r_coff == 0)), RD_ESHAPE,
+             "deconv2d_pairs: the output / residual must be dense %d-channel tensors (two phases are one 128-channel write)", cout);
+  RD_REQUIRE(w_pair_bytes >= (long)conv_packed_bytes(6, cin, 2 * cout, RD_BF16) && w_pair_bytes % 16 == 0, RD_EINVAL, "deconv2d_pairs: w_pair_bytes");
+  allow_conv_lds();
+  Conv3Phases ph;
+  ph.nph = stride_w / 2; ph.ts_mask = 0; ph.y_pc = 2 * cout; ph.r_pc = 2 * cout; ph.w_pb = w_pair_bytes;
+  for (int p = 0; p < stride_w; p += 2)
+    if (deconv_tap_set(deconv_taps_sorted(kh, kw, stride_w, pad_w, p)) == 2) ph.ts_mask |= 1 << (p / 2);
+  return launch_conv3(x, x_cstride, x_coff, w_packed_pairs, nullptr, shift2, residual, r_cstride * stride_w, r_coff, y, y_cstride * stride_w,
+                      y_coff, B, H, Win, cin, 2 * cout, flags, 1, (hipStream_t)stream, 3, nullptr, dtype, nullptr, &ph);
+}
+
 int rd_head_out(const void* x, int x_cstride, int x_coff, const float* w, const float* bias, float* out,
                 long out_batch_stride, long n_off, int B, int H, int W, int cin, int nout, int dtype, void* stream) {
   RD_REQUIRE(x && w && bias && out, RD_EINVAL, "head_out: null pointer");

@@ -56,6 +56,11 @@ SIGNATURES = {
     "rd_deconv2d_bn_act_all": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_void_p]),
+    "rd_deconv2d_phase_pairs_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rd_pack_deconv_phase_pair_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rd_deconv2d_bn_act_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -203,6 +208,14 @@ class Lib:
         fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
         self.call("rd_pack_deconv_weight_folded_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cin, cout, kh, kw,
                   stride_w, pad_w, phase, dtype, out.ctypes.data)
+        return out
+
+    def pack_deconv_phase_pair(self, img_a, img_b, cin, dtype):
+        """Two phase images of pack_deconv_weight (cout 64, folded scale) -> the pair image of rd_deconv2d_bn_act_pairs."""
+        assert img_a.nbytes == img_b.nbytes
+        out = np.empty(2 * img_a.nbytes, np.uint8)
+        a, b = np.ascontiguousarray(img_a), np.ascontiguousarray(img_b)
+        self.call("rd_pack_deconv_phase_pair_host", a.ctypes.data, b.ctypes.data, cin, dtype, out.ctypes.data)
         return out
 
     def pack_head_weight(self, w, dtype=RD_BF16):

@@ -195,6 +195,15 @@ class Executor:
                 b["one_launch"] = False      # (a development switch turned the library's form off: per-phase launches)
             if b["all_phases"]:
                 b["w_all"], b["w_pb"] = A.upload(np.concatenate(imgs)), len(imgs[0])
+            # phases 2p | 2p+1 as one 128-channel problem where the layer has that form and its tensors are dense (agg1: 128 -> 64, stride 4;
+            # RD_DECONV_NO_PAIRS=1: the all-phases launch, for A/B runs)
+            r_, o_ = st["res"], st["out"]
+            b["pairs"] = b["all_phases"] and not os.environ.get("RD_DECONV_NO_PAIRS") and o_.cs == st["cout"] and o_.co == 0 and \
+                (r_ is None or (r_.cs == st["cout"] and r_.co == 0)) and \
+                L.raw("rd_deconv2d_phase_pairs_ok")(st["k"][0], st["k"][1], st["stride_w"], st["pad_w"], st["cout"], dt) == 1
+            if b["pairs"]:
+                pimgs = [L.pack_deconv_phase_pair(imgs[p], imgs[p + 1], st["cin"], dt) for p in range(0, st["stride_w"], 2)]
+                b["w_pairs"], b["w_pairb"], b["shift2"] = A.upload(np.concatenate(pimgs)), len(pimgs[0]), A.upload(np.concatenate([t, t]))
             b["w"] = [A.upload(i) for i in imgs]
             b["scale"], b["shift"] = (None if st.get("fold") else A.upload(s)), A.upload(t)
             if st.get("fold"):
@@ -294,6 +303,11 @@ class Executor:
                        b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["flags"], dt, st_)
             elif k == "deconv":
                 x, o, r = b["x"], b["out"], b["res"]
+                if b.get("pairs"):
+                    L.call("rd_deconv2d_bn_act_pairs", self.p(x), x.cs, x.co, A.ptr(b["w_pairs"]), b["w_pairb"], A.ptr(b["shift2"]), self.p(r), r.cs,
+                           r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["pad_w"],
+                           b["flags"], dt, st_)
+                    continue
                 if b.get("all_phases"):
                     L.call("rd_deconv2d_bn_act_all", self.p(x), x.cs, x.co, A.ptr(b["w_all"]), b["w_pb"], A.ptr(b["shift"]), self.p(r), r.cs,
                            r.co, self.p(o), o.cs, o.co, B, x.H, x.W, b["cin"], b["cout"], b["k"][0], b["k"][1], b["stride_w"], b["pad_w"],

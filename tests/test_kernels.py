@@ -304,6 +304,50 @@ def test_deconv2d_all_phases_in_one_launch(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(BF16, 2, 9, 70, 128, True), (BF16, 3, 17, 40, 64, True), (F16, 1, 11, 33, 128, True), (BF16, 1, 8, 64, 128, False)])
+def test_deconv2d_phase_pairs_equal_all_phases(be, case):
+    """rd_deconv2d_bn_act_pairs (output phases 2p | 2p+1 of the k(3,8) stride-4 transposed conv as ONE 128-channel problem on the
+    cout-128 form of the persistent kernel, dla_backbone.py:117-127 'agg1') == rd_deconv2d_bn_act_all bit for bit: the K order of
+    every output element is the same.  With and without the residual; error codes for layers / tensors without the form."""
+    dt, B, H, W, cin, with_res = case
+    cout, k, s, pw = 64, (3, 8), 4, 2
+    rng = np.random.default_rng(33)
+    x = h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), dt)
+    w = (rng.standard_normal((cin, cout, k[0], k[1])) / np.sqrt(cin * k[0] * k[1] / s)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32) * np.where(rng.random(cout) < 0.2, -1, 1).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    Wout = s * W
+    res = h16_round(rng.standard_normal((B, cout, H, Wout)).astype(np.float32), dt)
+    L = be.lib
+    ok = L.raw("rd_deconv2d_phase_pairs_ok")
+    assert ok(3, 8, 4, 2, 64, dt) == 1
+    assert ok(3, 4, 2, 1, 64, dt) == 0          # stride 2: the two phases read different column pairs
+    assert ok(3, 8, 4, 2, 128, dt) == 0         # a pair would have 256 output channels
+    assert ok(3, 8, 4, 2, 64, F32) == 0
+    xin, rin = be.up(to_nhwc(x, dt)), be.up(to_nhwc(res, dt))
+    fl = (R.RD_RELU_PRE | R.RD_ADD | R.RD_SCALE_FOLDED) if with_res else (R.RD_RELU_POST | R.RD_SCALE_FOLDED)
+    rp = be.ptr(rin) if with_res else None
+    imgs = [L.pack_deconv_weight(w, s, pw, ph, dt, fold_scale=sc) for ph in range(s)]
+    pairs = [L.pack_deconv_phase_pair(imgs[p], imgs[p + 1], cin, dt) for p in (0, 2)]
+    y1, y2 = be.empty(B * H * Wout * cout * 2), be.empty(B * H * Wout * cout * 2)
+    L.call("rd_deconv2d_bn_act_all", be.ptr(xin), cin, 0, be.ptr(be.up(np.concatenate(imgs))), len(imgs[0]), be.ptr(be.up(sh)), rp, cout, 0,
+           be.ptr(y1), cout, 0, B, H, W, cin, cout, k[0], k[1], s, pw, fl, dt, be.stream)
+    L.call("rd_deconv2d_bn_act_pairs", be.ptr(xin), cin, 0, be.ptr(be.up(np.concatenate(pairs))), len(pairs[0]), be.ptr(be.up(np.concatenate([sh, sh]))),
+           rp, cout, 0, be.ptr(y2), cout, 0, B, H, W, cin, cout, k[0], k[1], s, pw, fl, dt, be.stream)
+    a, b = be.down(y1, np.uint16, (B, H, Wout, cout)), be.down(y2, np.uint16, (B, H, Wout, cout))
+    assert np.array_equal(a, b), int((a != b).sum())
+    ref = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), stride=(1, s), padding=(1, pw)).numpy() * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = (np.maximum(ref, 0) + res) if with_res else np.maximum(ref, 0)
+    assert np.abs(from_nhwc(b, dt, cout) - ref).max() <= 1.5 * _tol(dt, ref)
+    buf = be.ptr(be.empty(1 << 16))
+    f = L.raw("rd_deconv2d_bn_act_pairs")
+    assert f(buf, 128, 0, buf, 1 << 20, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 4, 2, 1, fl, dt, be.stream) == R.RD_ESHAPE      # stride 2
+    assert f(buf, 128, 0, buf, 1 << 20, buf, buf, 64, 0, buf, 80, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, fl, dt, be.stream) == R.RD_ESHAPE      # output not dense
+    assert f(buf, 128, 0, buf, 1 << 20, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, fl & ~R.RD_SCALE_FOLDED, dt, be.stream) == R.RD_EINVAL
+    assert f(buf, 128, 0, buf, 4096, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, fl, dt, be.stream) == R.RD_EINVAL          # pair images overlap
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40), (BF16, 8, 17, 70), (BF16, 4, 8, 33)])
 def test_meta_kernel_unit(be, case):
     """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97.  (8 images x 3 column
