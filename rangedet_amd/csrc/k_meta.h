@@ -340,15 +340,16 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 //   32  MFMA #1 two steps ahead (three dynamic-weight buffers)
 //   64  the epilogue's ReLU as a packed 16-bit integer max after the conversion (16 instead of 32 instructions)
 //   128 hidden-layer operand without the two per-tap selects of the upper lane half (its k-slots 12 .. 15 meet zero weights)
-//   1024 the neighbour's 16-bit channels are converted to fp32 by an MFMA with a 0 / 1 permutation matrix (exact) instead of 32 shift / mask
-//        instructions per tap: vector work moves to the matrix pipe, which is 30 % busy
-//   256 / 512: timing ablations (WRONG results: no per-tap constant reads / two vector instructions per pair) -- harness only
+// (Forms measured and removed again -- the commit "Meta-Kernel: tap loop as an explicit software pipeline" has them: 256 / 512 timing
+//  ablations without the per-tap constant reads / with two vector instructions per pair; 1024 the neighbour's 16-bit channels converted
+//  to fp32 by an MFMA with a 0 / 1 permutation matrix, exact and bit-identical but 240 us.)
 // META_FORM = 219 (1 + 2 + 8 + 16 + 64 + 128) is what rd_meta_kernel_fwd launches: 210 - 215 us against 225 - 227 us for V = 0 on the same
 // boxes (gpurun_out/r4m4, r4m5).  What did NOT pay: the fence (4), two steps of look-ahead (32), the conversion MFMA (1024: 240 us --
 // every added MFMA sits in a step's dependent chain and costs ~80 wave cycles, 2.5 x its pipe time).
 constexpr int META_FORM = 219;
 template <int WAVES, int DT = RD_BF16, int V = META_FORM>
 __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
+  static_assert((V & ~0xFF) == 0, "meta16_kernel: unknown form flag");
   using HT = H16<DT>;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -432,17 +433,6 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
 
   // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
   const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(DT).w0f + lane * 16);
-  // (1024) 16-bit -> fp32 conversion of the neighbour's channels ON THE MATRIX CORES: x_f32[ch][px] = sum_k P[ch][k] * x[k][px] with P a 0 / 1
-  // permutation matrix, so the product is exact; its D layout is the dynamic weight's (lane (px, hi), register r = channel 16*hi + r of the
-  // block).  A operand of k-step s2: lane (m, h) element j is 1 iff m = 16*s2 + 8*(j >> 2) + 4*h + (j & 3).  The matrix pipe is 30 % busy,
-  // the vector ALU is what binds: 4 MFMAs per tap replace 32 shift / mask instructions per wave.
-  s16x8 idf[2];
-  if constexpr (V & 1024) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) idf[s2][j] = (px == 16 * s2 + 8 * (j >> 2) + 4 * hi + (j & 3)) ? (short)HT::ONE : (short)0;
-  }
   // per-lane LDS addresses that do not depend on the tile: everything a tap adds to them is a compile-time constant
   const unsigned char* w1l = lw + lane * 16;                 // + ((k*2 + mt)*2 + ks) * 1024
   const unsigned char* a2l = lw + W1S_B + lane * 16;         // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
@@ -502,7 +492,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
         f32x16 d1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = (V & 256) ? f32x4{1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(cbl + k * 64 + 32 * mt + 4 * q);   // (256: timing ablation)
+          const f32x4 bq = *(const f32x4*)(cbl + k * 64 + 32 * mt + 4 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) d1[4 * q + e] = bq[e];
         }
@@ -520,27 +510,15 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
         const unsigned char* hp = halo + pl * PXB;
         const int swz = (pl >> 1) & 7;
         s16x8 bfr[2];
-        f32x16 xf = f32x16{};
-        if constexpr (V & 1024) {
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const s16x8 xq = *(const s16x8*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
-            xf = HT::mfma(idf[s2], xq, xf);
-          }
-        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const Slot16 dv = (V & 1024) ? Slot16{0u, 0u, 0u, 0u} : *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
-          const f32x4 t0 = (V & 256) ? f32x4{.5f, .5f, .5f, .5f} : *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2);
-          const f32x4 t1v = (V & 256) ? f32x4{.5f, .5f, .5f, .5f} : *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2 + 4);
+          const Slot16 dv = *(const Slot16*)(hp + (((4 * mt + 2 * hi + s2) ^ swz) << 4));
+          const f32x4 t0 = *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2);
+          const f32x4 t1v = *(const f32x4*)(ctl + k * 64 + 32 * mt + 8 * s2 + 4);
           unsigned pk[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if constexpr (V & 512) {   // (timing ablation: two vector instructions per pair instead of five)
-              pk[e] = HT::pk(d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]) ^ dv[e] ^ __builtin_bit_cast(unsigned, e < 2 ? t0[2 * e] : t1v[2 * e - 4]);
-              continue;
-            }
-            const f32x2 x2 = (V & 1024) ? f32x2{xf[8 * s2 + 2 * e], xf[8 * s2 + 2 * e + 1]} : HT::unpk(dv[e]);
+            const f32x2 x2 = HT::unpk(dv[e]);
             const f32x2 w2 = {d1[8 * s2 + 2 * e], d1[8 * s2 + 2 * e + 1]};
             const f32x2 b2 = e < 2 ? f32x2{t0[2 * e], t0[2 * e + 1]} : f32x2{t1v[2 * e - 4], t1v[2 * e - 3]};
             const f32x2 v2 = x2 * w2 + b2;
