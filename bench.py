@@ -501,8 +501,8 @@ def main(argv=None):
                           "avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["gbps"], "frac": alone["frac_hbm_peak"],
                           "tflops": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12,
                           "frac_mfma_peak": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                          "binding_roof": "mfma (433 FLOP/B is above the ridge of 312 FLOP/B); in practice vector-ALU issue "
-                                          "(DESIGN.md section 5)",
+                          "binding_roof": "mfma (433 FLOP/B is above the ridge of 312 FLOP/B); in practice the latency of its dependent "
+                                          "MFMA -> vector -> MFMA chains at two waves per SIMD (DESIGN.md section 6.3)",
                           "note": "achieved / avg_launch_ms: serial replay of the kernel alone (HIP events); in_pipeline_*: the "
                                   "same launch inside the timed pipeline, where the previous batch's NMS kernels share the GPU"})
 
