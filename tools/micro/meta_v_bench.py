@@ -1,6 +1,6 @@
 """Dev harness: the experimental forms of meta16_kernel (k_meta.h, template parameter V) against the shipping form V = 0 at the
 production shape -- outputs compared bit for bit, all timed alternately.  Builds tools/micro/meta_v.hip into
-tools/micro/libmeta_v.so on the fly (hipcc, seconds per form).  MV_FLAGS: extra hipcc flags, e.g. '-DMV_LIST="X(0) X(8)"'.
+tools/micro/libmeta_v.so on the fly (hipcc, seconds per form).  MV_FLAGS: extra hipcc flags, e.g. '-DMV_LIST="X(0) X(8)"', '-DMV_DT=RD_F16' (the fp16 instantiations).
     python tools/micro/meta_v_bench.py [B] [reps]"""
 import ctypes
 import os
@@ -29,6 +29,8 @@ L, A = rdlib.get_lib(), TorchAllocator()
 M = ctypes.CDLL(so)
 M.mv_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+DT = M.mv_dtype()
+tdt = torch.float16 if DT == rdlib.RD_F16 else torch.bfloat16
 vbuf = (ctypes.c_int * 64)()
 variants = list(vbuf[: M.mv_variants(vbuf, 64)])
 P = synth.make_weights(seed=18)
@@ -36,10 +38,10 @@ name, pre = 'res1_unit2', 'res1_unit2_%d' % W
 s1, t1 = bn_affine(P, name + "point_wise_mlp_bn1", 1e-5 + 1e-10)
 s2, t2 = bn_affine(P, name + "aggregation_bn1", 1e-5 + 1e-10)
 pk = A.upload(L.pack_meta(P[pre + "_mlp0_weight"].reshape(32, 3), P[pre + "_mlp0_bias"], P[pre + "_mlp1_weight"].reshape(64, 32),
-                          P[pre + "_mlp1_bias"], s1, t1, P[name + "aggregation_conv1_weight"].reshape(64, 576), s2, t2, rdlib.RD_BF16))
-x = torch.relu(torch.randn(B, H, W, 64, device="cuda")).to(torch.bfloat16)
+                          P[pre + "_mlp1_bias"], s1, t1, P[name + "aggregation_conv1_weight"].reshape(64, 576), s2, t2, DT))
+x = torch.relu(torch.randn(B, H, W, 64, device="cuda")).to(tdt)
 c = torch.randn(B, 3, H, W, device="cuda") * 20
-ys = {v: torch.zeros(B, H, W, 64, device="cuda", dtype=torch.bfloat16) for v in variants}
+ys = {v: torch.zeros(B, H, W, 64, device="cuda", dtype=tdt) for v in variants}
 st = torch.cuda.current_stream().cuda_stream
 
 
