@@ -971,7 +971,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
             const int tcs = 32 * (i % FC) + pr, ows = ct * C3_TW + tcs;
             if (tcs < C3_TW && ows < a.W && oh0 + i / FC < a.H && !(ows & sh) && (!(DBG & 1) || a.B < 0))
-              *(Slot16*)(yrow0 + (size_t)(i / FC) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + jp * CW + sl * 8) = v;
+              // non-temporal: an output line is written once and read back by the NEXT launch; without the hint the stores displace the
+              // halo rows / residual lines that neighbouring tiles are about to re-read (A/B on one box, 7 alternations: +0.7 ... +0.9 %
+              // frames/s, serial step sum -2.5 ... -3.3 %; a run-time size test around the store gave the gain away again, EXPERIMENTS.md)
+              __builtin_nontemporal_store(v, (Slot16*)(yrow0 + (size_t)(i / FC) * a.Wo * a.y_cs + (size_t)(ows >> sh) * a.y_cs + jp * CW + sl * 8));
           }
         }
         __builtin_amdgcn_wave_barrier();
