@@ -261,6 +261,9 @@ def main(argv=None):
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
     ap.add_argument("--wnms-cap", type=int, default=8192, help="rows per frame the weighted NMS is sized for (checked every step)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps (barrier + synchronize on both sides) is run this many times back to back; "
+                         "`value` / `ms_per_step` are the MEDIAN region, the spread is reported next to it (SURVEY.md 8d: median + p5/p95)")
     args = ap.parse_args(argv)
     argv = list(sys.argv[1:] if argv is None else argv)
 
@@ -343,6 +346,7 @@ def main(argv=None):
     for h in host:
         h.update(done=None, step=-1)
     max_cand = [0]
+    done_events = []
 
     def harvest(j):
         """Host side of a finished batch: wait for its copies, check the WNMS capacity (K <= cap is what makes the
@@ -381,9 +385,10 @@ def main(argv=None):
                 # batch's forward overlaps it, nothing on a launch stream waits for it
                 for g_ in gathers[j]:
                     g_.enqueue(pj._post_stream)
-            h["done"] = torch.cuda.Event()
+            h["done"] = torch.cuda.Event(enable_timing=True)
             h["done"].record(pj._post_stream)
             h["step"] = i
+            done_events.append(h["done"])      # (completion time of every step: the per-step percentiles of the report)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -397,20 +402,46 @@ def main(argv=None):
     if gather:   # RCCL prints a version banner through C stdio when the communicator comes up: get it out of the way now
         import ctypes
         ctypes.CDLL(None).fflush(None)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    for j in range(len(multi.pipes)):
-        harvest(j)
-    elapsed = time.perf_counter() - t0
+    # The timed region = EXACTLY --steps steps between two barriers (+ synchronize on both sides), max over ranks.  It is run
+    # --repeats times back to back (step numbering continues, so the pipelines keep alternating); the headline is the MEDIAN
+    # region, and the completion event of every step gives the per-step distribution (interval between consecutive completions
+    # inside a region: with two batches in flight that is the steady-state time per step).
+    repeats = max(1, args.repeats)
+    region_s, step_ms = [], []
+    nstep = args.warmup
+    for r in range(repeats):
+        del done_events[:]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(nstep)
+            nstep += 1
+        barrier()
+        for j in range(len(multi.pipes)):
+            harvest(j)
+        region_s.append(time.perf_counter() - t0)
+        step_ms += [done_events[i].elapsed_time(done_events[i + 1]) for i in range(len(done_events) - 1)]
     if gather:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor(region_s, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    last = (args.warmup + args.steps - 1) % len(multi.pipes)
+        region_s = [float(v) for v in t.cpu()]
+    elapsed = float(np.median(region_s))
+    total_steps = args.warmup + args.steps * repeats
+    last = (total_steps - 1) % len(multi.pipes)
     res = multi.pipes[last].collect()[0]
-    gathered_frames = len(gathers[last][0].unpack((args.warmup + args.steps - 1))) if gather else None
+    gathered_frames = gather_matches_local = None
+    # digest of the last step's device results (every frame's kept rows, counts): the same data with and without the collective
+    import hashlib
+    lastf = multi.pipes[last].bposts[classes[0]].collect_all()
+    results_sha256 = hashlib.sha256(b"".join(f["wnms_rows"].tobytes() + f["keep_inds"].tobytes() for f in lastf)).hexdigest()[:16]
+    if gather:
+        # what came out of the collective against what this rank put in: its own B frames' records, bit for bit
+        got = gathers[last][0].unpack(total_steps - 1)
+        gathered_frames = len(got)
+        gather_matches_local = True
+        for b_, f_ in enumerate(shard.frames_of_step(total_steps - 1, Bf)):
+            rows_, M_ = got[f_]
+            want_ = lastf[b_]["wnms_rows"][:rdist.MAX_DET]
+            gather_matches_local = gather_matches_local and M_ == len(lastf[b_]["wnms_rows"]) and np.array_equal(rows_.view(np.uint32), want_.view(np.uint32))
 
     # ---- per-kernel timing with HIP events on the launch stream, over a replay of the same steps ------------------
     roof = meta_info = prof = backbone_info = None
@@ -493,7 +524,7 @@ def main(argv=None):
         meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
         meta_info["intensity_flop_per_byte"] = META_FLOP_PER_PX * NPIX * Bf / mbytes
         meta_info["traffic"] = measured_traffic("meta_kernel", Bf) if dt == rdlib.RD_BF16 else None
-        backbone_info = backbone_forward_roofline(pipe, frames[0], Bf, esz)
+        backbone_info = backbone_forward_roofline(pipe, frames[0], Bf, esz, reps=10)
         # headline figure of the Meta-Kernel = the kernel with nothing else resident; in the pipeline the previous batch's NMS
         # kernels (side stream) co-run with it and its launch-to-end time is longer -- both are reported
         alone = backbone_info.pop("meta_kernel_alone")
@@ -511,6 +542,15 @@ def main(argv=None):
             "metric": "range-image frames/sec (64x2650, 8ch) at 1/2/4/8 GPU; Meta-Kernel HBM GB/s vs peak",
             "value": args.steps * world * Bf / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            # spread: `value` / `ms_per_step` are the median of `repeats` timed regions of `steps` steps each;
+            # ms_per_step_p5/p50/p95 come from the completion events of the individual steps (steady-state interval between
+            # consecutive completions, (steps - 1) x repeats samples; own-rank events -- rank 0 for N > 1)
+            "repeats": repeats, "value_min": args.steps * world * Bf / max(region_s), "value_max": args.steps * world * Bf / min(region_s),
+            "region_ms": [round(v * 1e3, 3) for v in region_s],
+            "ms_per_step_p5": float(np.percentile(step_ms, 5)) if step_ms else None,
+            "ms_per_step_p50": float(np.percentile(step_ms, 50)) if step_ms else None,
+            "ms_per_step_p95": float(np.percentile(step_ms, 95)) if step_ms else None,
+            "value_p50": (world * Bf / (float(np.percentile(step_ms, 50)) * 1e-3)) if step_ms else None,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("KITTI-shaped (BASELINE configs[4]): DLA backbone + Meta-Kernel + vehicle and pedestrian heads + per-class "
                                     "top-k (50000 / 5000) + 3D decode + weighted NMS per class on 64x2048 x 5ch synthetic range images, "
@@ -523,7 +563,8 @@ def main(argv=None):
                                      for c, r in res.get("per_class", {}).items()} or None,
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
-                       "gathered_frames_last_step": gathered_frames, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
+                       "gathered_frames_last_step": gathered_frames, "gather_matches_local": gather_matches_local,
+                       "results_sha256_last_step": results_sha256, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
                        "cpus_per_rank": len(cpus) if cpus else None,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("self (mp.spawn)" if world > 1 else "single process")},

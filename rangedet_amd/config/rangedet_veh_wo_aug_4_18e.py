@@ -30,7 +30,10 @@ def variant_classes(variant):
 
 
 def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(64, 2656), fp16=True, batch_image=1,
-               pre_nms_top_n=None, wnms=True, sampling_rate=4, end_epoch=18, name=None):
+               pre_nms_top_n=None, wnms=True, sampling_rate=4, end_epoch=18, name=None, backbone=None):
+    """backbone: optional {attribute: value} overrides of BackboneParam (dict-valued attributes are merged key by key), e.g.
+    backbone={'num_filter': {'res1': 96}} -- the reference's config surface lets these vary (dla_backbone.py:59-103,130-161); the
+    symbol builds for any value, the HIP lowering only takes the shipped widths and says so (lower.py)."""
     _wnms = bool(wnms)
     if is_train:
         raise NotImplementedError("training is outside the hot path this package implements")
@@ -79,6 +82,10 @@ def get_config(is_train=False, variant="veh", feat_size=(64, 2650), pad_field=(6
         num_filter = {'res1': 64, 'res2a': 64, 'res2': 128, 'res3a': 128, 'res3': 128, 'agg1': 64, 'agg2': 128,
                       'agg2a': 64, 'agg3': 64}
         add_data_sc = True
+
+    for _k, _v in (backbone or {}).items():
+        _cur = getattr(BackboneParam, _k)
+        setattr(BackboneParam, _k, dict(_cur, **_v) if isinstance(_cur, dict) and isinstance(_v, dict) else _v)
 
     class RpnParam:
         fp16 = General.fp16

@@ -1025,8 +1025,8 @@ inline int conv_num_cus() {
 template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false, int BODY = 0>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
   auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP, BODY>;
-  static unsigned long long seen = 0;   // (benign race: two threads may both set the attribute)
-  if (first_use_on_device(seen)) allow_big_lds(k);
+  static std::atomic<unsigned long long> seen{0};
+  once_per_device(seen, [&] { allow_big_lds(k); });
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
   return check_launch("conv3x3_stream_kernel");

@@ -14,6 +14,12 @@
 //   per-tap constants, and the (WAVES+2) x 34 data halo (XOR-swizzled 16-byte slots).
 //   meta_kernel<RD_F32> (parity mode): v_mfma_f32_32x32x2_f32, hidden layer on the VALU, weights streamed from L2
 //   (220 KiB > LDS).  meta_bf16_kernel (production, end of this file): hidden layer on the matrix cores too.
+// INPUT CONTRACT: data and coordinates are FINITE.  The 16-bit production form (meta16_kernel<8, DT, 219>) applies its ReLUs as a packed
+// signed 16-bit max on the converted values and splits coordinates into a high + low part: for finite inputs that is bit-identical to
+// relu(x) = x > 0 ? x : 0, but a positive-signed NaN survives the integer max (the reference's relu maps NaN to 0) and an Inf / fp16
+// overflow in a coordinate difference makes the low part NaN.  rd_input_transform (k_input.h) produces finite values by
+// construction (missing returns are filled, ranges are clipped: rangedet/core/input.py ProcessMissValue / SepAndClipData); a caller
+// that feeds its own tensors must do the same.
 #pragma once
 #include "rd_common.h"
 

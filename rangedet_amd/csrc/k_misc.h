@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const float* __rest
     float* d = dets + (size_t)pos * 12;
 #pragma unroll
     for (int k = 0; k < 8; ++k) d[k] = b[k];
-    d[8] = atan2f(b[1] - b[3], b[0] - b[2]);  // yaw = arctan2(yA - yB, xA - xB)
+    d[8] = fdlibm_atan2f(b[1] - b[3], b[0] - b[2]);  // yaw = arctan2(yA - yB, xA - xB): numpy's float32 arctan2 = the C library's atan2f where numpy has no SIMD routine (rd_common.h)
     d[9] = b[8];
     d[10] = b[9] - b[8];
     d[11] = scores[i];

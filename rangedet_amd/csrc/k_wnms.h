@@ -37,7 +37,8 @@ constexpr int PREP_F = 26;  // floats per prepped box: 8 corners, 4 angles, area
 //   * both boxes are rectangles (1e-3 relative) with edges of 0.2 .. 25 m and |coordinates| <= 200 m       (w_box_domain)
 //   * their bounding rectangles are more than 0.01 m apart (then the polygons are disjoint, whatever the rounding)
 //   * their edge directions mod 90 degrees differ by at least 0.01 rad
-//   * thresh >= 1e-3 and thresh_vote >= 1e-3 (the launcher's condition; the largest value seen inside the domain is 9e-9)
+//   * thresh >= 1e-3 and thresh_vote >= 1e-3, BEV mode (the launcher's conditions; the largest reference value seen among skippable
+//     pairs is 4.2e-7; the 3-D value divides by a volume sum that was not part of the study, so is3d clips every pair)
 // Zero violations on the 8.1e9 pairs; every other pair is clipped as before.  oracle/ and the golden vectors know nothing of this.
 __device__ __forceinline__ void w_box_domain(const float* c, float* o) {   // c: the 8 corner floats of a dets row, as given
   RD_NOCONTRACT
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void wnms_prep_kernel(const float* __restrict_
     o[2 * k] = p[k].x;
     o[2 * k + 1] = p[k].y;
     int k1 = (k + 1) & 3;
-    o[8 + k] = atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);  // nms.h:71
+    o[8 + k] = fdlibm_atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);  // nms.h:71 (the C library's atan2f, rd_common.h)
   }
   float area = 0.f;
   area += w_cross3(p[0], p[1], p[2]);
@@ -1077,7 +1078,7 @@ __device__ __forceinline__ void w_prep_box(const float* b, float* o) {
     o[2 * k] = p[k].x;
     o[2 * k + 1] = p[k].y;
     int k1 = (k + 1) & 3;
-    o[8 + k] = atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);
+    o[8 + k] = fdlibm_atan2f(p[k1].y - p[k].y, p[k1].x - p[k].x);
   }
   float area = 0.f;
   area += w_cross3(p[0], p[1], p[2]);

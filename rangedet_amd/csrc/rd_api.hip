@@ -44,11 +44,12 @@ inline WnmsWs wnms_ws_carve(void* ws, int cap) {
   return w;
 }
 inline void allow_conv_lds() {   // the generic tap kernel (the persistent 3x3 kernel does this per instantiation, k_conv3.h c3_go)
-  static unsigned long long seen = 0;
-  if (!first_use_on_device(seen)) return;
-  allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_F16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_F16, 4, 8>);
-  allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>); allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
+  static std::atomic<unsigned long long> seen{0};
+  once_per_device(seen, [] {
+    allow_big_lds(conv_taps_kernel<RD_BF16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_BF16, 4, 8>);
+    allow_big_lds(conv_taps_kernel<RD_F16, 4, 3>); allow_big_lds(conv_taps_kernel<RD_F16, 4, 8>);
+    allow_big_lds(conv_taps_kernel<RD_F32, 4, 8>); allow_big_lds(conv_taps_kernel<RD_F32, 4, 3>);
+  });
 }
 }  // namespace rd
 
@@ -608,8 +609,8 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
   ProfScope ps(RD_PROF_META, st);
   if (is_h16(dtype)) {
     const size_t lds = meta_layout(dtype).wbytes + consts + (size_t)(WAVES + 2) * 34 * 128 + 4096;
-    static unsigned long long seen = 0;
-    if (first_use_on_device(seen)) { allow_big_lds(meta16_kernel<WAVES, RD_BF16>); allow_big_lds(meta16_kernel<WAVES, RD_F16>); }
+    static std::atomic<unsigned long long> seen{0};
+    once_per_device(seen, [] { allow_big_lds(meta16_kernel<WAVES, RD_BF16>); allow_big_lds(meta16_kernel<WAVES, RD_F16>); });
     const dim3 mgrid(std::min(a.ntiles, conv_num_cus())), mblock(WAVES * 64);
     const int strips = a.tiles_w * B;
     a.r0 = dev_switches().conv_xcd && strips % 8 == 0 ? 8 : strips;   // (MetaArgs::r0: XCD-aware tile order; a permutation for any grid)
@@ -764,8 +765,11 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const int ct = dev_switches().wnms_ct == 32 ? 32 : dev_switches().wnms_ct == 16 ? 16 : 8;   // columns per pair tile
   const int pgrid = std::min(2048, std::max(64, nb * (64 / ct) * std::min(nb, 16)));
   // the rejection test of the pair kernel (k_wnms.h w_pair_skippable) is only sound for thresholds far above the noise the
-  // reference's clipper returns on disjoint boxes (<= 9e-9 inside the test's domain); RD_WNMS_NO_SKIP: every pair clipped (A/B)
-  const int allow_skip = thresh >= 1e-3f && thresh_vote >= 1e-3f && !dev_switches().wnms_no_skip;
+  // reference's clipper returns on disjoint boxes (<= 4.2e-7 inside the test's domain, profiles/r04_nms_spurious_study.txt), and it
+  // was characterised on the BEV value only: in 3-D mode the reference divides the clipped area x height overlap by a volume sum
+  // that non-positive or cancelling heights can make arbitrarily small (nms.h:234-246), so there every pair is clipped.
+  // RD_WNMS_NO_SKIP: every pair clipped (A/B)
+  const int allow_skip = thresh >= 1e-3f && thresh_vote >= 1e-3f && !is3d && !dev_switches().wnms_no_skip;
   auto pairs = [&](const int* rows, const int* nrows, const unsigned long long* supp, int rb_end) {
     auto k = dev_switches().wnms_bal ? (ct == 8 ? wnms_pairs_kernel<8, true> : ct == 16 ? wnms_pairs_kernel<16, true> : wnms_pairs_kernel<32, true>)
                                      : (ct == 8 ? wnms_pairs_kernel<8, false> : ct == 16 ? wnms_pairs_kernel<16, false> : wnms_pairs_kernel<32, false>);

@@ -11,6 +11,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
 #include "../../include/rangedet_hip.h"
 
 namespace rd {
@@ -89,13 +90,18 @@ inline void allow_big_lds(K kernel) {
 }
 // The attribute is a property of the function ON A DEVICE: "once" means once per (kernel, device), so that a process which
 // launches on a second GPU raises the limit there too (one process per GPU never sees more than one bit set).
-inline bool first_use_on_device(unsigned long long& seen) {
+// once_per_device(seen, f): runs f() unless this device's bit is already set, and sets the bit only AFTER f() has returned -- two host
+// threads may both run f (the attribute call is idempotent), but none can see the bit and launch before some thread's call is
+// complete.  Devices >= 64 and a failing hipGetDevice are never cached (f runs every time).
+template <class F>
+inline void once_per_device(std::atomic<unsigned long long>& seen, F f) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (seen & bit) return false;
-  seen |= bit;
-  return true;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); f(); return; }
+  if (dev < 0 || dev >= 64) { f(); return; }
+  const unsigned long long bit = 1ull << dev;
+  if (seen.load(std::memory_order_acquire) & bit) return;
+  f();
+  seen.fetch_or(bit, std::memory_order_release);
 }
 
 // ---- per-kind event profiling ------------------------------------------------------------------------
@@ -275,6 +281,77 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_unifor
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 #endif
+}
+
+// ---- atan2f as the reference's host computes it ------------------------------------------------------------------------------------
+// The weighted NMS takes the polar angle of every box edge with atan2 on float arguments (operator_cxx/src_cxx/nms.h:71), i.e. the
+// C library's atan2f, and compares angles with a tolerance of 1e-5 (nms.h:58-64), so an ulp decides which half-plane survives a tie.
+// glibc 2.35 (the image's, and what the compiled reference under oracle/_ref links) ships the fdlibm float routines
+// (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c: argument reduction at 7/16, 11/16, 19/16, 39/16, an 11-term odd / even polynomial,
+// hi + lo table values) -- NOT a correctly rounded function: it differs from float(atan2(double)) on 15 % of box-edge inputs
+// (1e9 inputs, profiles/r05_atan2f_study.txt), so an fp64 evaluation rounded once would not reproduce it.  This is that published
+// algorithm restated operation by operation in float arithmetic without contraction; the same text compiled for the host is
+// bit-equal to glibc's atan2f on 2e9 inputs (box edges, random bit patterns incl. NaN / Inf / denormals, the reduction thresholds).
+// A reference built against another C library may differ from it in the last bit.
+__host__ __device__ inline float fdlibm_atanf(float x) {
+  _Pragma("clang fp contract(off)")
+  const float hi_[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float lo_[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float t0 = 3.3333334327e-01f, t1 = -2.0000000298e-01f, t2 = 1.4285714924e-01f, t3 = -1.1111110449e-01f, t4 = 9.0908870101e-02f,
+              t5 = -7.6918758452e-02f, t6 = 6.6610731184e-02f, t7 = -5.8335702866e-02f, t8 = 4.9768779427e-02f, t9 = -3.6531571299e-02f,
+              t10 = 1.6285819933e-02f;
+  const int hx = __builtin_bit_cast(int, x), ix = hx & 0x7fffffff;
+  int id;
+  if (ix >= 0x4c000000) {                      // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;         // NaN
+    return hx > 0 ? hi_[3] + lo_[3] : -hi_[3] - lo_[3];
+  }
+  if (ix < 0x3ee00000) {                       // |x| < 7/16
+    if (ix < 0x31000000) return x;             // |x| < 2^-29
+    id = -1;
+  } else {
+    x = __builtin_fabsf(x);
+    if (ix < 0x3f980000) {                     // |x| < 19/16
+      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+      else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+    } else {
+      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+      else { id = 3; x = -1.0f / x; }
+    }
+  }
+  const float z = x * x, w = z * z;
+  const float s1 = z * (t0 + w * (t2 + w * (t4 + w * (t6 + w * (t8 + w * t10)))));
+  const float s2 = w * (t1 + w * (t3 + w * (t5 + w * (t7 + w * t9))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float r = hi_[id] - ((x * (s1 + s2) - lo_[id]) - x);
+  return hx < 0 ? -r : r;
+}
+__host__ __device__ inline float fdlibm_atan2f(float y, float x) {
+  _Pragma("clang fp contract(off)")
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int hx = __builtin_bit_cast(int, x), ix = hx & 0x7fffffff;
+  const int hy = __builtin_bit_cast(int, y), iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;           // NaN
+  if (hx == 0x3f800000) return fdlibm_atanf(y);                   // x == 1
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);              // 2 * sign(x) + sign(y)
+  if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+    return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                          // |y / x| > 2^60
+  else if (hx < 0 && k < -60) z = 0.0f;                           // |y| / x < -2^60
+  else z = fdlibm_atanf(__builtin_fabsf(y / x));
+  switch (m) {
+    case 0: return z;
+    case 1: return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
 }
 
 }  // namespace rd

@@ -144,10 +144,11 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
     return annotation_dict, output_dict
 
 
-def merge_across_ranks(annotation_dict, output_dict):
-    """All ranks' (annotation_dict, output_dict) merged on every rank (keys are global record ids, disjoint across ranks)."""
+def merge_across_ranks(annotation_dict, output_dict, force=False):
+    """All ranks' (annotation_dict, output_dict) merged on every rank (keys are global record ids, disjoint across ranks).
+    force: run the collective with one rank too (RD_EVAL_GATHER)."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return annotation_dict, output_dict
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, (annotation_dict, output_dict))
@@ -192,7 +193,13 @@ def main(argv=None, _spawned=False):
         mp.spawn(_rank_main, args=(a.gpus, port, list(argv) if argv is not None else __import__("sys").argv[1:]), nprocs=a.gpus)
         return
     shard = None
-    if launched and int(os.environ["WORLD_SIZE"]) > 1:
+    # RD_EVAL_GATHER=1 (like bench.py's RD_BENCH_GATHER): take the multi-rank branch with ONE rank -- RCCL communicator on the GPU,
+    # sharding, the merge of the per-rank dictionaries through the collective -- so that the path runs on a one-GPU box
+    force = bool(os.environ.get("RD_EVAL_GATHER"))
+    if force and not launched:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        launched = True
+    if launched and (int(os.environ["WORLD_SIZE"]) > 1 or force):
         import torch
         from . import dist as rdist
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -218,12 +225,15 @@ def main(argv=None, _spawned=False):
     rank = shard.rank if shard else 0
     ann, out = run(roidb, params, batch=a.batch, wnms=not a.nms3d, shard=shard, loader_threads=a.loader_threads,
                    progress=(lambda d, n: print('%d of %d records' % (d, n), flush=True)) if rank == 0 else None)
-    ann, out = merge_across_ranks(ann, out)
+    ann, out = merge_across_ranks(ann, out, force=force)
     if rank == 0:
         with open(a.out, 'wb') as fw:
             pkl.dump(ann, fw)
             pkl.dump(out, fw)
         print('%d frames with detections of %d -> %s' % (len(out), len(roidb), a.out))
+        if shard is not None:
+            import torch.distributed as dist
+            print('merged over %d rank(s) through the %s communicator' % (dist.get_world_size(), dist.get_backend()))
         if a.bin_dir:
             from . import export
             export.main(a.out, a.config_name, a.bin_dir)

@@ -225,6 +225,15 @@ class Lowering:
 
     def step(self, kind, **kw):
         kw["kind"] = kind
+        # A "virtual concat" TRef (tail set: [feature map | variable], never written) describes ONE buffer's channels only; the single
+        # consumer that knows how to read both tensors is the 3x3 conv over a two-tensor input (x + x2, rd_conv3x3_bn_act_cat).  Any
+        # other step handed such a reference -- transposed conv, 1x1 conv, Meta-Kernel, residual, shortcut input, output conv --
+        # would silently read the feature map's channels alone, so it is refused here, once, for every step builder.
+        for key, v in kw.items():
+            if isinstance(v, TRef) and v.tail is not None and not (kind == "conv" and key == "x" and kw.get("x2") is v.tail and tuple(kw.get("k", ())) == (3, 3)):
+                raise NotImplementedError("%s step %r: operand %r is a virtual concat [%d channels | %d more from another tensor]; only a "
+                                          "3x3 stride-1 convolution can read it (set RD_CONCAT_BUFFER=1 for a materialised concat)" %
+                                          (kind, kw.get("name", ""), key, v.C, v.tail.C))
         self.plan.steps.append(kw)
 
     def want_input(self, name):
@@ -296,7 +305,9 @@ class Lowering:
         k, sw, Wout = self._conv_geom(conv, x)
         cout = conv.attrs["num_filter"]
         if cout not in (64, 128):
-            raise NotImplementedError("Convolution %s: %d output channels (kernels cover 64/128)" % (conv.name, cout))
+            raise NotImplementedError("Convolution %s: %d output channels.  The HIP conv kernels are instantiated for 64 and 128 output "
+                                      "channels only (the widths of the shipped configs: BackboneParam.num_filter = (64, 64, 128, 128, ...), "
+                                      "128-channel head towers); other dla_backbone.py num_filter values have no lowering" % (conv.name, cout))
         if x.tail is not None and (k != (3, 3) or sw != 1 or residual is not None or sc is not None or os.environ.get("RD_NO_FOLD")):
             raise NotImplementedError("Convolution %s reads a virtual concat: only 3x3 stride 1 without residual / shortcut" % conv.name)
         out = self._out(cout, x.H, Wout, dest)
@@ -480,13 +491,16 @@ class Lowering:
             raise NotImplementedError("meta kernel: coordinates must be one input variable")
         if (c0.attrs["num_filter"], c1.attrs["num_filter"], agg_conv.attrs["num_filter"]) != (32, 64, 64) or \
                 c0.attrs["no_bias"] or c1.attrs["no_bias"] or not agg_conv.attrs["no_bias"]:
-            raise NotImplementedError("meta kernel: only the shipped 3->32->64 (bias) MLP, 64 data channels, 576->64")
+            raise NotImplementedError("meta kernel %s: MLP %d -> %d, aggregation to %d channels.  The fused Meta-Kernel is built for the shipped "
+                                      "unit only: 3 -> 32 -> 64 MLP with biases (meta_kernel_units / fc channels of the reference config), "
+                                      "64 data channels, 9 x 64 = 576 -> 64 aggregation without bias" %
+                                      (agg_conv.name, c0.attrs["num_filter"], c1.attrs["num_filter"], agg_conv.attrs["num_filter"]))
         return dict(data=data, coord=coord.name, mlp0=c0.name, mlp1=c1.name, bn1=bn1.name, eps1=bn1.attrs["eps"])
 
     def _emit_meta(self, m, agg_conv, bn2, dest):
         x = self.emit_act(m["data"])
         if x.C != 64:
-            raise NotImplementedError("meta kernel: %d data channels" % x.C)
+            raise NotImplementedError("meta kernel %s: %d data channels (the fused Meta-Kernel is built for 64)" % (agg_conv.name, x.C))
         cshape = self.want_input(m["coord"])
         if cshape != (3, x.H, x.W):
             raise ValueError("meta kernel: coord shape %s vs data %s" % (cshape, (x.H, x.W)))

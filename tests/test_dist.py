@@ -164,3 +164,63 @@ def test_bench_world_mismatch_is_an_error_not_an_assert():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", RD_BENCH_DRYRUN="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def _json_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_rccl_gather_world1():
+    """The RCCL branch of bench.py on ONE GPU (RD_BENCH_GATHER=1): `init_process_group("nccl", device_id=...)`, the rank / device
+    report through the communicator, `all_gather_into_tensor` of the padded detections on the post-processing stream behind the NMS,
+    and the gathered records against what the rank put in and against the same run without the collective
+    (replaces the per-GPU result queue of tools/test.py:139-170)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RD_BENCH_GATHER")}
+    env["MASTER_PORT"] = str(_free_port())
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
+    plain = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    gath = subprocess.run(cmd, env=dict(env, RD_BENCH_GATHER="1"), capture_output=True, text=True, timeout=900)
+    assert gath.returncode == 0, gath.stderr[-2000:]
+    p, g = _json_line(plain.stdout), _json_line(gath.stdout)
+    pc, gc = p["config"], g["config"]
+    assert pc["rccl_version"] is None and pc["gathered_frames_last_step"] is None
+    assert gc["ranks_seen"] == [0] and gc["rccl_version"] and gc["gathered_frames_last_step"] == 8
+    assert gc["gather_matches_local"] is True                                  # the collective returned this rank's records bit for bit
+    assert gc["results_sha256_last_step"] == pc["results_sha256_last_step"]    # ... and the results are those of the run without it
+    assert gc["wnms_kept"] == pc["wnms_kept"] and gc["wnms_candidates"] == pc["wnms_candidates"]
+    for d in (p, g):                                                           # the spread fields of the report (SURVEY.md 8d)
+        assert d["repeats"] == 2 and len(d["region_ms"]) == 2 and d["steps"] == 3
+        assert d["ms_per_step_p5"] <= d["ms_per_step_p50"] <= d["ms_per_step_p95"]
+        assert d["value_min"] <= d["value"] <= d["value_max"]
+
+
+@pytest.mark.gpu
+def test_evaluate_rccl_merge_world1(tmp_path):
+    """`python -m rangedet_amd.evaluate` through its multi-rank branch with one rank (RD_EVAL_GATHER=1: nccl communicator bound to
+    the GPU, sharded record list, per-rank dictionaries merged through the collective) writes the same pickle as the plain run."""
+    import pickle
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RD_EVAL_GATHER")}
+    env["MASTER_PORT"] = str(_free_port())
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    outs = []
+    for tag, extra in (("plain", {}), ("rccl", {"RD_EVAL_GATHER": "1"})):
+        out = str(tmp_path / (tag + ".pkl"))
+        r = subprocess.run([sys.executable, "-m", "rangedet_amd.evaluate", "--synthetic", "3", "--random-weights", "--batch", "2", "--gpus", "1", "--out", out],
+                           env=dict(env, **extra), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("through the nccl communicator" in r.stdout) == (tag == "rccl"), r.stdout[-1000:]
+        with open(out, "rb") as f:
+            outs.append((pickle.load(f), pickle.load(f)))
+    (a0, o0), (a1, o1) = outs
+    assert sorted(o0) == sorted(o1) and len(o0) > 0 and sorted(a0) == sorted(a1)
+    for k in o0:
+        assert o0[k]["meta_info"] == o1[k]["meta_info"]
+        for c in o0[k]["det_xyzlwhyaws"]:
+            assert np.array_equal(o0[k]["det_xyzlwhyaws"][c], o1[k]["det_xyzlwhyaws"][c])

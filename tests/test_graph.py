@@ -81,6 +81,29 @@ def test_config_and_full_graph_lowering(monkeypatch):
     assert abs(macs / 1e9 - (557.07 - 9.64 - 20.89 - 0.35)) < 1.0  # SURVEY appendix A minus meta unit, deconvs, head 1x1
 
 
+def test_unsupported_widths_fail_at_lowering_with_the_supported_set():
+    """The reference's config surface lets BackboneParam.num_filter / meta_kernel_units vary (dla_backbone.py:59-103,130-161).  The symbol
+    mirror builds any of them; the HIP lowering is welded to the shipped widths and must say which ones instead of mis-computing."""
+    sym = cfgmod.get_config(False, backbone={'num_filter': {'res2': 96}})[6].test_symbol
+    with pytest.raises(NotImplementedError, match=r"96 output channels.*64 and 128"):
+        lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
+    mk = dict(stride=1, meta_func_param='meta_baseline_bias', data_channels=64, coord_channels=3, channel_list=[16, 64], kernel_size=3)
+    sym = cfgmod.get_config(False, backbone={'meta_kernel_units': {'res1_unit2': mk}})[6].test_symbol
+    with pytest.raises(NotImplementedError, match=r"MLP 16 -> 64.*3 -> 32 -> 64"):
+        lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
+    # a virtual concat ([agg3 | range image], never written) handed to anything but a 3x3 stride-1 conv is refused, not half-read
+    from rangedet_amd.lower import TRef, Lowering
+    lw = Lowering.__new__(Lowering)
+    from rangedet_amd.lower import Plan
+    lw.plan = Plan(R.RD_BF16, 1)
+    v = TRef(1, 64, 8, 32, 64, 0, None, TRef(2, 8, 8, 32, 16))
+    with pytest.raises(NotImplementedError, match="virtual concat"):
+        lw.step("deconv", name="d", x=v, out=TRef(3, 64, 8, 64, 64))
+    with pytest.raises(NotImplementedError, match="virtual concat"):
+        lw.step("conv", name="c", x=TRef(4, 64, 8, 32, 64), res=v, k=(3, 3), out=TRef(3, 64, 8, 32, 64))
+    lw.step("conv", name="c", x=v, x2=v.tail, k=(3, 3), out=TRef(3, 128, 8, 32, 128))
+
+
 def test_api_surface_matches_reference():
     from rangedet_amd.symbol.backbone.meta_kernel import MetaKernel
     from rangedet_amd.symbol.backbone.dla_backbone import DLABackbone, DLABackboneBuilder
@@ -530,12 +553,13 @@ def test_kitti_pipeline_two_class_fp16(be):
             assert got["keep_inds"].tolist() == list(keep), (c, b)
             if len(keep):
                 # merged rows: a kept box's voter set depends on IoUs whose clip compares edge angles from atan2f with |da| < 1e-5
-                # (nms.h:120-123); device atan2f and glibc's differ by an ulp, which at ~7000 candidates
-                # flips about one vote in a few thousand rows -- the survivors (above) are identical, a flipped row is not
+                # (nms.h:120-123).  Round 4: the device's own atan2f differed from glibc's by an ulp and flipped about one vote in a few
+                # thousand rows (0.5 % of the rows were exempt).  Round 5: the edge angles are the C library's algorithm restated on the
+                # device (rd_common.h fdlibm_atan2f) -- every row agrees; the tolerance left is the yaw column's atan2f in the score
+                # filter (numpy's arctan2 in the reference, tools/test.py:56-81: an SVML routine, neither glibc's nor the device's)
                 rowerr = np.abs(got["wnms_rows"] - rows).max(axis=1)
-                assert (rowerr < 1e-5).mean() >= 0.995, (c, b, int((rowerr >= 1e-5).sum()), len(rowerr))
-                ok = rowerr < 1e-5
-                assert np.abs(got["det_xyzlwhyaws"][ok] - d8[ok]).max() < 1e-4
+                assert (rowerr < 1e-5).all(), (c, b, int((rowerr >= 1e-5).sum()), len(rowerr))
+                assert np.abs(got["det_xyzlwhyaws"] - d8).max() < 1e-4
             seen += dets.shape[0]
     assert seen > 100, "the synthetic weights must produce candidates in at least one class"
     # the first class's result is also what single-class callers read

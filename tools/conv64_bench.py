@@ -1,7 +1,8 @@
 """The HBM-bound 64->64 3x3 layers through the PRODUCTION entry point (rd_conv3x3_bn_act_ex, folded scales, 8 x 30 tiles): us,
 TFLOP/s and TB/s of algorithmic bytes, with and without the residual.  Tuning aid; dev switches (RD_CONV_HB3, and RD_CONV3_DBG
 with a -DRD_CONV3_DEV build selected through RANGEDET_HIP_LIB) are read by the library.
-    [B=8] [WS=2656,1328] python tools/conv64_bench.py"""
+    [B=8] [WS=2656,1328] [C128=1] [RES=0|1|both] [ITER=30] python tools/conv64_bench.py
+(RES / ITER / WS select ONE launch class for a counter pass: tools/pmc_conv_classes.sh)"""
 import os
 import sys
 
@@ -19,7 +20,7 @@ st = torch.cuda.current_stream().cuda_stream
 DT = R.RD_F16 if os.environ.get("F16") else R.RD_BF16
 tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("RD_CONV_HB3", "RD_CONV3_DBG") if k in os.environ)
 for W in [int(v) for v in os.environ.get("WS", "2656,1328").split(",")]:
-    for cin, cout in ((64, 64), (128, 128)) if os.environ.get("C128") else ((64, 64),):
+    for cin, cout in {"1": ((64, 64), (128, 128)), "only": ((128, 128),)}.get(os.environ.get("C128", ""), ((64, 64),)):
         # several distinct buffers cycled so that no launch finds its input in the Infinity Cache by accident of the benchmark
         NB = 3
         xs = [torch.randn(B * H * W * cin, device="cuda").to(torch.float16 if DT == R.RD_F16 else torch.bfloat16) for _ in range(NB)]
@@ -28,7 +29,7 @@ for W in [int(v) for v in os.environ.get("WS", "2656,1328").split(",")]:
         w = torch.from_numpy(L.pack_conv3x3_ex(np.random.randn(cout, cin, 3, 3).astype(np.float32) * 0.05, 1, cin,
                                                fold_scale=np.ones(cout, np.float32), dtype=DT)).cuda()
         sh = torch.zeros(cout, device="cuda")
-        for res in (False, True):
+        for res in {"0": (False,), "1": (True,)}.get(os.environ.get("RES", "both"), (False, True)):
             fl = R.RD_RELU_POST | R.RD_SCALE_FOLDED | (R.RD_ADD if res else 0)
 
             def run(i):
@@ -39,7 +40,7 @@ for W in [int(v) for v in os.environ.get("WS", "2656,1328").split(",")]:
                 run(i)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 30
+            n = int(os.environ.get("ITER", "30"))
             e0.record()
             for i in range(n):
                 run(i)
