@@ -42,6 +42,8 @@ def conv_flops(plan, only_conv3=False):
     from rangedet_amd.lower import conv_steps
     fl, n = 0.0, 0
     for s, launches in conv_steps(plan.steps):   # (a "conv_pair" -- two tower convs in one launch -- counts as two convs, one launch)
+        if only_conv3 and bool(s.get("in_block")) != (only_conv3 == "block"):
+            continue                                 # (the two convs of a fused BasicBlock run in block64_stream_kernel: only_conv3="block")
         if s["kind"] == "conv" and (not only_conv3 or is_conv3(s)):
             fl += 2.0 * s["out"].H * s["out"].W * s["cin"] * s["cout"] * s["k"][0] * s["k"][1]
             if s.get("sc"):   # the block's 1x1 projection shortcut, accumulated in this launch's epilogue
@@ -60,6 +62,8 @@ def conv_bytes(plan, esz, only_conv3=False):
     from rangedet_amd.lower import conv_steps
     by = 0.0
     for s, _ in conv_steps(plan.steps):
+        if only_conv3 and bool(s.get("in_block")) != (only_conv3 == "block"):
+            continue
         if s["kind"] == "deconv" or (s["kind"] == "conv" and (not only_conv3 or is_conv3(s))):
             x, o = s["x"], s["out"]
             by += (x.H * x.W * s["cin"] + o.H * o.W * s["cout"]) * esz
@@ -444,7 +448,7 @@ def main(argv=None):
             gather_matches_local = gather_matches_local and M_ == len(lastf[b_]["wnms_rows"]) and np.array_equal(rows_.view(np.uint32), want_.view(np.uint32))
 
     # ---- per-kernel timing with HIP events on the launch stream, over a replay of the same steps ------------------
-    roof = meta_info = prof = backbone_info = None
+    roof = meta_info = prof = backbone_info = block_info = None
     if rank == 0:
         # the forwards of the timed steps back to back on ONE stream with nothing else on the GPU, then the post-processing of those
         # batches the same way: every kernel runs alone at a steady clock, which is what a `rocprofv3 --kernel-trace --stats` pass
@@ -475,7 +479,7 @@ def main(argv=None):
             e1.record()
         torch.cuda.synchronize(dev)
         fwd_ms = e0.elapsed_time(e1) / nprof
-        fwd_kinds = ("conv", "conv3", "meta", "head_out", "sort", "decode", "layout")
+        fwd_kinds = ("conv", "conv3", "block", "meta", "head_out", "sort", "decode", "layout")
         ev_fwd_ms = sum(prof[k][0] for k in fwd_kinds) / nprof
         scale = fwd_ms / ev_fwd_ms if ev_fwd_ms else 1.0
         prof = {k: ((v[0] * scale, v[1]) if k in fwd_kinds else v) for k, v in prof.items()}
@@ -486,7 +490,20 @@ def main(argv=None):
         avg_ms = ms / max(cnt, 1)
         achieved = (fl * Bf / nlaunch) / (avg_ms * 1e-3) / 1e12 if cnt else 0.0   # a launch covers the Bf frames of the batch
         fl_all, n_all = conv_flops(pipe.plan)
-        ms_all = prof["conv"][0] + prof["conv3"][0]
+        ms_all = prof["conv"][0] + prof["conv3"][0] + prof["block"][0]
+        # the fused BasicBlock launches (block64_stream_kernel, csrc/k_block.h): algorithmic FLOPs / bytes of the two convs each replaces
+        fl_b, n_b = conv_flops(pipe.plan, only_conv3="block")
+        ms_b, cnt_b = prof["block"]
+        block_info = None
+        if n_b:
+            avg_b = ms_b / max(cnt_b, 1)
+            by_b = conv_bytes(pipe.plan, 2 if bf else 4, only_conv3="block") * Bf / n_b
+            block_info = {"kernel": "block64_stream_kernel (conv1 + BN + ReLU + conv2 + BN + shortcut + ReLU of a 64-channel BasicBlock, the "
+                                    "intermediate tensor in LDS)", "launches_per_step": n_b, "avg_launch_ms": avg_b,
+                          "gflop_per_launch": fl_b * Bf / n_b / 1e9, "tflops_algorithmic": (fl_b * Bf / n_b) / (avg_b * 1e-3) / 1e12 if cnt_b else 0.0,
+                          "algorithmic_bytes_per_launch_unfused_model": by_b,
+                          "note": "FLOPs = those of the two 3x3 convs (+ 1x1 shortcut) the launch replaces; the kernel executes 1.25x that "
+                                  "(conv1 on the 10 x 34 halo of every 8 x 32 tile)"}
         roof = {"kernel": "conv3x3_stream_kernel (persistent 3x3 implicit-GEMM conv / transposed-conv phase + BN + ReLU + residual)" if bf
                 else "conv_taps_kernel (implicit-GEMM conv/deconv + BN + ReLU + residual)", "bound": "mfma",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS if bf else 157.3, "unit": "TFLOP/s",
@@ -568,7 +585,7 @@ def main(argv=None):
                        "cpus_per_rank": len(cpus) if cpus else None,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("self (mp.spawn)" if world > 1 else "single process")},
-            "roofline": roof, "meta_kernel": meta_info, "meta_dla_forward": backbone_info,
+            "roofline": roof, "block_kernel": block_info, "meta_kernel": meta_info, "meta_dla_forward": backbone_info,
             # the whole path against both roofs: algorithmic conv-family bytes / flops of a frame + the
             # Meta-Kernel's, over the measured wall time per frame (everything included: NMS, launches, side stream)
             "path_roofline": (lambda sec, gb, gf: {"ms_per_frame": sec * 1e3, "algorithmic_gb_per_frame": gb,

@@ -8,6 +8,7 @@
  *   rd_conv2d_bn_act          mx.sym.Convolution + BatchNorm (+ReLU, +residual)   mxnext/simple.py:123-158,
  *                             mxnext/complicate.py:26-45, dla_backbone.py:18-56, head/builder.py:221-240
  *   rd_conv3x3_bn_act_ex      BasicBlock conv2 (+ stride (1,2), + projection shortcut)   dla_backbone.py:18-56,139-143
+ *   rd_block64_bn_act         a whole 64-channel BasicBlock (conv1 + conv2 + shortcut) in one launch   dla_backbone.py:18-56
  *   rd_conv3x3_bn_act_pair,   the cls and the reg tower conv i of a head level in ONE launch (the last pair with the towers'
  *   rd_conv2d_bn_act_head_out_pair   1x1 output convs)                            head/builder.py:221-261
  *   rd_deconv2d_bn_act,       mx.sym.Deconvolution + BatchNorm + ReLU + add       mxnext/simple.py:545-580,
@@ -133,6 +134,20 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
                          const void* residual, int r_cstride, int r_coff, const void* sc_x, int sc_cstride, int sc_coff,
                          int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
                          int cout, int stride_w, int flags, int dtype, void* stream);
+/* A whole 64-channel BasicBlock (rangedet/symbol/backbone/dla_backbone.py:18-56: conv1 3x3 + BN + ReLU, conv2 3x3 + BN, + shortcut, ReLU;
+ * stride 1, 64 -> 64 -> 64) as ONE launch -- replaces the two rd_conv3x3_bn_act_ex calls of the block; the intermediate tensor is never
+ * written to HBM (it lives in LDS as conv2's halo image) and the results are BIT-IDENTICAL to the two calls.
+ *   sc_w_packed == NULL  identity shortcut (units 2.. of a stage):  y = relu(BN2(conv2(relu(BN1(conv1(x))))) + x)
+ *   sc_w_packed != NULL  projection shortcut (unit 1, dla_backbone.py:44-51): + BNs(conv1x1(x)) instead of + x; sc_w_packed =
+ *                        rd_pack_conv1x1_sc_host(64 -> 64, fold_scale = the shortcut BatchNorm's scale), shift2 = conv2's + the shortcut's.
+ * w_packed = rd_pack_block64_host (HOST): both 3x3 weights (64, 64, 3, 3) with their BatchNorm scales folded in; shift1 / shift2 (64)
+ * floats on the device.  x: [B][H][W][x_cstride] channels [x_coff, x_coff + 64), y likewise; 16-bit types only. */
+size_t rd_block64_packed_bytes(void);
+int rd_pack_block64_host(const float* w1_oihw_host, const float* fold_scale1_host, const float* w2_oihw_host,
+                         const float* fold_scale2_host, int dtype, void* packed_host);
+int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* shift1, const float* shift2,
+                      const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream);
+
 /* Last conv of a head tower (3x3, cout 128, BN + ReLU, RD_BF16 or RD_F16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
  * rpn_{cls,reg}_conv_3 + BN + ReLU, then rpn_cls_logit / rpn_reg_delta with bias): the 128-channel result is consumed in
  * the epilogue and never written.  out[b*out_batch_stride + (n_off + h*W + w)*nout + o], float32, like rd_head_out; nout <= 8.
@@ -379,7 +394,8 @@ int rd_input_transform(const float* range_image, const float* pc_vehicle_frame, 
 #define RD_PROF_WNMS 5
 #define RD_PROF_LAYOUT 6
 #define RD_PROF_CONV3 7 /* the persistent 3x3 stride-1 bf16 kernel (its launches are NOT counted in RD_PROF_CONV) */
-#define RD_PROF_NKINDS 8
+#define RD_PROF_BLOCK 8 /* the fused BasicBlock kernel (rd_block64_bn_act) */
+#define RD_PROF_NKINDS 9
 int rd_prof_enable(int on);
 int rd_prof_reset(void);
 /* synchronises the recorded events; total_ms / launches per kind */

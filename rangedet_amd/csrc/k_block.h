@@ -1,5 +1,6 @@
 // A whole 64-channel BasicBlock (dla_backbone.py:18-56 without projection shortcut, stride 1) as ONE persistent launch:
-//     t = relu(BN1(conv1_3x3(x)))        y = relu(BN2(conv2_3x3(t)) + x)
+//     t = relu(BN1(conv1_3x3(x)))        y = relu(BN2(conv2_3x3(t)) + x)                     (units 2.. of a stage)
+//                                        y = relu(BN2(conv2_3x3(t)) + BNs(conv_1x1(x)))      (SC: unit 1, projection shortcut :44-51)
 // The unfused pair (k_conv3.h, twice) moves 5.5 tile-sized passes through HBM per block (x with its halo, t written, t read back
 // with its halo, the residual x again, y); here t never leaves the CU: conv1 is evaluated on the 10 x 34 pixels conv2 needs for an
 // 8 x 32 output tile and its rounded result is written straight into LDS in the halo-image layout conv2 reads.  Price: conv1 runs
@@ -19,9 +20,9 @@
 //     The 16-byte slots of a pixel are XOR-swizzled with (flat position >> 2) & 3 -- conflict-free for any alignment of a fragment;
 //   * t is stored with the 34-pixel pitch and the by-column swizzle of the wide tile (k_conv3.h C3Cfg<.., WD>), pixels outside the
 //     image as ZERO (conv2's zero padding -- not conv1 evaluated on padding), so conv2's addressing is the production kernel's;
-//   * the software pipeline is cut at the two places where the fragment shape changes (after U1: 3 -> 2 fragments per wave, after
-//     the epilogue: 2 -> 3): the last step of U1 / U3 pre-reads nothing, and the first fragments of U2 / U0 are read after the
-//     intermediate write / the epilogue.  The other workgroup of the CU runs under these two bubbles.
+//   * the software pipeline is cut once per tile, after U1: t does not exist before every wave has written its part, so U1's last
+//     step pre-reads nothing and U2's first fragments are read after the intermediate write (the other workgroup of the CU runs
+//     under this bubble).  U3's last step pre-reads the NEXT tile's first conv1 fragments (3 instead of 2: the shape changes there).
 // Results are BIT-IDENTICAL to the two launches of conv3x3_stream_kernel: every accumulator sees the same MFMA sequence (shift,
 // then chunk 0 taps 0..8, chunk 1 taps 0..8, two k-steps each) on the same operands, and t is rounded once, like the stored tensor.
 #pragma once
@@ -32,7 +33,8 @@ namespace rd {
 struct BlockArgs {
   const bf16_t* x; int x_cs, x_co; long x_bs;      // block input = residual (64 channels)
   const unsigned char* w;                          // [conv1: pack_taps_frag(9, 64, 64) | conv2: the same | RD_CONV_TAIL zeros]
-  const float* shift1; const float* shift2;        // BatchNorm shifts (scales folded into the weights)
+  const float* shift1; const float* shift2;        // BatchNorm shifts (scales folded into the weights; SC: shift2 = conv2's + the shortcut's)
+  const unsigned char* scw;                        // SC: packed 1x1 shortcut weights, pack_sc_frag(64 -> 64) = [4 k-steps][2][64 lanes][8]
   bf16_t* y; int y_cs, y_co; long y_bs;
   const unsigned char* zero16;
   int H, W, B, ncol, nrow, ntiles, xcd;
@@ -61,7 +63,7 @@ constexpr int bk_younger(int g) {
   return ((u == 0 || u == 3) && s == 7 && n > cap) ? cap : n;
 }
 
-template <int DT>
+template <int DT, bool SC>
 __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   constexpr int R = BK_R, SLAB = BK_SLAB, RING = 2 * BK_BUF, NCT = 2;
@@ -207,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   }
   // One step (tap) of unit U_ (0..3), ordinal S_, with F pixel fragments per wave:
   //   block 0: MFMAs of k-step 0, the reads of (this step, k-step 1) interleaved 1:1;
-  //   block 1: MFMAs of k-step 1, first half with the reads of (next step, k-step 0) -- none when LAST_ (pipeline cut) --,
-  //            the step's barrier, then the second half with the step's DMA pieces.
+  //   block 1: MFMAs of k-step 1, first half with the reads of (next step, k-step 0) -- NF_ pixel fragments at stride NFS_: the next
+  //            step's shape (NF_ = 0: none, the pipeline is cut) --, the step's barrier, then the second half with the step's DMA pieces.
   // ACUR_ = address of this step's fragment 0 at k-step 0; ANEXT_ = the next step's.
-#define BK_STEP(F, FS, U_, S_, LAST_, ACUR_, ANEXT_)                                                               \
+#define BK_STEP(F, FS, U_, S_, NF_, NFS_, ACUR_, ANEXT_)                                                           \
   {                                                                                                                \
-    constexpr int NM_ = (F) * NCT, NR_ = (F) + NCT, G_ = 9 * (U_) + (S_);                                          \
+    constexpr int NM_ = (F) * NCT, NR_ = (F) + NCT, G_ = 9 * (U_) + (S_), NRN_ = (NF_) ? (NF_) + NCT : 0;          \
     constexpr int NH_ = bk_pieces(G_), NP_ = 1 + NH_, HF_ = bk_first_u(S_), YG_ = bk_younger(G_);                  \
     const int acur_ = (ACUR_) ^ 32;                                                                                \
     const int bcur_ = boff + rslot * SLAB;                                                                         \
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     }                                                                                                              \
     _Pragma("unroll") for (int n = 0; n < NM_ / 2; ++n) {                                                          \
       BK_MM(1, n)                                                                                                  \
-      if (!(LAST_) && n < NR_) BK_RD(F, FS, 0, n, anext_, bnext_, 0)                                               \
+      if (n < NRN_) BK_RD(NF_, NFS_, 0, n, anext_, bnext_, 0)                                                      \
     }                                                                                                              \
-    if (!(LAST_)) { _Pragma("unroll") for (int n = NM_ / 2; n < NR_; ++n) BK_RD(F, FS, 0, n, anext_, bnext_, 0) }  \
-    BK_SYNC(YG_, (LAST_) ? 0 : NR_)                                                                                \
+    { _Pragma("unroll") for (int n = NM_ / 2; n < NRN_; ++n) BK_RD(NF_, NFS_, 0, n, anext_, bnext_, 0) }           \
+    BK_SYNC(YG_, NRN_)                                                                                             \
     if (NH_ > 0 && (S_) == 0) halo_begin();                                                                        \
     _Pragma("unroll") for (int n = NM_ / 2; n < NM_; ++n) {                                                        \
       BK_MM(1, n)                                                                                                  \
@@ -243,14 +245,16 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     rslot = rnext_;                                                                                                \
   }
   // conv1 step: unit U_ (0 or 1) reads x chunk U_ from buffer U_; tap S_; the next step is tap S_ + 1 of the same buffer, or tap 0 of
-  // buffer 1 after U0's last step
+  // buffer 1 after U0's last step; U1's last step pre-reads nothing (t does not exist yet)
 #define BK_C1(U_, S_)                                                                                              \
-  BK_STEP(3, 2048, U_, S_, ((U_) == 1 && (S_) == 8), a1[(S_) / 3][(S_) % 3] + (U_) * BK_BUF,                       \
+  BK_STEP(3, 2048, U_, S_, (((U_) == 1 && (S_) == 8) ? 0 : 3), 2048, a1[(S_) / 3][(S_) % 3] + (U_) * BK_BUF,       \
           ((S_) == 8 ? a1[0][0] + BK_BUF : a1[(((S_) + 1) % 9) / 3][((S_) + 1) % 3] + (U_) * BK_BUF))
-  // conv2 step: unit 2 + C_ reads t chunk C_ from buffer C_
+  // conv2 step: unit 2 + C_ reads t chunk C_ from buffer C_; U3's last step pre-reads the first fragments of the NEXT tile's conv1
+  // (x chunk 0 in buffer 0 has landed: the wait of U3's ordinal 7 covered it), so only the cut after U1 leaves a bubble
 #define BK_C2(C_, S_)                                                                                              \
-  BK_STEP(2, ROWB2, 2 + (C_), S_, ((C_) == 1 && (S_) == 8), a2[(S_) % 3] + ((S_) / 3) * ROWB2 + (C_) * BK_BUF,     \
-          ((S_) == 8 ? a2[0] + BK_BUF : a2[((S_) + 1) % 3] + ((((S_) + 1) % 9) / 3) * ROWB2 + (C_) * BK_BUF))
+  BK_STEP(2, ROWB2, 2 + (C_), S_, (((C_) == 1 && (S_) == 8) ? 3 : 2), (((C_) == 1 && (S_) == 8) ? 2048 : ROWB2),   \
+          a2[(S_) % 3] + ((S_) / 3) * ROWB2 + (C_) * BK_BUF,                                                       \
+          ((S_) == 8 ? ((C_) == 1 ? a1[0][0] : a2[0] + BK_BUF) : a2[((S_) + 1) % 3] + ((((S_) + 1) % 9) / 3) * ROWB2 + (C_) * BK_BUF))
 
   // ---- prologue: x chunk 0 of the first tile, a full ring ----------------------------------------------------------------------------
   halo_begin();
@@ -260,6 +264,8 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   for (int s0 = 0; s0 < R; ++s0) { slab_piece(); slab_advance(); }
   BK_SYNC(0, 0)
   int rslot = 0;
+#pragma unroll
+  for (int kk = 0; kk < 3 + NCT; ++kk) BK_RD(3, 2048, 0, kk, a1[0][0], boff + rslot * SLAB, 0)      // first fragments of the first tile
 
   for (int k = 0; k < ntl; ++k) {
     unsigned z0 = 0u;
@@ -279,8 +285,6 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
       acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
     }
     BK_FENCE();
-#pragma unroll
-    for (int kk = 0; kk < 3 + NCT; ++kk) BK_RD(3, 2048, 0, kk, a1[0][0], boff + rslot * SLAB, 0)
     BK_C1(0, 0) BK_C1(0, 1) BK_C1(0, 2) BK_C1(0, 3) BK_C1(0, 4) BK_C1(0, 5) BK_C1(0, 6) BK_C1(0, 7) BK_C1(0, 8)
     BK_C1(1, 0) BK_C1(1, 1) BK_C1(1, 2) BK_C1(1, 3) BK_C1(1, 4) BK_C1(1, 5) BK_C1(1, 6) BK_C1(1, 7) BK_C1(1, 8)
 
@@ -342,6 +346,31 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
       unsigned char* scr = smem + BK_BUF + wave * (BK_BUF / 4);       // 7 KB >= 32 pixels x 128 B
       bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.W * a.y_cs + a.y_co;
       const bf16_t* __restrict__ rimg0 = a.x + (size_t)b * a.x_bs + a.x_co;
+      if constexpr (SC) {
+        // projection shortcut (k_conv3.h SC): acc[px][co] += sum_ci scw[co][ci] * x[px][ci] on the conv's own accumulators -- B operand =
+        // this wave's output pixels of x straight from global memory (L2: the tile's x was fetched moments ago), A = the packed 1x1
+        // weights; four 16-channel k-steps in the unfused launch's order
+        const bf16_t* __restrict__ sb = a.x + (size_t)b * a.x_bs + a.x_co + 8 * ehi;
+        const unsigned char* __restrict__ wq = a.scw + el * 16;
+        s16x8 sxq[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ow = ct * 32 + em, oh = oh0 + i;
+          const bool live = ow < a.W && oh < a.H;
+          const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.x_cs : 0);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) sxq[i][ks] = *(const s16x8*)(sp + 16 * ks);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < NCT; ++j) {
+            const s16x8 wf = *(const s16x8*)(wq + (size_t)(ks * NCT + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = H16<DT>::mfma(wf, sxq[i][ks], acc[i][j]);
+          }
+        BK_FENCE();
+      }
       Slot16 rv[2][NCT][2];
       auto res_load = [&](int i, Slot16 (&dst)[NCT][2]) {
         const int ow = ct * 32 + em, oh = oh0 + i;
@@ -353,10 +382,10 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
           dst[j][1] = *(const Slot16*)(rp + j * 32 + 8);
         }
       };
-      res_load(0, rv[0]);
+      if constexpr (!SC) res_load(0, rv[0]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        if (i + 1 < 2) res_load(i + 1, rv[(i + 1) & 1]);
+        if constexpr (!SC) { if (i + 1 < 2) res_load(i + 1, rv[(i + 1) & 1]); }
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
           BK_FENCE();
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             f32x2 v = {acc[i][j][2 * q], acc[i][j][2 * q + 1]};
-            v += H16<DT>::unpk(rv[i & 1][j][q >> 2][q & 3]);
+            if constexpr (!SC) v += H16<DT>::unpk(rv[i & 1][j][q >> 2][q & 3]);
             unsigned p2 = H16<DT>::pk(v[0], v[1]);
             pk[q] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
           }
@@ -412,27 +441,31 @@ inline void pack_block64(const float* w1, const float* s1, const float* w2, cons
   }
 }
 
-inline int launch_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, void* y, int y_cs,
-                          int y_co, int B, int H, int W, int dt, hipStream_t st) {
+inline int launch_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, const void* sc_w,
+                          void* y, int y_cs, int y_co, int B, int H, int W, int dt, hipStream_t st) {
   RD_REQUIRE(is_h16(dt), RD_EINVAL, "block64: dtype %d (RD_BF16 or RD_F16)", dt);
   BlockArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
-  a.w = (const unsigned char*)w; a.shift1 = shift1; a.shift2 = shift2;
+  a.w = (const unsigned char*)w; a.shift1 = shift1; a.shift2 = shift2; a.scw = (const unsigned char*)sc_w;
   a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * W * y_cs;
   a.zero16 = (const unsigned char*)w + BK_WBYTES;
   a.H = H; a.W = W; a.B = B;
   a.ncol = (W + 31) / 32; a.nrow = (H + 7) / 8; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus() * 2);
   a.xcd = dev_switches().conv_xcd && (a.ncol * B) % 8 == 0 && grid % 8 == 0;
-  ProfScope ps(RD_PROF_CONV3, st);
+  ProfScope ps(RD_PROF_BLOCK, st);
   static std::atomic<unsigned long long> seen{0};
+  once_per_device(seen, [] {
+    allow_big_lds(block64_stream_kernel<RD_F16, false>); allow_big_lds(block64_stream_kernel<RD_BF16, false>);
+    allow_big_lds(block64_stream_kernel<RD_F16, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true>);
+  });
   if (dt == RD_F16) {
-    once_per_device(seen, [] { allow_big_lds(block64_stream_kernel<RD_F16>); allow_big_lds(block64_stream_kernel<RD_BF16>); });
-    hipLaunchKernelGGL(block64_stream_kernel<RD_F16>, dim3(grid), dim3(256), BK_LDS, st, a);
+    if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<RD_F16, true>), dim3(grid), dim3(256), BK_LDS, st, a);
+    else hipLaunchKernelGGL((block64_stream_kernel<RD_F16, false>), dim3(grid), dim3(256), BK_LDS, st, a);
   } else {
-    once_per_device(seen, [] { allow_big_lds(block64_stream_kernel<RD_F16>); allow_big_lds(block64_stream_kernel<RD_BF16>); });
-    hipLaunchKernelGGL(block64_stream_kernel<RD_BF16>, dim3(grid), dim3(256), BK_LDS, st, a);
+    if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<RD_BF16, true>), dim3(grid), dim3(256), BK_LDS, st, a);
+    else hipLaunchKernelGGL((block64_stream_kernel<RD_BF16, false>), dim3(grid), dim3(256), BK_LDS, st, a);
   }
   return check_launch("block64_stream_kernel");
 }

@@ -16,7 +16,7 @@ H16 = (RD_BF16, RD_F16)     # the two 16-bit element types (same layouts)
 RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED = 1, 2, 4, 8
 RD_WNMS_MAX_K = 65536
 RD_TIE_STABLE, RD_TIE_REFERENCE = 0, 1
-PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7}
+PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7, "block": 8}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RANGEDET_HIP_LIB: another build of the same library (A/B timing of two builds on one box); never a CPU substitute
@@ -61,6 +61,10 @@ SIGNATURES = {
     "rd_deconv2d_bn_act_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
+    "rd_block64_packed_bytes": (c_size_t, []),
+    "rd_pack_block64_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rd_block64_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -196,6 +200,15 @@ class Lib:
         fs = None if fold_scale is None else np.ascontiguousarray(fold_scale, dtype=np.float32)
         out = np.zeros(self.cdll.rd_conv1x1_sc_packed_bytes(cin, cout), dtype=np.uint8)
         self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, dtype, out.ctypes.data)
+        return out
+
+    def pack_block64(self, w1_oihw, scale1, w2_oihw, scale2, dtype=RD_BF16):
+        """weights of rd_block64_bn_act: the two (64, 64, 3, 3) convs of a BasicBlock with their BatchNorm scales folded in"""
+        w1, w2 = (np.ascontiguousarray(w, dtype=np.float32) for w in (w1_oihw, w2_oihw))
+        s1, s2 = (np.ascontiguousarray(v, dtype=np.float32) for v in (scale1, scale2))
+        assert w1.shape == (64, 64, 3, 3) and w2.shape == (64, 64, 3, 3) and s1.shape == (64,) and s2.shape == (64,)
+        out = np.zeros(self.cdll.rd_block64_packed_bytes(), dtype=np.uint8)
+        self.call("rd_pack_block64_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, dtype, out.ctypes.data)
         return out
 
     def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype, fold_scale=None):

@@ -58,10 +58,11 @@ class Plan:
 
 def conv_steps(steps):
     """The conv / deconv steps of a plan one by one: the two members of a "conv_pair" (one launch) as two entries.
+    Likewise the two convs of a fused BasicBlock ("block").
     Yields (step, launches): launches = what the step adds to the launch count (1, 0.5 + 0.5 for a pair; a transposed conv: 1 when
     all its phases run in one launch, else stride_w)."""
     for st in steps:
-        if st["kind"] == "conv_pair":
+        if st["kind"] in ("conv_pair", "block"):   # (a fused BasicBlock: its two convs, one launch)
             yield st["a"], 0.5
             yield st["b"], 0.5
         elif st["kind"] == "conv":
@@ -98,6 +99,7 @@ class Lowering:
         for out in group.inputs:
             self.plan.outputs.append(self.emit_value(out))
         self._fuse_head_out()
+        self._fuse_blocks()
         self._pair_equal_convs()
 
     # ---- fusion ------------------------------------------------------------------------------------------------
@@ -169,6 +171,49 @@ class Lowering:
                     if is_write(k2):
                         written[r.buf] = len(out)
             out.append(st)
+        self.plan.steps = out
+
+    def _fuse_blocks(self):
+        """16-bit: a 64-channel BasicBlock at stride 1 (dla_backbone.py:18-56: conv1 3x3 + BN + ReLU -> conv2 3x3 + BN, + shortcut, ReLU)
+        whose intermediate tensor has no other reader runs as ONE launch (rd_block64_bn_act, csrc/k_block.h): conv1's result stays in
+        LDS as conv2's halo image.  Both shortcut forms: identity (residual = the block input) and the fused 1x1 projection of the
+        block input.  Plan step kind "block": a / b = the two conv steps as they were (bit-identical results).
+        RD_NO_FUSE_BLOCK=1 keeps the two launches (A/B runs)."""
+        if not self.h16 or os.environ.get("RD_NO_FUSE_BLOCK"):
+            return
+        steps = self.plan.steps
+        uses = {}
+        for i, st in enumerate(steps):
+            for key, v in st.items():
+                if isinstance(v, TRef):
+                    uses.setdefault(v.buf, []).append((i, key))
+
+        def plain64(st):
+            return (st["kind"] == "conv" and tuple(st["k"]) == (3, 3) and st["stride_w"] == 1 and st["cin"] == 64 and st["cout"] == 64 and
+                    st.get("ex") and st.get("fold") and not st.get("head") and st.get("x2") is None and not st.get("cmap") and
+                    st["x"].C == 64 and st["x"].tail is None)
+
+        out, i = [], 0
+        while i < len(steps):
+            a = steps[i]
+            b = steps[i + 1] if i + 1 < len(steps) else None
+            ok = b is not None and plain64(a) and plain64(b) and a["flags"] == RD_RELU_POST and a["res"] is None and not a.get("sc") and \
+                b["flags"] == (RD_ADD | RD_RELU_POST) and b["x"] == a["out"] and a["out"].co == 0 and a["out"].cs == 64 and \
+                sorted(uses.get(a["out"].buf, [])) == [(i, "out"), (i + 1, "x")] and b["out"].buf != a["x"].buf
+            if ok:
+                if b.get("sc"):      # projection shortcut of the block input (64 channels, no channel map)
+                    ok = b["res"] is None and b["sc_x"] == a["x"] and b["sc"]["cin"] == 64 and not b["sc"].get("cmap")
+                else:                # identity shortcut: the residual IS the block input
+                    ok = b["res"] == a["x"]
+            if ok:
+                blk = dict(kind="block", name=a["name"] + " + " + b["name"], a=a, b=b, x=a["x"], out=b["out"])
+                a["in_block"] = b["in_block"] = True
+                self.plan.buffers.pop(a["out"].buf, None)      # the intermediate tensor no longer exists
+                out.append(blk)
+                i += 2
+            else:
+                out.append(a)
+                i += 1
         self.plan.steps = out
 
     def _fuse_head_out(self):

@@ -38,15 +38,26 @@ def test_config_and_full_graph_lowering(monkeypatch):
     # 63 backbone conv/deconv - 4 deconv - 1 aggregation conv (inside the fused Meta unit) + 24 head tower convs
     # bf16: the six 1x1 output convs ride in the epilogue of their tower's last conv (lower._fuse_head_out) and the nine
     # 1x1 projection shortcuts in the epilogue of their block's second conv (lower._fusable_projection)
-    assert kinds["conv"] == 73 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
+    # round 5: the seven 64-channel stride-1 BasicBlocks whose intermediate tensor has one reader are ONE launch each (lower._fuse_blocks,
+    # rd_block64_bn_act): 73 convs = 59 launches + 7 blocks of two
+    assert kinds["conv"] == 59 and kinds["block"] == 7 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
+    assert [s["name"] for s in plan.steps if s["kind"] == "block"] == [n + "_conv1 + " + n + "_conv2" for n in (
+        "res2a_unit2", "res2a_unit3", "agg2a_res_unit1", "agg1_res_unit1", "agg1_res_unit2", "agg3_res_unit1", "agg3_res_unit2")]
+    assert [bool(s["b"].get("sc")) for s in plan.steps if s["kind"] == "block"] == [False, False, True, True, False, True, False]
+    inter = {s["a"]["out"].buf for s in plan.steps if s["kind"] == "block"}
+    assert not inter & set(plan.buffers), "the intermediate tensor of a fused block has no buffer"
+    monkeypatch.setenv("RD_NO_FUSE_BLOCK", "1")
+    assert Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_BF16, 1).steps)["conv"] == 73
+    monkeypatch.delenv("RD_NO_FUSE_BLOCK")
     convs = [s for s, _ in conv_steps(plan.steps) if s["kind"] == "conv"]
+    assert len(convs) == 73
     # RD_PAIR=1 (opt-in): the cls and the reg tower conv i of a level are ONE launch (lower._pair_equal_convs): 24 tower convs = 12
     # pairs, each pair at the place of its cls conv, nothing else moves
     monkeypatch.setenv("RD_PAIR", "1")
     pplan = lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
     monkeypatch.delenv("RD_PAIR")
     pk = Counter(s["kind"] for s in pplan.steps)
-    assert pk["conv"] == 49 and pk["conv_pair"] == 12 and pk["deconv"] == 4 and pk["meta"] == 1
+    assert pk["conv"] == 35 and pk["block"] == 7 and pk["conv_pair"] == 12 and pk["deconv"] == 4 and pk["meta"] == 1
     for s in pplan.steps:
         if s["kind"] == "conv_pair":
             na, nb = s["a"]["name"], s["b"]["name"]
@@ -55,12 +66,12 @@ def test_config_and_full_graph_lowering(monkeypatch):
     assert order[:4] == ["rpn_cls_conv_%d_lvl_0 + rpn_reg_conv_%d_lvl_0" % (i, i) for i in range(4)]
     assert sorted(s["name"] for s, _ in conv_steps(pplan.steps)) == sorted(s["name"] for s, _ in conv_steps(plan.steps))
     # (launch counts: a transposed conv is ONE launch -- all its phases, rd_deconv2d_bn_act_all)
-    assert sum(n for _, n in conv_steps(pplan.steps)) == 49 + 12 + 4 and sum(n for _, n in conv_steps(plan.steps)) == 73 + 4
+    assert sum(n for _, n in conv_steps(pplan.steps)) == 35 + 7 + 12 + 4 and sum(n for _, n in conv_steps(plan.steps)) == 59 + 7 + 4
     assert all(s["one_launch"] for s in plan.steps if s["kind"] == "deconv")
-    scs = [s for s in plan.steps if s.get("sc")]
+    scs = [s for s, _ in conv_steps(plan.steps) if s.get("sc")]
     assert sorted(s["sc"]["name"] for s in scs) == sorted(n + "_unit1_sc" for n in (
         "res1", "res2a", "res2", "res3a", "res3", "agg2_res", "agg2a_res", "agg1_res", "agg3_res"))
-    assert sorted(s["name"] for s in plan.steps if s["kind"] == "conv" and s["stride_w"] == 2) == \
+    assert sorted(s["name"] for s, _ in conv_steps(plan.steps) if s["kind"] == "conv" and s["stride_w"] == 2) == \
         ["res2_unit1_conv2", "res2a_unit1_conv2", "res3_unit1_conv2", "res3a_unit1_conv2"]
     assert all(s["ex"] for s in plan.steps if s["kind"] == "conv" and s["stride_w"] == 2)
     f32_kinds = Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_F32, 1).steps)
@@ -692,7 +703,8 @@ def test_e2e_bf16_tolerance(be, dt, monkeypatch):
     plan = lower(sym, small_shapes(H, W), dt, 1)
     # (the reduced graph's one-layer towers read the never-materialised concat [agg3 | range image] directly at level 0: that two-tensor
     #  launch has no fused output conv, the level's two 1x1 output convs stay separate launches there)
-    assert sum(1 for s in plan.steps if s.get("sc")) == 9 and sum(1 for s, _ in conv_steps(plan.steps) if s.get("head")) == (4 if emu else 6)
+    assert sum(1 for s, _ in conv_steps(plan.steps) if s.get("sc")) == 9 and sum(1 for s, _ in conv_steps(plan.steps) if s.get("head")) == (4 if emu else 6)
+    assert sum(1 for s in plan.steps if s["kind"] == "block") == (3 if emu else 7)      # fused BasicBlocks (lower._fuse_blocks) run in both graphs
     assert sum(1 for s in plan.steps if s.get("x2") is not None) == 2 and sum(1 for s in plan.steps if s["kind"] == "nchw_in") == 1
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
     fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)

@@ -711,6 +711,57 @@ def test_conv3x3_cat_two_tensor_input(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("case", [(BF16, 2, 16, 72, False, 64), (BF16, 1, 11, 33, True, 64), (F16, 1, 8, 100, False, 80), (BF16, 3, 24, 64, True, 80),
+                                  (F16, 2, 9, 40, True, 64)], ids=lambda c: "-".join(str(v) for v in c))
+def test_block64_equals_the_two_launches(be, case):
+    """rd_block64_bn_act (csrc/k_block.h): a 64-channel BasicBlock -- conv1 3x3 + BN + ReLU, conv2 3x3 + BN, + identity or 1x1 projection
+    shortcut, ReLU (dla_backbone.py:18-56) -- as ONE launch whose intermediate tensor stays in LDS.  BIT-IDENTICAL to the two
+    rd_conv3x3_bn_act_ex launches it replaces (same MFMA sequence per accumulator, the intermediate rounded once like the stored
+    tensor), and within one rounding per conv of torch on the same 16-bit weights.  Partial tiles in both directions, several tiles per
+    workgroup (the x prefetch of the next tile into the buffer the intermediate just left), both shortcut forms, both 16-bit types, an
+    input with a channel stride beyond its 64 channels."""
+    dt, B, H, W, proj, xcs = case
+    rng = np.random.default_rng(B * 100 + H + W)
+    L = be.lib
+    x = h16_round(rng.standard_normal((B, 64, H, W)).astype(np.float32), dt)
+    w1, w2 = ((rng.standard_normal((64, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32) for _ in range(2))
+    wsc = (rng.standard_normal((64, 64)) / 8).astype(np.float32)
+    s1, s2, ss = (rng.uniform(0.5, 1.5, 64).astype(np.float32) for _ in range(3))
+    t1, t2, ts = (rng.standard_normal(64).astype(np.float32) * 0.3 for _ in range(3))
+    sh2 = (t2.astype(np.float64) + ts).astype(np.float32) if proj else t2
+    dx = be.up(to_nhwc(x, dt, cstride=xcs))
+    p1, p2 = be.up(L.pack_conv3x3_ex(w1, 1, xcs, fold_scale=s1, dtype=dt)), be.up(L.pack_conv3x3_ex(w2, 1, 64, fold_scale=s2, dtype=dt))
+    psc = be.up(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt)) if proj else None
+    d1, d2 = be.up(t1), be.up(sh2)
+    t, yr, y = be.empty(B * H * W * 64 * 2), be.empty(B * H * W * 64 * 2), be.empty(B * H * W * 64 * 2)
+    FO = R.RD_SCALE_FOLDED
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(dx), xcs, 0, be.ptr(p1), None, be.ptr(d1), None, 0, 0, None, 0, 0, 0, None, be.ptr(t), 64, 0, B, H, W, 64, 64, 1,
+           R.RD_RELU_POST | FO, dt, be.stream)
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(t), 64, 0, be.ptr(p2), None, be.ptr(d2), None if proj else be.ptr(dx), 0 if proj else xcs, 0,
+           be.ptr(dx) if proj else None, xcs if proj else 0, 0, 64 if proj else 0, be.ptr(psc) if proj else None, be.ptr(yr), 64, 0, B, H, W, 64, 64, 1,
+           R.RD_ADD | R.RD_RELU_POST | FO, dt, be.stream)
+    pk = be.up(L.pack_block64(w1, s1, w2, s2, dtype=dt))
+    L.call("rd_block64_bn_act", be.ptr(dx), xcs, 0, be.ptr(pk), be.ptr(d1), be.ptr(d2), be.ptr(psc) if proj else None, be.ptr(y), 64, 0, B, H, W, dt, be.stream)
+    got, two = be.down(y, np.uint16, (B, H, W, 64)), be.down(yr, np.uint16, (B, H, W, 64))
+    assert np.array_equal(got, two), int((got != two).sum())
+    # ... and the pair itself against torch, conv by conv on the device's own intermediate (one output rounding each)
+    tq = from_nhwc(be.down(t, np.uint16, (B, H, W, 64)), dt, 64)
+    w1q, w2q = h16_round(w1 * s1[:, None, None, None], dt), h16_round(w2 * s2[:, None, None, None], dt)
+    r1 = np.maximum(F.conv2d(torch.from_numpy(x), torch.from_numpy(w1q), padding=1).numpy() + t1[None, :, None, None], 0)
+    assert np.abs(tq - r1).max() <= _tol(dt, r1)
+    r2 = F.conv2d(torch.from_numpy(tq), torch.from_numpy(w2q), padding=1).numpy() + sh2[None, :, None, None]
+    r2 = r2 + (F.conv2d(torch.from_numpy(x), torch.from_numpy(h16_round(wsc * ss[:, None], dt))[:, :, None, None]).numpy() if proj else x)
+    r2 = np.maximum(r2, 0)
+    assert np.abs(from_nhwc(got, dt, 64) - r2).max() <= 1.5 * _tol(dt, r2)
+    f = L.raw("rd_block64_bn_act")
+    p = be.ptr(be.empty(1 << 16))
+    assert f(p, 64, 0, p, p, p, None, p, 64, 0, 1, 4, 8, R.RD_F32, be.stream) == R.RD_EINVAL             # 16-bit types only
+    assert f(p, 64, 8, p, p, p, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                   # 64 channels do not fit the stride
+    q = be.ptr(be.empty(1 << 16))
+    assert f(p, 64, 0, q, q, q, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                   # in place
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_conv3x3_ex_errors(be):
     L = be.lib
     p = be.ptr(be.empty(1 << 16))

@@ -9,7 +9,9 @@ fused tower output convs on both tile shapes and the Meta-Kernel's register pref
 TIME: the step's actual device inputs are read back (exact: they are 16-bit values), the layer is recomputed by PyTorch-CPU in
 fp32 from those inputs and the SAME 16-bit weights the packer makes (folded BatchNorm scale, dla_backbone.py:18-56,117-127;
 mxnext/complicate.py:26-45), and the device output must agree PER ELEMENT to one rounding of the output type
-(|got - ref| <= 2^-8 |ref| for bf16, 2^-11 for fp16, plus fp32 summation-order noise).  The Meta-Kernel step is checked
+(|got - ref| <= 2^-8 |ref| for bf16, 2^-11 for fp16, plus fp32 summation-order noise).  A fused BasicBlock (round 5,
+rd_block64_bn_act) must be BIT-IDENTICAL to the two launches it replaces, which are replayed on scratch buffers and checked per
+element like every other conv (conv2 on the device's own intermediate).  The Meta-Kernel step is checked
 against oracle/graph_ref.meta_kernel_unit (meta_kernel.py:166-240) with test_meta_kernel_unit's error model.
 """
 import time
@@ -148,6 +150,66 @@ def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
     seen_forms = set()
     for i, st in enumerate(plan.steps):
         k = st["kind"]
+        if k == "block":
+            # A fused BasicBlock (rd_block64_bn_act, round 5).  Its bound is "two roundings" only in the sense that the intermediate tensor is
+            # rounded like the stored one: the launch must be BIT-IDENTICAL to the two launches it replaces, and those two are checked per
+            # element to one output rounding each -- conv1 against torch on the block input, conv2 (+ shortcut) on the DEVICE's own
+            # intermediate -- so no tolerance is widened for the fused form.
+            a_, b_ = st["a"], st["b"]
+            xr, orf = st["x"], st["out"]
+            x = host.get(xr)
+            exe.forward(fr, only=i, dev=dev)
+            host.invalidate(orf)
+            got = host.get(orf, fresh=True)
+            L_, A_ = be.lib, be.alloc
+            (s1, t1), (s2, t2) = bn_affine(P, a_["bn"], a_["eps"]), bn_affine(P, b_["bn"], b_["eps"])
+            w1, w2 = (np.asarray(P[c_["name"] + "_weight"], np.float32) for c_ in (a_, b_))
+            p1 = A_.upload(L_.pack_conv3x3_ex(w1, 1, xr.cs, fold_scale=s1, dtype=dt))
+            p2 = A_.upload(L_.pack_conv3x3_ex(w2, 1, 64, fold_scale=s2, dtype=dt))
+            shift2 = t2.astype(np.float64)
+            psc = None
+            if b_.get("sc"):
+                sc = b_["sc"]
+                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(64, -1)
+                ss, ts = bn_affine(P, sc["bn"], sc["eps"])
+                psc = A_.upload(L_.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
+                shift2 = shift2 + ts
+            d1, d2 = A_.upload(t1), A_.upload(shift2.astype(np.float32))
+            nby = B * xr.H * xr.W * 64 * 2
+            exe._phys[-1], exe._phys[-2] = A_.alloc(nby), A_.alloc(nby)
+            tr, yr = TRef(-1, 64, xr.H, xr.W, 64, 0), TRef(-2, 64, xr.H, xr.W, 64, 0)
+            FO = R.RD_SCALE_FOLDED
+            L_.call("rd_conv3x3_bn_act_ex", exe.p(xr), xr.cs, xr.co, A_.ptr(p1), None, A_.ptr(d1), None, 0, 0, None, 0, 0, 0, None, exe.p(tr), 64, 0,
+                    B, xr.H, xr.W, 64, 64, 1, R.RD_RELU_POST | FO, dt, A_.stream)
+            L_.call("rd_conv3x3_bn_act_ex", exe.p(tr), 64, 0, A_.ptr(p2), None, A_.ptr(d2), None if psc is not None else exe.p(xr),
+                    0 if psc is not None else xr.cs, 0 if psc is not None else xr.co, exe.p(xr) if psc is not None else None,
+                    xr.cs if psc is not None else 0, xr.co if psc is not None else 0, 64 if psc is not None else 0,
+                    A_.ptr(psc) if psc is not None else None, exe.p(yr), 64, 0, B, xr.H, xr.W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | FO, dt, A_.stream)
+            t_dev = torch.from_numpy(np.ascontiguousarray(exe.debug_tensor(tr)))
+            y_two = torch.from_numpy(np.ascontiguousarray(exe.debug_tensor(yr)))
+            del exe._phys[-1], exe._phys[-2]
+            nd = int((got != y_two).sum())
+            report.append((st["name"] + " [fused block vs its two launches, differing elements]", tuple(got.shape), 0.0, nd))
+            if nd:
+                failed.append(st["name"] + " (fused block differs from the two launches on %d elements)" % nd)
+            w1q = _round_t(torch.from_numpy(w1 * s1[:, None, None, None]), dt)
+            w2q = _round_t(torch.from_numpy(w2 * s2[:, None, None, None]), dt)
+            r1 = torch.relu(F.conv2d(x, w1q, padding=1) + torch.from_numpy(t1)[None, :, None, None])
+            se1 = 2.0 ** -16 * float(np.abs(t1).max()) if dt == BF16 else 0.0
+            if not _check(a_["name"], t_dev, r1, dt, report, extra_abs=se1):
+                failed.append(a_["name"])
+            y2 = F.conv2d(t_dev, w2q, padding=1)
+            if psc is not None:
+                y2 = y2 + F.conv2d(x, _round_t(torch.from_numpy(wsc * ss[:, None]), dt)[:, :, None, None])
+            y2 = y2 + torch.from_numpy(shift2.astype(np.float32))[None, :, None, None]
+            if psc is None:
+                y2 = y2 + x
+            se2 = 2.0 ** -16 * float(np.abs(shift2).max()) if dt == BF16 else 0.0
+            if not _check(b_["name"], got, torch.relu(y2), dt, report, extra_abs=se2):
+                failed.append(b_["name"])
+            seen_forms.add(("block", xr.W, psc is not None))
+            host.retire(i)
+            continue
         if k not in ("conv", "deconv", "meta"):
             exe.forward(fr, only=i, dev=dev)
             if isinstance(st.get("out"), TRef):
@@ -262,5 +324,7 @@ def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
         print("  %-44s %-22s %.3f  %d" % (name, "x".join(str(v) for v in shape), worst, nbad))
     print("%d distinct launch forms, %d steps checked, %.0f s" % (len(seen_forms), len(report), time.time() - t00))
     kinds = [s["kind"] for s in plan.steps]
-    assert len(report) == kinds.count("conv") + kinds.count("deconv") + kinds.count("meta") == 78
+    # (a fused BasicBlock reports three lines: bit-equality with its two launches, conv1, conv2)
+    assert kinds.count("conv") + 2 * kinds.count("block") + kinds.count("deconv") + kinds.count("meta") == 78 and kinds.count("block") == 7
+    assert len(report) == kinds.count("conv") + 3 * kinds.count("block") + kinds.count("deconv") + kinds.count("meta")
     assert not failed, failed

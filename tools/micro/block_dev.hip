@@ -7,9 +7,9 @@ int rdm_pack_block64_host(const float* w1, const float* s1, const float* w2, con
   rd::pack_block64(w1, s1, w2, s2, dtype, out);
   return 0;
 }
-int rdm_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, void* y, int y_cs, int y_co,
-                int B, int H, int W, int dtype, void* stream) {
-  return rd::launch_block64(x, x_cs, x_co, w, shift1, shift2, y, y_cs, y_co, B, H, W, dtype, (hipStream_t)stream);
+int rdm_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, const void* sc_w, void* y,
+                int y_cs, int y_co, int B, int H, int W, int dtype, void* stream) {
+  return rd::launch_block64(x, x_cs, x_co, w, shift1, shift2, sc_w, y, y_cs, y_co, B, H, W, dtype, (hipStream_t)stream);
 }
 const char* rdm_last_error(void) { return rd::err_buf(); }
 }

@@ -22,7 +22,7 @@ def bind(path):
     m = ctypes.CDLL(path)
     m.rdm_block64_packed_bytes.restype = ctypes.c_size_t
     m.rdm_pack_block64_host.argtypes = [c_void_p] * 4 + [c_int, c_void_p]
-    m.rdm_block64.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    m.rdm_block64.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     m.rdm_last_error.restype = ctypes.c_char_p
     return m
 
@@ -67,7 +67,7 @@ if mode == "emu":
                yr.ctypes.data, 64, 0, B, H, W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, None)
         pk = pack_block(m, w1, s1, w2, s2, dt)
         y = np.full((B, H, W, 64), 0x7fc0, np.uint16)
-        rc = m.rdm_block64(xb.ctypes.data, 64, 0, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, y.ctypes.data, 64, 0, B, H, W, dt, None)
+        rc = m.rdm_block64(xb.ctypes.data, 64, 0, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, None, y.ctypes.data, 64, 0, B, H, W, dt, None)
         assert rc == 0, m.rdm_last_error()
         bad = y != yr
         print("B %d H %d W %d dt %d: %d of %d values differ from the unfused pair" % (B, H, W, dt, int(bad.sum()), bad.size), flush=True)
@@ -103,7 +103,7 @@ else:
                        yr[i].data_ptr(), 64, 0, B, H, W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, st)
 
             def fused(i):
-                rc = m.rdm_block64(xs[i].data_ptr(), 64, 0, pk.data_ptr(), T1.data_ptr(), T2.data_ptr(), yf[i].data_ptr(), 64, 0, B, H, W, dt, st)
+                rc = m.rdm_block64(xs[i].data_ptr(), 64, 0, pk.data_ptr(), T1.data_ptr(), T2.data_ptr(), None, yf[i].data_ptr(), 64, 0, B, H, W, dt, st)
                 assert rc == 0, m.rdm_last_error()
             for i in range(NB):
                 unfused(i)

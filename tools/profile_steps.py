@@ -40,6 +40,10 @@ for i, st in enumerate(pipe.plan.steps):
         o = a["out"]
         fl = 2 * B * 2.0 * o.H * o.W * a["cin"] * a["cout"] * 9
         desc = "%s %d->%d x2 W%d" % (st["name"].replace("rpn_", "").replace("_conv", ""), a["cin"], a["cout"], o.W)
+    elif k == "block":     # a fused 64-channel BasicBlock: the FLOPs of its two convs (+ the 1x1 shortcut)
+        o = st["out"]
+        fl = B * 2.0 * o.H * o.W * 64 * 64 * (18 + (1 if st["b"].get("sc") else 0))
+        desc = "%s 64->64->64 W%d%s" % (st["name"].replace("_conv1 + ", " + ").split(" + ")[0] + " block", o.W, " +sc" if st["b"].get("sc") else "")
     elif k in ("conv", "deconv"):
         o = st["out"]
         fl = B * 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
@@ -54,7 +58,11 @@ for i, st in enumerate(pipe.plan.steps):
     # report: 8 x 32 tiles (RD_CONV_WIDE=0: 8 x 30) with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
     # a stride-2 conv runs on the pixel-pair view = its output grid, a transposed conv phase on its input grid)
     tps = ""
-    if dt in rdlib.H16 and k == "conv_pair":
+    if dt in rdlib.H16 and k == "block":
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        ntiles = -(-st["out"].W // 32) * -(-st["out"].H // 8) * B
+        tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, 2 * cus, ntiles / (2 * cus))
+    elif dt in rdlib.H16 and k == "conv_pair":
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         ntiles = 2 * -(-st["out"].W // 32) * -(-st["out"].H // 8) * B
         tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, 2 * cus, ntiles / (2 * cus))
