@@ -423,7 +423,11 @@ def main(argv=None):
         for j in range(len(multi.pipes)):
             harvest(j)
         region_s.append(time.perf_counter() - t0)
-        step_ms += [done_events[i].elapsed_time(done_events[i + 1]) for i in range(len(done_events) - 1)]
+        # steady-state time per step from the completion events: with n batches in flight on n pipelines the completions come in
+        # bursts of n (the streams share the GPU and finish together), so the interval is taken over a window of n steps and divided
+        # by n -- (steps - n) samples per region
+        nw = len(multi.pipes)
+        step_ms += [done_events[i].elapsed_time(done_events[i + nw]) / nw for i in range(len(done_events) - nw)]
     if gather:
         t = torch.tensor(region_s, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -560,8 +564,8 @@ def main(argv=None):
             "value": args.steps * world * Bf / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             # spread: `value` / `ms_per_step` are the median of `repeats` timed regions of `steps` steps each;
-            # ms_per_step_p5/p50/p95 come from the completion events of the individual steps (steady-state interval between
-            # consecutive completions, (steps - 1) x repeats samples; own-rank events -- rank 0 for N > 1)
+            # ms_per_step_p5/p50/p95 come from the completion events of the individual steps (interval between the completions of
+            # steps i and i + n over n = batches in flight, (steps - n) x repeats samples; own-rank events -- rank 0 for N > 1)
             "repeats": repeats, "value_min": args.steps * world * Bf / max(region_s), "value_max": args.steps * world * Bf / min(region_s),
             "region_ms": [round(v * 1e3, 3) for v in region_s],
             "ms_per_step_p5": float(np.percentile(step_ms, 5)) if step_ms else None,
