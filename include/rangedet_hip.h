@@ -135,17 +135,20 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
                          int sc_cin, const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int Win, int cin,
                          int cout, int stride_w, int flags, int dtype, void* stream);
 /* A whole 64-channel BasicBlock (rangedet/symbol/backbone/dla_backbone.py:18-56: conv1 3x3 + BN + ReLU, conv2 3x3 + BN, + shortcut, ReLU;
- * stride 1, 64 -> 64 -> 64) as ONE launch -- replaces the two rd_conv3x3_bn_act_ex calls of the block; the intermediate tensor is never
+ * stride 1, cin -> 64 -> 64) as ONE launch -- replaces the two rd_conv3x3_bn_act_ex calls of the block; the intermediate tensor is never
  * written to HBM (it lives in LDS as conv2's halo image) and the results are BIT-IDENTICAL to the two calls.
- *   sc_w_packed == NULL  identity shortcut (units 2.. of a stage):  y = relu(BN2(conv2(relu(BN1(conv1(x))))) + x)
- *   sc_w_packed != NULL  projection shortcut (unit 1, dla_backbone.py:44-51): + BNs(conv1x1(x)) instead of + x; sc_w_packed =
- *                        rd_pack_conv1x1_sc_host(64 -> 64, fold_scale = the shortcut BatchNorm's scale), shift2 = conv2's + the shortcut's.
- * w_packed = rd_pack_block64_host (HOST): both 3x3 weights (64, 64, 3, 3) with their BatchNorm scales folded in; shift1 / shift2 (64)
- * floats on the device.  x: [B][H][W][x_cstride] channels [x_coff, x_coff + 64), y likewise; 16-bit types only. */
-size_t rd_block64_packed_bytes(void);
+ *   cin == 64, sc_w_packed == NULL  identity shortcut (units 2.. of a stage):  y = relu(BN2(conv2(relu(BN1(conv1(x))))) + x)
+ *   cin == 64, sc_w_packed != NULL  projection shortcut (unit 1, dla_backbone.py:44-51): + BNs(conv1x1(x)) instead of + x; sc_w_packed =
+ *                        rd_pack_conv1x1_sc_host(cin -> 64, fold_scale = the shortcut BatchNorm's scale), shift2 = conv2's + the shortcut's.
+ *   cin <= 16            the network's first block (res1_unit1: the 8-channel range image, or 5 channels for KITTI): conv1 runs as five
+ *                        two-tap steps on one 16-channel k-slot; the projection shortcut is required.
+ * w_packed = rd_pack_block64_host (HOST): the 3x3 weights (64, cin, 3, 3) and (64, 64, 3, 3) with their BatchNorm scales folded in;
+ * shift1 / shift2 (64) floats on the device.  x: [B][H][W][x_cstride] channels [x_coff, x_coff + cin) -- the channels up to the next
+ * multiple of 16 must exist in the buffer and be zero --, y: channels [y_coff, y_coff + 64); 16-bit types only. */
+size_t rd_block64_packed_bytes(int cin);
 int rd_pack_block64_host(const float* w1_oihw_host, const float* fold_scale1_host, const float* w2_oihw_host,
-                         const float* fold_scale2_host, int dtype, void* packed_host);
-int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* shift1, const float* shift2,
+                         const float* fold_scale2_host, int cin, int dtype, void* packed_host);
+int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const void* w_packed, const float* shift1, const float* shift2,
                       const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream);
 
 /* Last conv of a head tower (3x3, cout 128, BN + ReLU, RD_BF16 or RD_F16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:

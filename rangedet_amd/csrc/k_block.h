@@ -32,12 +32,13 @@ namespace rd {
 
 struct BlockArgs {
   const bf16_t* x; int x_cs, x_co; long x_bs;      // block input = residual (64 channels)
-  const unsigned char* w;                          // [conv1: pack_taps_frag(9, 64, 64) | conv2: the same | RD_CONV_TAIL zeros]
+  const unsigned char* w;                          // [conv1: pack_taps_frag(9, 64, 64) (FIRST: pack_body_frag(3, cin <= 16, 64)) | conv2: pack_taps_frag | RD_CONV_TAIL zeros]
   const float* shift1; const float* shift2;        // BatchNorm shifts (scales folded into the weights; SC: shift2 = conv2's + the shortcut's)
   const unsigned char* scw;                        // SC: packed 1x1 shortcut weights, pack_sc_frag(64 -> 64) = [4 k-steps][2][64 lanes][8]
   bf16_t* y; int y_cs, y_co; long y_bs;
   const unsigned char* zero16;
   int H, W, B, ncol, nrow, ntiles, xcd;
+  int nslots1;                                     // FIRST: valid 16-byte channel slots of x (1 or 2); the others are read from the zero page
 };
 
 constexpr int BK_R = 6;                    // ring depth (slabs of 4 KB)
@@ -47,24 +48,31 @@ constexpr int BK_BUF = 4 * BK_XPIECES * 1024;   // bytes of one buffer (28 672)
 constexpr int BK_TP = 34;                  // row pitch of the intermediate image (pixels)
 constexpr int BK_SLAB = 4096;
 constexpr size_t BK_LDS = 2 * BK_BUF + BK_R * BK_SLAB;   // 81 920 = 80 KB: two workgroups per CU
-constexpr size_t BK_WBYTES = 2 * 18 * BK_SLAB;           // packed weights of both convs (without the tail)
 
-// halo pieces issued in step `s` of a unit that fetches (U0, U3): 2, 2, 1, 1, 1 at ordinals 0..4 (all of them at least two steps
-// before the wait at ordinal 7 that must cover them)
+// Step structure of a tile.  Units: [U0 | U1 | U2 | U3] of 9 steps each; FIRST (the first block of the network, conv1 on <= 16 input
+// channels): [P | U2 | U3] with P = five two-tap steps on the one 16-channel k-slot (k_conv3.h UK_P5), 23 steps and 23 slabs per tile.
+// A unit that FETCHES (U0: x chunk 1 of this tile -> buffer 1; U3: x chunk 0 of the next tile -> buffer 0; FIRST has one x chunk, so only
+// U3 fetches) issues its 7 halo pieces per wave as 2, 2, 1, 1, 1 at ordinals 0..4 -- all of them at least two steps before the wait
+// at ordinal 7 that must cover them.
+constexpr int bk_nsteps(bool first) { return first ? 23 : 36; }
+constexpr int bk_unit(bool first, int g) { return first ? (g < 5 ? 0 : g < 14 ? 2 : 3) : g / 9; }           // 0..3 (FIRST: 0 = the P unit)
+constexpr int bk_ord(bool first, int g) { return first ? (g < 5 ? g : (g - 5) % 9) : g % 9; }
+constexpr bool bk_fetches(bool first, int g) { return bk_unit(first, g) == 3 || (!first && bk_unit(first, g) == 0); }
 constexpr int bk_pieces_u(int s) { return s <= 1 ? 2 : s <= 4 ? 1 : 0; }
 constexpr int bk_first_u(int s) { int n = 0; for (int t = 0; t < s; ++t) n += bk_pieces_u(t); return n; }
-constexpr int bk_pieces(int g) { const int u = (g / 9) & 3; return (u == 0 || u == 3) ? bk_pieces_u(g % 9) : 0; }   // g = step of the tile, 0..35 (cyclic)
+constexpr int bk_pieces(bool first, int g) { return bk_fetches(first, g) ? bk_pieces_u(bk_ord(first, g)) : 0; }   // g = step of the tile (cyclic)
 // DMA instructions a wave issued after "its part of slab g + 2" as seen at the wait of step g (k_conv3.h c3_younger; IPW = 1)
-constexpr int bk_younger(int g) {
+constexpr int bk_younger(bool first, int g) {
+  const int G = bk_nsteps(first);
   int n = BK_R - 3;
-  for (int d = 1; d <= BK_R - 2; ++d) n += bk_pieces(((g - d) % 36 + 36) % 36);
-  const int u = (g / 9) & 3, s = g % 9;
+  for (int d = 1; d <= BK_R - 2; ++d) n += bk_pieces(first, ((g - d) % G + G) % G);
   const int cap = 9 - 3 - 4;               // ordinal 7 of a fetching unit: the wait also covers the unit's last halo piece (ordinal 4)
-  return ((u == 0 || u == 3) && s == 7 && n > cap) ? cap : n;
+  return (bk_fetches(first, g) && bk_ord(first, g) == 7 && n > cap) ? cap : n;
 }
 
-template <int DT, bool SC>
+template <int DT, bool SC, bool FIRST = false>
 __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
+  static_assert(!FIRST || SC, "the first block changes the channel count: projection shortcut");
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   constexpr int R = BK_R, SLAB = BK_SLAB, RING = 2 * BK_BUF, NCT = 2;
   constexpr int ROWB2 = BK_TP * 64;        // bytes of one row of the intermediate image
@@ -142,8 +150,9 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
       hnew = false;
     }
     hbase = htile + hc * 64;
-    // advance: chunk 1 of the same tile, then chunk 0 of the next tile; past the end of the list the last unit is fetched again
-    if (hc == 0) hc = 1;
+    // advance: chunk 1 of the same tile, then chunk 0 of the next tile (FIRST: one chunk per tile); past the end of the list the last
+    // unit is fetched again
+    if (!FIRST && hc == 0) hc = 1;
     else if (hk + 1 < ntl) { ++hk; hc = 0; tile_advance(f_ct, f_rb, f_b); hnew = true; }
   };
   auto halo_piece = [&](int buf, int j) {
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     asm volatile("" : "+v"(ol));      // (opaque: keeps the per-piece index math out of the registers that live across the MFMA phase)
     const int pp = 16 * q + (ol >> 2), r = (pp * 1821) >> 16, cc = pp - BK_XP * r;      // pp / 36 exactly for pp < 448
     const int hs = (ol & 3) ^ ((ol >> 4) & 3);                      // logical 16-byte slot: physical slot ^ ((pp >> 2) & 3)
-    const bool ok = pp < 12 * BK_XP && (unsigned)(hh0 + r) < (unsigned)a.H && (unsigned)(hw0 + cc) < (unsigned)a.W;
+    const bool ok = pp < 12 * BK_XP && (unsigned)(hh0 + r) < (unsigned)a.H && (unsigned)(hw0 + cc) < (unsigned)a.W && (!FIRST || hs < a.nslots1);
     const unsigned char* src = hbase + (long)((r * a.W + cc) * a.x_cs * 2 + hs * 16);
     dma_v(ok ? (const void*)src : (const void*)a.zero16, buf + q * 1024);
   };
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   auto slab_piece = [&]() { dma_s(a.w + (size_t)fslab * SLAB + wave * 1024, lane * 16, RING + fslot * SLAB + wave * 1024); };
   auto slab_advance = [&]() {
     fslot = fslot + 1 == R ? 0 : fslot + 1;
-    fslab = fslab + 1 == 36 ? 0 : fslab + 1;
+    fslab = fslab + 1 == bk_nsteps(FIRST) ? 0 : fslab + 1;
   };
 
   // ---- fragment addressing -------------------------------------------------------------------------------------------------------
@@ -207,16 +216,16 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     asm volatile("" ::: "memory");                                \
     BK_FENCE();                                                   \
   }
-  // One step (tap) of unit U_ (0..3), ordinal S_, with F pixel fragments per wave:
-  //   block 0: MFMAs of k-step 0, the reads of (this step, k-step 1) interleaved 1:1;
-  //   block 1: MFMAs of k-step 1, first half with the reads of (next step, k-step 0) -- NF_ pixel fragments at stride NFS_: the next
-  //            step's shape (NF_ = 0: none, the pipeline is cut) --, the step's barrier, then the second half with the step's DMA pieces.
-  // ACUR_ = address of this step's fragment 0 at k-step 0; ANEXT_ = the next step's.
-#define BK_STEP(F, FS, U_, S_, NF_, NFS_, ACUR_, ANEXT_)                                                           \
+  // One step of the tile, G_ = its index in the tile (bk_unit / bk_ord), with F pixel fragments per wave:
+  //   block 0: MFMAs of k-step 0, the reads of (this step, k-step 1) interleaved 1:1 -- from A1_;
+  //   block 1: MFMAs of k-step 1, first half with the reads of (next step, k-step 0) -- from ANEXT_, NF_ pixel fragments at stride NFS_:
+  //            the next step's shape (NF_ = 0: none, the pipeline is cut) --, the step's barrier, then the second half with the step's
+  //            DMA pieces (the slab, and the halo pieces of a fetching unit into buffer HB_).
+#define BK_STEP(F, FS, G_, HB_, NF_, NFS_, A1_, ANEXT_)                                                            \
   {                                                                                                                \
-    constexpr int NM_ = (F) * NCT, NR_ = (F) + NCT, G_ = 9 * (U_) + (S_), NRN_ = (NF_) ? (NF_) + NCT : 0;          \
-    constexpr int NH_ = bk_pieces(G_), NP_ = 1 + NH_, HF_ = bk_first_u(S_), YG_ = bk_younger(G_);                  \
-    const int acur_ = (ACUR_) ^ 32;                                                                                \
+    constexpr int NM_ = (F) * NCT, NR_ = (F) + NCT, NRN_ = (NF_) ? (NF_) + NCT : 0;                                \
+    constexpr int NH_ = bk_pieces(FIRST, G_), NP_ = 1 + NH_, HF_ = bk_first_u(bk_ord(FIRST, G_)), YG_ = bk_younger(FIRST, G_); \
+    const int acur_ = (A1_);                                                                                       \
     const int bcur_ = boff + rslot * SLAB;                                                                         \
     const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                             \
     const int anext_ = (ANEXT_);                                                                                   \
@@ -232,28 +241,36 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     }                                                                                                              \
     { _Pragma("unroll") for (int n = NM_ / 2; n < NRN_; ++n) BK_RD(NF_, NFS_, 0, n, anext_, bnext_, 0) }           \
     BK_SYNC(YG_, NRN_)                                                                                             \
-    if (NH_ > 0 && (S_) == 0) halo_begin();                                                                        \
+    if (NH_ > 0 && bk_ord(FIRST, G_) == 0) halo_begin();                                                           \
     _Pragma("unroll") for (int n = NM_ / 2; n < NM_; ++n) {                                                        \
       BK_MM(1, n)                                                                                                  \
       _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                              \
         if (p * (NM_ / 2) / NP_ == n - NM_ / 2) {                                                                  \
-          if (p == 0) slab_piece(); else halo_piece((U_) == 0 ? BK_BUF : 0, HF_ + p - 1);                          \
+          if (p == 0) slab_piece(); else halo_piece(HB_, HF_ + p - 1);                                             \
           BK_FENCE();                                                                                              \
         }                                                                                                          \
     }                                                                                                              \
     slab_advance();                                                                                                \
     rslot = rnext_;                                                                                                \
   }
-  // conv1 step: unit U_ (0 or 1) reads x chunk U_ from buffer U_; tap S_; the next step is tap S_ + 1 of the same buffer, or tap 0 of
-  // buffer 1 after U0's last step; U1's last step pre-reads nothing (t does not exist yet)
+  // conv1 step: unit U_ (0 or 1) reads x chunk U_ from buffer U_; tap S_ (k-step 1 = the same pixels' second 16-channel slot: ^ 32); the
+  // next step is tap S_ + 1 of the same buffer, or tap 0 of buffer 1 after U0's last step; U1's last step pre-reads nothing (t does
+  // not exist yet).  U0 fetches x chunk 1 into buffer 1.
 #define BK_C1(U_, S_)                                                                                              \
-  BK_STEP(3, 2048, U_, S_, (((U_) == 1 && (S_) == 8) ? 0 : 3), 2048, a1[(S_) / 3][(S_) % 3] + (U_) * BK_BUF,       \
+  BK_STEP(3, 2048, 9 * (U_) + (S_), BK_BUF, (((U_) == 1 && (S_) == 8) ? 0 : 3), 2048,                              \
+          (a1[(S_) / 3][(S_) % 3] + (U_) * BK_BUF) ^ 32,                                                           \
           ((S_) == 8 ? a1[0][0] + BK_BUF : a1[(((S_) + 1) % 9) / 3][((S_) + 1) % 3] + (U_) * BK_BUF))
-  // conv2 step: unit 2 + C_ reads t chunk C_ from buffer C_; U3's last step pre-reads the first fragments of the NEXT tile's conv1
-  // (x chunk 0 in buffer 0 has landed: the wait of U3's ordinal 7 covered it), so only the cut after U1 leaves a bubble
+  // FIRST: conv1 step S_ of the five two-tap steps on x's one 16-channel k-slot: k-step 0 = tap 2 S_, k-step 1 = tap 2 S_ + 1 (tap 9 does
+  // not exist: its packed weights are zero, any address will do); the last one pre-reads nothing
+#define BK_P1(S_)                                                                                                  \
+  BK_STEP(3, 2048, (S_), 0, ((S_) == 4 ? 0 : 3), 2048, a1[((2 * (S_) + 1) % 9) / 3][(2 * (S_) + 1) % 3],           \
+          a1[((2 * (S_) + 2) % 9) / 3][(2 * (S_) + 2) % 3])
+  // conv2 step: unit 2 + C_ reads t chunk C_ from buffer C_; U3 fetches the next tile's x chunk 0 into buffer 0, and its last step
+  // pre-reads the first fragments of the NEXT tile's conv1 (that chunk has landed: the wait of U3's ordinal 7 covered it), so only the
+  // cut before conv2 leaves a bubble
 #define BK_C2(C_, S_)                                                                                              \
-  BK_STEP(2, ROWB2, 2 + (C_), S_, (((C_) == 1 && (S_) == 8) ? 3 : 2), (((C_) == 1 && (S_) == 8) ? 2048 : ROWB2),   \
-          a2[(S_) % 3] + ((S_) / 3) * ROWB2 + (C_) * BK_BUF,                                                       \
+  BK_STEP(2, ROWB2, (FIRST ? 5 : 18) + 9 * (C_) + (S_), 0, (((C_) == 1 && (S_) == 8) ? 3 : 2), (((C_) == 1 && (S_) == 8) ? 2048 : ROWB2), \
+          (a2[(S_) % 3] + ((S_) / 3) * ROWB2 + (C_) * BK_BUF) ^ 32,                                                \
           ((S_) == 8 ? ((C_) == 1 ? a1[0][0] : a2[0] + BK_BUF) : a2[((S_) + 1) % 3] + ((((S_) + 1) % 9) / 3) * ROWB2 + (C_) * BK_BUF))
 
   // ---- prologue: x chunk 0 of the first tile, a full ring ----------------------------------------------------------------------------
@@ -285,8 +302,12 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
       acc[n / NCT][n % NCT] = H16<DT>::mfma(bz, ones, f32x16{});
     }
     BK_FENCE();
-    BK_C1(0, 0) BK_C1(0, 1) BK_C1(0, 2) BK_C1(0, 3) BK_C1(0, 4) BK_C1(0, 5) BK_C1(0, 6) BK_C1(0, 7) BK_C1(0, 8)
-    BK_C1(1, 0) BK_C1(1, 1) BK_C1(1, 2) BK_C1(1, 3) BK_C1(1, 4) BK_C1(1, 5) BK_C1(1, 6) BK_C1(1, 7) BK_C1(1, 8)
+    if constexpr (FIRST) {
+      BK_P1(0) BK_P1(1) BK_P1(2) BK_P1(3) BK_P1(4)
+    } else {
+      BK_C1(0, 0) BK_C1(0, 1) BK_C1(0, 2) BK_C1(0, 3) BK_C1(0, 4) BK_C1(0, 5) BK_C1(0, 6) BK_C1(0, 7) BK_C1(0, 8)
+      BK_C1(1, 0) BK_C1(1, 1) BK_C1(1, 2) BK_C1(1, 3) BK_C1(1, 4) BK_C1(1, 5) BK_C1(1, 6) BK_C1(1, 7) BK_C1(1, 8)
+    }
 
     // ---- t = relu(conv1 + shift1), rounded, into buf0 (channels 0..31) / buf1 (32..63) in conv2's halo layout ---------------------
     // Every wave is past the barrier of U1's last step, i.e. nobody reads x any more and no DMA targets the two buffers.
@@ -352,17 +373,18 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
         // weights; four 16-channel k-steps in the unfused launch's order
         const bf16_t* __restrict__ sb = a.x + (size_t)b * a.x_bs + a.x_co + 8 * ehi;
         const unsigned char* __restrict__ wq = a.scw + el * 16;
-        s16x8 sxq[2][4];
+        constexpr int SNK = FIRST ? 1 : 4;                 // 16-channel k-steps of the block input
+        s16x8 sxq[2][SNK];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int ow = ct * 32 + em, oh = oh0 + i;
           const bool live = ow < a.W && oh < a.H;
           const bf16_t* sp = sb + (live ? ((size_t)oh * a.W + ow) * a.x_cs : 0);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) sxq[i][ks] = *(const s16x8*)(sp + 16 * ks);
+          for (int ks = 0; ks < SNK; ++ks) sxq[i][ks] = *(const s16x8*)(sp + 16 * ks);
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < SNK; ++ks)
 #pragma unroll
           for (int j = 0; j < NCT; ++j) {
             const s16x8 wf = *(const s16x8*)(wq + (size_t)(ks * NCT + j) * 1024);
@@ -420,6 +442,7 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));      // the dummy tail fetches target this workgroup's LDS: retire them before it is released
 #undef BK_C2
+#undef BK_P1
 #undef BK_C1
 #undef BK_STEP
 #undef BK_SYNC
@@ -428,29 +451,36 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
 #undef BK_FENCE
 }
 
-// packed weights of a fused block: [conv1 | conv2] images of pack_taps_frag(9 taps, 64, 64) + the zero tail.  w1, w2: (64, 64, 3, 3)
+// packed weights of a fused block: [conv1 | conv2 | zero tail].  conv2: pack_taps_frag(9 taps, 64, 64).  conv1 with cin = 64: the same;
+// with cin <= 16 (FIRST): pack_body_frag(body 3: five two-tap steps on one 16-channel k-slot).  w1: (64, cin, 3, 3), w2: (64, 64, 3, 3)
 // row-major, scale1 / scale2: the folded BatchNorm scales (nullptr = none)
-inline size_t block64_packed_bytes() { return BK_WBYTES + RD_CONV_TAIL; }
-inline void pack_block64(const float* w1, const float* s1, const float* w2, const float* s2, int dt, void* out) {
-  memset(out, 0, block64_packed_bytes());
-  for (int c = 0; c < 2; ++c) {
-    const float* w = c ? w2 : w1;
-    const float* s = c ? s2 : s1;
-    pack_taps_frag(9, 64, 64, (unsigned char*)out + (size_t)c * 18 * BK_SLAB,
-                   [&](int co, int ci, int t) { return (s ? s[co] : 1.f) * w[((size_t)co * 64 + ci) * 9 + t]; }, dt);
-  }
+inline bool block64_first(int cin) { return cin <= 16; }
+inline size_t block64_body_bytes(int cin) { return (size_t)bk_nsteps(block64_first(cin)) * BK_SLAB; }
+inline size_t block64_packed_bytes(int cin) { return block64_body_bytes(cin) + RD_CONV_TAIL; }
+inline void pack_block64(const float* w1, const float* s1, const float* w2, const float* s2, int cin, int dt, void* out) {
+  memset(out, 0, block64_packed_bytes(cin));
+  if (block64_first(cin))
+    pack_body_frag(3, cin, 64, out, [&](int co, int ci, int dh, int dw) { return (s1 ? s1[co] : 1.f) * w1[(((size_t)co * cin + ci) * 3 + dh) * 3 + dw]; }, dt);
+  else
+    pack_taps_frag(9, 64, 64, out, [&](int co, int ci, int t) { return (s1 ? s1[co] : 1.f) * w1[((size_t)co * 64 + ci) * 9 + t]; }, dt);
+  pack_taps_frag(9, 64, 64, (unsigned char*)out + block64_body_bytes(cin) - 18 * BK_SLAB,
+                 [&](int co, int ci, int t) { return (s2 ? s2[co] : 1.f) * w2[((size_t)co * 64 + ci) * 9 + t]; }, dt);
 }
 
-inline int launch_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, const void* sc_w,
+inline int launch_block64(const void* x, int x_cs, int x_co, int cin, const void* w, const float* shift1, const float* shift2, const void* sc_w,
                           void* y, int y_cs, int y_co, int B, int H, int W, int dt, hipStream_t st) {
   RD_REQUIRE(is_h16(dt), RD_EINVAL, "block64: dtype %d (RD_BF16 or RD_F16)", dt);
+  const bool first = block64_first(cin);
+  RD_REQUIRE(cin == 64 || (first && cin >= 1), RD_ESHAPE, "block64: %d input channels (64, or at most 16 for the network's first block)", cin);
+  RD_REQUIRE(!first || sc_w, RD_EINVAL, "block64: a block that changes the channel count needs its projection shortcut");
   BlockArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const bf16_t*)x; a.x_cs = x_cs; a.x_co = x_co; a.x_bs = (long)H * W * x_cs;
   a.w = (const unsigned char*)w; a.shift1 = shift1; a.shift2 = shift2; a.scw = (const unsigned char*)sc_w;
   a.y = (bf16_t*)y; a.y_cs = y_cs; a.y_co = y_co; a.y_bs = (long)H * W * y_cs;
-  a.zero16 = (const unsigned char*)w + BK_WBYTES;
+  a.zero16 = (const unsigned char*)w + block64_body_bytes(cin);
   a.H = H; a.W = W; a.B = B;
+  a.nslots1 = std::min(2, (x_cs - x_co) / 8);      // (channels past cin are zero in the buffer and meet zero weights)
   a.ncol = (W + 31) / 32; a.nrow = (H + 7) / 8; a.ntiles = a.ncol * a.nrow * B;
   const int grid = std::min(a.ntiles, conv_num_cus() * 2);
   a.xcd = dev_switches().conv_xcd && (a.ncol * B) % 8 == 0 && grid % 8 == 0;
@@ -459,14 +489,16 @@ inline int launch_block64(const void* x, int x_cs, int x_co, const void* w, cons
   once_per_device(seen, [] {
     allow_big_lds(block64_stream_kernel<RD_F16, false>); allow_big_lds(block64_stream_kernel<RD_BF16, false>);
     allow_big_lds(block64_stream_kernel<RD_F16, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true>);
+    allow_big_lds(block64_stream_kernel<RD_F16, true, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true, true>);
   });
-  if (dt == RD_F16) {
-    if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<RD_F16, true>), dim3(grid), dim3(256), BK_LDS, st, a);
-    else hipLaunchKernelGGL((block64_stream_kernel<RD_F16, false>), dim3(grid), dim3(256), BK_LDS, st, a);
-  } else {
-    if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<RD_BF16, true>), dim3(grid), dim3(256), BK_LDS, st, a);
-    else hipLaunchKernelGGL((block64_stream_kernel<RD_BF16, false>), dim3(grid), dim3(256), BK_LDS, st, a);
+#define BK_GO(DT_)                                                                                                         \
+  {                                                                                                                        \
+    if (first) hipLaunchKernelGGL((block64_stream_kernel<DT_, true, true>), dim3(grid), dim3(256), BK_LDS, st, a);         \
+    else if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<DT_, true>), dim3(grid), dim3(256), BK_LDS, st, a);           \
+    else hipLaunchKernelGGL((block64_stream_kernel<DT_, false>), dim3(grid), dim3(256), BK_LDS, st, a);                    \
   }
+  if (dt == RD_F16) BK_GO(RD_F16) else BK_GO(RD_BF16)
+#undef BK_GO
   return check_launch("block64_stream_kernel");
 }
 

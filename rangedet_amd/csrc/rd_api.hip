@@ -309,22 +309,24 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
 }
 
 // ---- a whole 64-channel BasicBlock in one launch (k_block.h) ------------------------------------------------------------------------
-size_t rd_block64_packed_bytes(void) { return block64_packed_bytes(); }
-int rd_pack_block64_host(const float* w1, const float* fold_scale1, const float* w2, const float* fold_scale2, int dtype, void* out) {
+size_t rd_block64_packed_bytes(int cin) { return block64_packed_bytes(cin); }
+int rd_pack_block64_host(const float* w1, const float* fold_scale1, const float* w2, const float* fold_scale2, int cin, int dtype, void* out) {
   RD_REQUIRE(w1 && w2 && out, RD_EINVAL, "pack_block64: null pointer");
   RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_block64: dtype %d (RD_BF16 or RD_F16)", dtype);
-  pack_block64(w1, fold_scale1, w2, fold_scale2, dtype, out);
+  RD_REQUIRE(cin == 64 || (cin >= 1 && cin <= 16), RD_ESHAPE, "pack_block64: %d input channels (64, or at most 16)", cin);
+  pack_block64(w1, fold_scale1, w2, fold_scale2, cin, dtype, out);
   return RD_OK;
 }
-int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* shift1, const float* shift2,
+int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const void* w_packed, const float* shift1, const float* shift2,
                       const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream) {
   RD_REQUIRE(x && w_packed && shift1 && shift2 && y, RD_EINVAL, "block64: null pointer");
   RD_REQUIRE(is_h16(dtype), RD_EINVAL, "block64: dtype %d (RD_BF16 or RD_F16)", dtype);
   RD_REQUIRE(B > 0 && H > 0 && W > 0, RD_ESHAPE, "block64: shape");
-  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff >= 0 && x_coff + 64 <= x_cstride, RD_ESHAPE, "block64: x channel stride / offset");
+  RD_REQUIRE(cin == 64 || (cin >= 1 && cin <= 16), RD_ESHAPE, "block64: %d input channels (64, or at most 16 for the network's first block)", cin);
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff >= 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "block64: x channel stride / offset");
   RD_REQUIRE(y_cstride % 8 == 0 && y_coff % 8 == 0 && y_coff >= 0 && y_coff + 64 <= y_cstride, RD_ESHAPE, "block64: y channel stride / offset");
   RD_REQUIRE(x != y, RD_EINVAL, "block64: in-place (a tile's halo is another tile's output)");
-  return launch_block64(x, x_cstride, x_coff, w_packed, shift1, shift2, sc_w_packed, y, y_cstride, y_coff, B, H, W, dtype, (hipStream_t)stream);
+  return launch_block64(x, x_cstride, x_coff, cin, w_packed, shift1, shift2, sc_w_packed, y, y_cstride, y_coff, B, H, W, dtype, (hipStream_t)stream);
 }
 
 // ---- 3x3 conv over the channel concatenation [x1 | x2] of two tensors that is never materialised (16-bit, folded scales) -----------

@@ -78,9 +78,9 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
     shard (rangedet_amd.dist.FrameSharding): this process handles the records shard.mine(len(roidb)) -- the reference runs one
     DetModule per GPU off a shared queue (tools/test.py:143-161); here one process per GPU owns every world-th record and the
     per-rank dictionaries are merged by merge_across_ranks.  Batches overlap: `inflight` pipelines on their own streams
-    (pipeline.InterleavedPipelines), batch i+1 is enqueued before batch i's results are read back.  A frame with more
-    candidates above min_score than the weighted NMS was sized for is re-run alone with a capacity that fits (the reference
-    has no such limit, nms.h:452-577), never truncated."""
+    (pipeline.InterleavedPipelines), batch i+1 is enqueued before batch i's results are read back.  A batch in which a frame has
+    more candidates above min_score than the weighted NMS was sized for is re-run as a whole with a capacity that fits (the
+    reference has no such limit, nms.h:452-577), never truncated."""
     from . import lib as rdlib
     from .input_transform import DeviceInputTransform
     from .pipeline import InterleavedPipelines, RangeDetPipeline
@@ -101,11 +101,16 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
     cls = mapping[variant if variant in mapping else 'veh']
     big = {}                                                   # capacity -> single-frame pipeline for overflowing frames
 
-    def rerun(rec):
+    def rerun(inputs):
+        """The WHOLE batch again through a pipeline whose weighted NMS is sized for the worst case (every pre-NMS candidate above
+        min_score): one forward + one batched NMS instead of `batch` single-frame runs.  Built on first use and kept; its workspace
+        is 3 K^2 / 8 bytes per frame (0.94 GB at K = 50 000, so 7.5 GB for a batch of 8 -- small
+        against 288 GB)."""
         K = min(max(topn.values()), rdlib.RD_WNMS_MAX_K)
         if K not in big:
-            big[K] = RangeDetPipeline(params, wnms_cap=K, **dict(kw, batch=1))
-        return big[K].run(to_inputs([rec]))
+            big[K] = RangeDetPipeline(params, wnms_cap=K, **kw)
+        big[K].enqueue(inputs)
+        return big[K].collect()
 
     def finish(j, chunk, recs, inputs):
         # one wait (for this pipeline's own post-processing event) and one host copy per batch
@@ -114,7 +119,7 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
         except rdlib.RangeDetError as e:
             if e.code != rdlib.RD_EWORKSPACE or not wnms:
                 raise
-            frames = [rerun(r) for r in recs]                  # a frame above the WNMS capacity: this batch again, frame by frame, sized for the worst case
+            frames = rerun(inputs)                             # a frame above the WNMS capacity: this batch again, sized for the worst case
         for b, i in enumerate(chunk):
             rec, fr = roidb[i], frames[b]
             rid = rec.get('rec_id', i)

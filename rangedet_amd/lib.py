@@ -61,9 +61,9 @@ SIGNATURES = {
     "rd_deconv2d_bn_act_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
-    "rd_block64_packed_bytes": (c_size_t, []),
-    "rd_pack_block64_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "rd_block64_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    "rd_block64_packed_bytes": (c_size_t, [c_int]),
+    "rd_pack_block64_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rd_block64_bn_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -203,12 +203,14 @@ class Lib:
         return out
 
     def pack_block64(self, w1_oihw, scale1, w2_oihw, scale2, dtype=RD_BF16):
-        """weights of rd_block64_bn_act: the two (64, 64, 3, 3) convs of a BasicBlock with their BatchNorm scales folded in"""
+        """weights of rd_block64_bn_act: the two 3x3 convs of a BasicBlock, (64, cin, 3, 3) with cin = 64 or <= 16 and (64, 64, 3, 3), with
+        their BatchNorm scales folded in"""
         w1, w2 = (np.ascontiguousarray(w, dtype=np.float32) for w in (w1_oihw, w2_oihw))
         s1, s2 = (np.ascontiguousarray(v, dtype=np.float32) for v in (scale1, scale2))
-        assert w1.shape == (64, 64, 3, 3) and w2.shape == (64, 64, 3, 3) and s1.shape == (64,) and s2.shape == (64,)
-        out = np.zeros(self.cdll.rd_block64_packed_bytes(), dtype=np.uint8)
-        self.call("rd_pack_block64_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, dtype, out.ctypes.data)
+        cin = w1.shape[1]
+        assert w1.shape == (64, cin, 3, 3) and w2.shape == (64, 64, 3, 3) and s1.shape == (64,) and s2.shape == (64,)
+        out = np.zeros(self.cdll.rd_block64_packed_bytes(cin), dtype=np.uint8)
+        self.call("rd_pack_block64_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, cin, dtype, out.ctypes.data)
         return out
 
     def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype, fold_scale=None):

@@ -188,23 +188,29 @@ class Lowering:
                 if isinstance(v, TRef):
                     uses.setdefault(v.buf, []).append((i, key))
 
-        def plain64(st):
-            return (st["kind"] == "conv" and tuple(st["k"]) == (3, 3) and st["stride_w"] == 1 and st["cin"] == 64 and st["cout"] == 64 and
-                    st.get("ex") and st.get("fold") and not st.get("head") and st.get("x2") is None and not st.get("cmap") and
-                    st["x"].C == 64 and st["x"].tail is None)
+        def plain64(st, first=False):
+            """a folded 3x3 stride-1 conv to 64 channels from 64 channels -- or, as conv1 of the network's first block, from one
+            16-channel granule (the 8-channel range image / KITTI's 5 channels in a zero-padded 16-channel buffer)"""
+            if not (st["kind"] == "conv" and tuple(st["k"]) == (3, 3) and st["stride_w"] == 1 and st["cout"] == 64 and st.get("ex") and
+                    st.get("fold") and not st.get("head") and st.get("x2") is None and st["x"].tail is None):
+                return False
+            if first and st["x"].cs - st["x"].co == 16 and st["x"].C <= 16:
+                return not os.environ.get("RD_NO_FUSE_FIRST")      # (A/B switch: keep the first block as two launches)
+            return st["cin"] == 64 and st["x"].C == 64 and not st.get("cmap")
 
         out, i = [], 0
         while i < len(steps):
             a = steps[i]
             b = steps[i + 1] if i + 1 < len(steps) else None
-            ok = b is not None and plain64(a) and plain64(b) and a["flags"] == RD_RELU_POST and a["res"] is None and not a.get("sc") and \
+            ok = b is not None and plain64(a, first=True) and plain64(b) and a["flags"] == RD_RELU_POST and a["res"] is None and not a.get("sc") and \
                 b["flags"] == (RD_ADD | RD_RELU_POST) and b["x"] == a["out"] and a["out"].co == 0 and a["out"].cs == 64 and \
                 sorted(uses.get(a["out"].buf, [])) == [(i, "out"), (i + 1, "x")] and b["out"].buf != a["x"].buf
             if ok:
-                if b.get("sc"):      # projection shortcut of the block input (64 channels, no channel map)
-                    ok = b["res"] is None and b["sc_x"] == a["x"] and b["sc"]["cin"] == 64 and not b["sc"].get("cmap")
+                small = a["x"].C <= 16
+                if b.get("sc"):      # projection shortcut of the block input (the same tensor conv1 reads)
+                    ok = b["res"] is None and b["sc_x"] == a["x"] and (small or (b["sc"]["cin"] == 64 and not b["sc"].get("cmap")))
                 else:                # identity shortcut: the residual IS the block input
-                    ok = b["res"] == a["x"]
+                    ok = b["res"] == a["x"] and not small
             if ok:
                 blk = dict(kind="block", name=a["name"] + " + " + b["name"], a=a, b=b, x=a["x"], out=b["out"])
                 a["in_block"] = b["in_block"] = True

@@ -149,6 +149,12 @@ class Executor:
         if k == "block":   # a fused BasicBlock (lower._fuse_blocks): both 3x3 weights in one image, the shortcut's as for the unfused conv2
             ca, cb = st["a"], st["b"]
             w1, w2 = (np.asarray(P[c["name"] + "_weight"], np.float32) for c in (ca, cb))
+            if ca.get("cmap"):   # (the first block's input buffer carries alignment padding: zero weight columns there)
+                wp = np.zeros((w1.shape[0], len(ca["cmap"])) + w1.shape[2:], np.float32)
+                for pc, lc in enumerate(ca["cmap"]):
+                    if lc >= 0:
+                        wp[:, pc] = w1[:, lc]
+                w1 = wp
             (s1, t1), (s2, t2) = bn_affine(P, ca["bn"], ca["eps"]), bn_affine(P, cb["bn"], cb["eps"])
             b["w"] = A.upload(L.pack_block64(w1, s1, w2, s2, dtype=dt))
             b["shift1"] = A.upload(t1)
@@ -156,10 +162,17 @@ class Executor:
             if cb.get("sc"):
                 sc = cb["sc"]
                 wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(64, -1)
+                if sc.get("cmap"):
+                    wq = np.zeros((64, len(sc["cmap"])), np.float32)
+                    for pc, lc in enumerate(sc["cmap"]):
+                        if lc >= 0:
+                            wq[:, pc] = wsc[:, lc]
+                    wsc = wq
                 ss, ts = bn_affine(P, sc["bn"], sc["eps"])
                 b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 t2 = (t2.astype(np.float64) + ts).astype(np.float32)
             b["shift2"] = A.upload(t2)
+            b["cin"] = w1.shape[1]
             return b
         if k == "conv":
             w = np.asarray(P[st["name"] + "_weight"], np.float32)
@@ -275,7 +288,7 @@ class Executor:
                 L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
             elif k == "block":
                 x, o = b["x"], b["out"]
-                L.call("rd_block64_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["shift1"]), A.ptr(b["shift2"]),
+                L.call("rd_block64_bn_act", self.p(x), x.cs, x.co, b["cin"], A.ptr(b["w"]), A.ptr(b["shift1"]), A.ptr(b["shift2"]),
                        A.ptr(b["sc_w"]) if b["sc_w"] is not None else None, self.p(o), o.cs, o.co, B, x.H, x.W, dt, st_)
             elif k == "conv_pair":
                 # two convs of one shape in ONE launch (lower._pair_equal_convs: the cls and reg tower conv of a head level)

@@ -39,11 +39,11 @@ def test_config_and_full_graph_lowering(monkeypatch):
     # bf16: the six 1x1 output convs ride in the epilogue of their tower's last conv (lower._fuse_head_out) and the nine
     # 1x1 projection shortcuts in the epilogue of their block's second conv (lower._fusable_projection)
     # round 5: the seven 64-channel stride-1 BasicBlocks whose intermediate tensor has one reader are ONE launch each (lower._fuse_blocks,
-    # rd_block64_bn_act): 73 convs = 59 launches + 7 blocks of two
-    assert kinds["conv"] == 59 and kinds["block"] == 7 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
+    # rd_block64_bn_act), the network's first block (8 -> 64 -> 64) included: 73 convs = 57 launches + 8 blocks of two
+    assert kinds["conv"] == 57 and kinds["block"] == 8 and kinds["deconv"] == 4 and kinds["meta"] == 1 and kinds["head_out"] == 0
     assert [s["name"] for s in plan.steps if s["kind"] == "block"] == [n + "_conv1 + " + n + "_conv2" for n in (
-        "res2a_unit2", "res2a_unit3", "agg2a_res_unit1", "agg1_res_unit1", "agg1_res_unit2", "agg3_res_unit1", "agg3_res_unit2")]
-    assert [bool(s["b"].get("sc")) for s in plan.steps if s["kind"] == "block"] == [False, False, True, True, False, True, False]
+        "res1_unit1", "res2a_unit2", "res2a_unit3", "agg2a_res_unit1", "agg1_res_unit1", "agg1_res_unit2", "agg3_res_unit1", "agg3_res_unit2")]
+    assert [bool(s["b"].get("sc")) for s in plan.steps if s["kind"] == "block"] == [True, False, False, True, True, False, True, False]
     inter = {s["a"]["out"].buf for s in plan.steps if s["kind"] == "block"}
     assert not inter & set(plan.buffers), "the intermediate tensor of a fused block has no buffer"
     monkeypatch.setenv("RD_NO_FUSE_BLOCK", "1")
@@ -57,7 +57,7 @@ def test_config_and_full_graph_lowering(monkeypatch):
     pplan = lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
     monkeypatch.delenv("RD_PAIR")
     pk = Counter(s["kind"] for s in pplan.steps)
-    assert pk["conv"] == 35 and pk["block"] == 7 and pk["conv_pair"] == 12 and pk["deconv"] == 4 and pk["meta"] == 1
+    assert pk["conv"] == 33 and pk["block"] == 8 and pk["conv_pair"] == 12 and pk["deconv"] == 4 and pk["meta"] == 1
     for s in pplan.steps:
         if s["kind"] == "conv_pair":
             na, nb = s["a"]["name"], s["b"]["name"]
@@ -66,7 +66,7 @@ def test_config_and_full_graph_lowering(monkeypatch):
     assert order[:4] == ["rpn_cls_conv_%d_lvl_0 + rpn_reg_conv_%d_lvl_0" % (i, i) for i in range(4)]
     assert sorted(s["name"] for s, _ in conv_steps(pplan.steps)) == sorted(s["name"] for s, _ in conv_steps(plan.steps))
     # (launch counts: a transposed conv is ONE launch -- all its phases, rd_deconv2d_bn_act_all)
-    assert sum(n for _, n in conv_steps(pplan.steps)) == 35 + 7 + 12 + 4 and sum(n for _, n in conv_steps(plan.steps)) == 59 + 7 + 4
+    assert sum(n for _, n in conv_steps(pplan.steps)) == 33 + 8 + 12 + 4 and sum(n for _, n in conv_steps(plan.steps)) == 57 + 8 + 4
     assert all(s["one_launch"] for s in plan.steps if s["kind"] == "deconv")
     scs = [s for s, _ in conv_steps(plan.steps) if s.get("sc")]
     assert sorted(s["sc"]["name"] for s in scs) == sorted(n + "_unit1_sc" for n in (
@@ -704,7 +704,7 @@ def test_e2e_bf16_tolerance(be, dt, monkeypatch):
     # (the reduced graph's one-layer towers read the never-materialised concat [agg3 | range image] directly at level 0: that two-tensor
     #  launch has no fused output conv, the level's two 1x1 output convs stay separate launches there)
     assert sum(1 for s, _ in conv_steps(plan.steps) if s.get("sc")) == 9 and sum(1 for s, _ in conv_steps(plan.steps) if s.get("head")) == (4 if emu else 6)
-    assert sum(1 for s in plan.steps if s["kind"] == "block") == (3 if emu else 7)      # fused BasicBlocks (lower._fuse_blocks) run in both graphs
+    assert sum(1 for s in plan.steps if s["kind"] == "block") == (4 if emu else 8)      # fused BasicBlocks (lower._fuse_blocks) run in both graphs
     assert sum(1 for s in plan.steps if s.get("x2") is not None) == 2 and sum(1 for s in plan.steps if s["kind"] == "nchw_in") == 1
     P = synth.make_weights(seed=18, width=W, cls_bias=-0.5)
     fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)

@@ -711,21 +711,24 @@ def test_conv3x3_cat_two_tensor_input(be, case):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-@pytest.mark.parametrize("case", [(BF16, 2, 16, 72, False, 64), (BF16, 1, 11, 33, True, 64), (F16, 1, 8, 100, False, 80), (BF16, 3, 24, 64, True, 80),
-                                  (F16, 2, 9, 40, True, 64)], ids=lambda c: "-".join(str(v) for v in c))
+@pytest.mark.parametrize("case", [(BF16, 2, 16, 72, False, 64, 64), (BF16, 1, 11, 33, True, 64, 64), (F16, 1, 8, 100, False, 80, 64), (BF16, 3, 24, 64, True, 80, 64),
+                                  (F16, 2, 9, 40, True, 64, 64), (BF16, 2, 16, 72, True, 16, 8), (F16, 1, 11, 33, True, 16, 5), (BF16, 3, 24, 64, True, 16, 16)],
+                         ids=lambda c: "-".join(str(v) for v in c))
 def test_block64_equals_the_two_launches(be, case):
     """rd_block64_bn_act (csrc/k_block.h): a 64-channel BasicBlock -- conv1 3x3 + BN + ReLU, conv2 3x3 + BN, + identity or 1x1 projection
     shortcut, ReLU (dla_backbone.py:18-56) -- as ONE launch whose intermediate tensor stays in LDS.  BIT-IDENTICAL to the two
     rd_conv3x3_bn_act_ex launches it replaces (same MFMA sequence per accumulator, the intermediate rounded once like the stored
     tensor), and within one rounding per conv of torch on the same 16-bit weights.  Partial tiles in both directions, several tiles per
     workgroup (the x prefetch of the next tile into the buffer the intermediate just left), both shortcut forms, both 16-bit types, an
-    input with a channel stride beyond its 64 channels."""
-    dt, B, H, W, proj, xcs = case
-    rng = np.random.default_rng(B * 100 + H + W)
+    input with a channel stride beyond its 64 channels, and the network's FIRST block: 8 (KITTI: 5) input channels in a 16-channel
+    buffer, conv1 as five two-tap steps (the unfused launch's own form for <= 16 channels)."""
+    dt, B, H, W, proj, xcs, cin = case
+    rng = np.random.default_rng(B * 100 + H + W + cin)
     L = be.lib
-    x = h16_round(rng.standard_normal((B, 64, H, W)).astype(np.float32), dt)
-    w1, w2 = ((rng.standard_normal((64, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32) for _ in range(2))
-    wsc = (rng.standard_normal((64, 64)) / 8).astype(np.float32)
+    x = h16_round(rng.standard_normal((B, cin, H, W)).astype(np.float32), dt)
+    w1 = (rng.standard_normal((64, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    w2 = (rng.standard_normal((64, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    wsc = (rng.standard_normal((64, cin)) / np.sqrt(cin)).astype(np.float32)
     s1, s2, ss = (rng.uniform(0.5, 1.5, 64).astype(np.float32) for _ in range(3))
     t1, t2, ts = (rng.standard_normal(64).astype(np.float32) * 0.3 for _ in range(3))
     sh2 = (t2.astype(np.float64) + ts).astype(np.float32) if proj else t2
@@ -735,13 +738,13 @@ def test_block64_equals_the_two_launches(be, case):
     d1, d2 = be.up(t1), be.up(sh2)
     t, yr, y = be.empty(B * H * W * 64 * 2), be.empty(B * H * W * 64 * 2), be.empty(B * H * W * 64 * 2)
     FO = R.RD_SCALE_FOLDED
-    L.call("rd_conv3x3_bn_act_ex", be.ptr(dx), xcs, 0, be.ptr(p1), None, be.ptr(d1), None, 0, 0, None, 0, 0, 0, None, be.ptr(t), 64, 0, B, H, W, 64, 64, 1,
+    L.call("rd_conv3x3_bn_act_ex", be.ptr(dx), xcs, 0, be.ptr(p1), None, be.ptr(d1), None, 0, 0, None, 0, 0, 0, None, be.ptr(t), 64, 0, B, H, W, cin, 64, 1,
            R.RD_RELU_POST | FO, dt, be.stream)
     L.call("rd_conv3x3_bn_act_ex", be.ptr(t), 64, 0, be.ptr(p2), None, be.ptr(d2), None if proj else be.ptr(dx), 0 if proj else xcs, 0,
-           be.ptr(dx) if proj else None, xcs if proj else 0, 0, 64 if proj else 0, be.ptr(psc) if proj else None, be.ptr(yr), 64, 0, B, H, W, 64, 64, 1,
+           be.ptr(dx) if proj else None, xcs if proj else 0, 0, cin if proj else 0, be.ptr(psc) if proj else None, be.ptr(yr), 64, 0, B, H, W, 64, 64, 1,
            R.RD_ADD | R.RD_RELU_POST | FO, dt, be.stream)
     pk = be.up(L.pack_block64(w1, s1, w2, s2, dtype=dt))
-    L.call("rd_block64_bn_act", be.ptr(dx), xcs, 0, be.ptr(pk), be.ptr(d1), be.ptr(d2), be.ptr(psc) if proj else None, be.ptr(y), 64, 0, B, H, W, dt, be.stream)
+    L.call("rd_block64_bn_act", be.ptr(dx), xcs, 0, cin, be.ptr(pk), be.ptr(d1), be.ptr(d2), be.ptr(psc) if proj else None, be.ptr(y), 64, 0, B, H, W, dt, be.stream)
     got, two = be.down(y, np.uint16, (B, H, W, 64)), be.down(yr, np.uint16, (B, H, W, 64))
     assert np.array_equal(got, two), int((got != two).sum())
     # ... and the pair itself against torch, conv by conv on the device's own intermediate (one output rounding each)
@@ -755,10 +758,12 @@ def test_block64_equals_the_two_launches(be, case):
     assert np.abs(from_nhwc(got, dt, 64) - r2).max() <= 1.5 * _tol(dt, r2)
     f = L.raw("rd_block64_bn_act")
     p = be.ptr(be.empty(1 << 16))
-    assert f(p, 64, 0, p, p, p, None, p, 64, 0, 1, 4, 8, R.RD_F32, be.stream) == R.RD_EINVAL             # 16-bit types only
-    assert f(p, 64, 8, p, p, p, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                   # 64 channels do not fit the stride
     q = be.ptr(be.empty(1 << 16))
-    assert f(p, 64, 0, q, q, q, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                   # in place
+    assert f(p, 64, 0, 64, q, q, q, None, q, 64, 0, 1, 4, 8, R.RD_F32, be.stream) == R.RD_EINVAL          # 16-bit types only
+    assert f(p, 64, 8, 64, q, q, q, None, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                # 64 channels do not fit the stride
+    assert f(p, 64, 0, 64, q, q, q, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                # in place
+    assert f(p, 32, 0, 32, q, q, q, None, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                # 32 input channels: not a form
+    assert f(p, 16, 0, 8, q, q, q, None, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                 # first block without its projection shortcut
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

@@ -164,13 +164,19 @@ def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
             L_, A_ = be.lib, be.alloc
             (s1, t1), (s2, t2) = bn_affine(P, a_["bn"], a_["eps"]), bn_affine(P, b_["bn"], b_["eps"])
             w1, w2 = (np.asarray(P[c_["name"] + "_weight"], np.float32) for c_ in (a_, b_))
+            w1 = _expand(w1, a_.get("cmap"))
+            cin1 = w1.shape[1]
+            if x.shape[1] < cin1:     # (the first block: the buffer's zero channels past the real ones)
+                x = torch.cat([x, torch.zeros(x.shape[0], cin1 - x.shape[1], x.shape[2], x.shape[3])], 1)
             p1 = A_.upload(L_.pack_conv3x3_ex(w1, 1, xr.cs, fold_scale=s1, dtype=dt))
             p2 = A_.upload(L_.pack_conv3x3_ex(w2, 1, 64, fold_scale=s2, dtype=dt))
             shift2 = t2.astype(np.float64)
             psc = None
             if b_.get("sc"):
                 sc = b_["sc"]
-                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(64, -1)
+                wsc = _expand(np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(64, -1), sc.get("cmap"))
+                if wsc.shape[1] < cin1:
+                    wsc = np.concatenate([wsc, np.zeros((64, cin1 - wsc.shape[1]), np.float32)], 1)
                 ss, ts = bn_affine(P, sc["bn"], sc["eps"])
                 psc = A_.upload(L_.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 shift2 = shift2 + ts
@@ -180,10 +186,10 @@ def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
             tr, yr = TRef(-1, 64, xr.H, xr.W, 64, 0), TRef(-2, 64, xr.H, xr.W, 64, 0)
             FO = R.RD_SCALE_FOLDED
             L_.call("rd_conv3x3_bn_act_ex", exe.p(xr), xr.cs, xr.co, A_.ptr(p1), None, A_.ptr(d1), None, 0, 0, None, 0, 0, 0, None, exe.p(tr), 64, 0,
-                    B, xr.H, xr.W, 64, 64, 1, R.RD_RELU_POST | FO, dt, A_.stream)
+                    B, xr.H, xr.W, cin1, 64, 1, R.RD_RELU_POST | FO, dt, A_.stream)
             L_.call("rd_conv3x3_bn_act_ex", exe.p(tr), 64, 0, A_.ptr(p2), None, A_.ptr(d2), None if psc is not None else exe.p(xr),
                     0 if psc is not None else xr.cs, 0 if psc is not None else xr.co, exe.p(xr) if psc is not None else None,
-                    xr.cs if psc is not None else 0, xr.co if psc is not None else 0, 64 if psc is not None else 0,
+                    xr.cs if psc is not None else 0, xr.co if psc is not None else 0, cin1 if psc is not None else 0,
                     A_.ptr(psc) if psc is not None else None, exe.p(yr), 64, 0, B, xr.H, xr.W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | FO, dt, A_.stream)
             t_dev = torch.from_numpy(np.ascontiguousarray(exe.debug_tensor(tr)))
             y_two = torch.from_numpy(np.ascontiguousarray(exe.debug_tensor(yr)))
@@ -325,6 +331,6 @@ def test_every_production_launch_tight_at_full_geometry(be, dt, variant):
     print("%d distinct launch forms, %d steps checked, %.0f s" % (len(seen_forms), len(report), time.time() - t00))
     kinds = [s["kind"] for s in plan.steps]
     # (a fused BasicBlock reports three lines: bit-equality with its two launches, conv1, conv2)
-    assert kinds.count("conv") + 2 * kinds.count("block") + kinds.count("deconv") + kinds.count("meta") == 78 and kinds.count("block") == 7
+    assert kinds.count("conv") + 2 * kinds.count("block") + kinds.count("deconv") + kinds.count("meta") == 78 and kinds.count("block") == 8
     assert len(report) == kinds.count("conv") + 3 * kinds.count("block") + kinds.count("deconv") + kinds.count("meta")
     assert not failed, failed

@@ -2,14 +2,14 @@
 // (hipcc --offload-arch=gfx950 -O3 -shared -fPIC) and for the CPU emulator (tests/emu shim), tools/micro/block_dev.py drives both.
 #include "../../rangedet_amd/csrc/k_block.h"
 extern "C" {
-size_t rdm_block64_packed_bytes(void) { return rd::block64_packed_bytes(); }
-int rdm_pack_block64_host(const float* w1, const float* s1, const float* w2, const float* s2, int dtype, void* out) {
-  rd::pack_block64(w1, s1, w2, s2, dtype, out);
+size_t rdm_block64_packed_bytes(int cin) { return rd::block64_packed_bytes(cin); }
+int rdm_pack_block64_host(const float* w1, const float* s1, const float* w2, const float* s2, int cin, int dtype, void* out) {
+  rd::pack_block64(w1, s1, w2, s2, cin, dtype, out);
   return 0;
 }
-int rdm_block64(const void* x, int x_cs, int x_co, const void* w, const float* shift1, const float* shift2, const void* sc_w, void* y,
+int rdm_block64(const void* x, int x_cs, int x_co, int cin, const void* w, const float* shift1, const float* shift2, const void* sc_w, void* y,
                 int y_cs, int y_co, int B, int H, int W, int dtype, void* stream) {
-  return rd::launch_block64(x, x_cs, x_co, w, shift1, shift2, sc_w, y, y_cs, y_co, B, H, W, dtype, (hipStream_t)stream);
+  return rd::launch_block64(x, x_cs, x_co, cin, w, shift1, shift2, sc_w, y, y_cs, y_co, B, H, W, dtype, (hipStream_t)stream);
 }
 const char* rdm_last_error(void) { return rd::err_buf(); }
 }

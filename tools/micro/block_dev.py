@@ -21,8 +21,9 @@ c_int, c_void_p = ctypes.c_int, ctypes.c_void_p
 def bind(path):
     m = ctypes.CDLL(path)
     m.rdm_block64_packed_bytes.restype = ctypes.c_size_t
-    m.rdm_pack_block64_host.argtypes = [c_void_p] * 4 + [c_int, c_void_p]
-    m.rdm_block64.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    m.rdm_block64_packed_bytes.argtypes = [c_int]
+    m.rdm_pack_block64_host.argtypes = [c_void_p] * 4 + [c_int, c_int, c_void_p]
+    m.rdm_block64.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     m.rdm_last_error.restype = ctypes.c_char_p
     return m
 
@@ -39,8 +40,8 @@ def weights(seed):
 
 
 def pack_block(m, w1, s1, w2, s2, dt):
-    out = np.zeros(m.rdm_block64_packed_bytes(), np.uint8)
-    m.rdm_pack_block64_host(w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, dt, out.ctypes.data)
+    out = np.zeros(m.rdm_block64_packed_bytes(w1.shape[1]), np.uint8)
+    m.rdm_pack_block64_host(w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, w1.shape[1], dt, out.ctypes.data)
     return out
 
 
@@ -51,6 +52,35 @@ if mode == "emu":
         subprocess.check_call("/opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -shared -DRD_BUILD_NUM_CUS=4 -DRD_BUILD_F16_PRODUCTION_FORMS_ONLY "
                               "-Itests/emu -Iinclude tools/micro/block_dev.hip -o %s 2>/dev/null" % so, shell=True, cwd=ROOT)
     m, L = bind(so), emu_lib()
+    # the network's first block: 8 input channels in a 16-channel buffer, projection shortcut
+    for (B, H, W, dt, cin) in ((2, 16, 72, R.RD_BF16, 8), (3, 24, 64, R.RD_F16, 5)):
+        rng = np.random.default_rng(H + W)
+        w1, s1, t1, w2, s2, t2 = weights(B + H)
+        w1 = (rng.standard_normal((64, cin, 3, 3)) * 0.1).astype(np.float32)
+        wsc = (rng.standard_normal((64, cin)) * 0.3).astype(np.float32)
+        ss = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+        xf = np.zeros((B, H, W, 16), np.float32)
+        xf[..., :cin] = rng.standard_normal((B, H, W, cin))
+        xb = f32_to_bf16_bits(xf) if dt == R.RD_BF16 else xf.astype(np.float16).view(np.uint16)
+        p1 = L.pack_conv3x3_ex(w1, 1, 16, fold_scale=s1, dtype=dt)
+        p2 = L.pack_conv3x3_ex(w2, 1, 64, fold_scale=s2, dtype=dt)
+        psc = L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt)
+        t = np.zeros((B, H, W, 64), np.uint16)
+        yr = np.zeros((B, H, W, 64), np.uint16)
+        L.call("rd_conv3x3_bn_act_ex", xb.ctypes.data, 16, 0, p1.ctypes.data, None, t1.ctypes.data, None, 0, 0, None, 0, 0, 0, None,
+               t.ctypes.data, 64, 0, B, H, W, cin, 64, 1, R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, None)
+        L.call("rd_conv3x3_bn_act_ex", t.ctypes.data, 64, 0, p2.ctypes.data, None, t2.ctypes.data, None, 0, 0, xb.ctypes.data, 16, 0, cin, psc.ctypes.data,
+               yr.ctypes.data, 64, 0, B, H, W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, None)
+        pk = pack_block(m, w1, s1, w2, s2, dt)
+        y = np.full((B, H, W, 64), 0x7fc0, np.uint16)
+        rc = m.rdm_block64(xb.ctypes.data, 16, 0, cin, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, psc.ctypes.data, y.ctypes.data, 64, 0, B, H, W, dt, None)
+        assert rc == 0, m.rdm_last_error()
+        bad = y != yr
+        print("FIRST block cin %d B %d H %d W %d dt %d: %d of %d values differ from the unfused pair" % (cin, B, H, W, dt, int(bad.sum()), bad.size), flush=True)
+        if bad.any():
+            idx = np.argwhere(bad)
+            print("  first mismatches (b, h, w, c):", idx[:8].tolist())
+            sys.exit(1)
     for (B, H, W, dt) in ((2, 16, 72, R.RD_BF16), (1, 11, 33, R.RD_BF16), (1, 8, 100, R.RD_F16), (3, 24, 64, R.RD_BF16)):
         w1, s1, t1, w2, s2, t2 = weights(B + H)
         rng = np.random.default_rng(7 * H + W)
@@ -67,7 +97,7 @@ if mode == "emu":
                yr.ctypes.data, 64, 0, B, H, W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, None)
         pk = pack_block(m, w1, s1, w2, s2, dt)
         y = np.full((B, H, W, 64), 0x7fc0, np.uint16)
-        rc = m.rdm_block64(xb.ctypes.data, 64, 0, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, None, y.ctypes.data, 64, 0, B, H, W, dt, None)
+        rc = m.rdm_block64(xb.ctypes.data, 64, 0, 64, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, None, y.ctypes.data, 64, 0, B, H, W, dt, None)
         assert rc == 0, m.rdm_last_error()
         bad = y != yr
         print("B %d H %d W %d dt %d: %d of %d values differ from the unfused pair" % (B, H, W, dt, int(bad.sum()), bad.size), flush=True)
@@ -103,7 +133,7 @@ else:
                        yr[i].data_ptr(), 64, 0, B, H, W, 64, 64, 1, R.RD_ADD | R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, st)
 
             def fused(i):
-                rc = m.rdm_block64(xs[i].data_ptr(), 64, 0, pk.data_ptr(), T1.data_ptr(), T2.data_ptr(), None, yf[i].data_ptr(), 64, 0, B, H, W, dt, st)
+                rc = m.rdm_block64(xs[i].data_ptr(), 64, 0, 64, pk.data_ptr(), T1.data_ptr(), T2.data_ptr(), None, yf[i].data_ptr(), 64, 0, B, H, W, dt, st)
                 assert rc == 0, m.rdm_last_error()
             for i in range(NB):
                 unfused(i)

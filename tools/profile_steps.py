@@ -42,8 +42,9 @@ for i, st in enumerate(pipe.plan.steps):
         desc = "%s %d->%d x2 W%d" % (st["name"].replace("rpn_", "").replace("_conv", ""), a["cin"], a["cout"], o.W)
     elif k == "block":     # a fused 64-channel BasicBlock: the FLOPs of its two convs (+ the 1x1 shortcut)
         o = st["out"]
-        fl = B * 2.0 * o.H * o.W * 64 * 64 * (18 + (1 if st["b"].get("sc") else 0))
-        desc = "%s 64->64->64 W%d%s" % (st["name"].replace("_conv1 + ", " + ").split(" + ")[0] + " block", o.W, " +sc" if st["b"].get("sc") else "")
+        c1 = st["a"]["cin"]
+        fl = B * 2.0 * o.H * o.W * 64 * (9 * c1 + 9 * 64 + (c1 if st["b"].get("sc") else 0))
+        desc = "%s %d->64->64 W%d%s" % (st["name"].replace("_conv1 + ", " + ").split(" + ")[0] + " block", c1, o.W, " +sc" if st["b"].get("sc") else "")
     elif k in ("conv", "deconv"):
         o = st["out"]
         fl = B * 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
