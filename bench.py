@@ -506,6 +506,7 @@ def main(argv=None):
                                     "intermediate tensor in LDS)", "launches_per_step": n_b, "avg_launch_ms": avg_b,
                           "gflop_per_launch": fl_b * Bf / n_b / 1e9, "tflops_algorithmic": (fl_b * Bf / n_b) / (avg_b * 1e-3) / 1e12 if cnt_b else 0.0,
                           "algorithmic_bytes_per_launch_unfused_model": by_b,
+                          "traffic": measured_traffic("block64_stream_kernel", Bf),     # HBM bytes per launch by the PMC passes (null: kernels changed since)
                           "note": "FLOPs = those of the two 3x3 convs (+ 1x1 shortcut) the launch replaces; the kernel executes 1.25x that "
                                   "(conv1 on the 10 x 34 halo of every 8 x 32 tile)"}
         roof = {"kernel": "conv3x3_stream_kernel (persistent 3x3 implicit-GEMM conv / transposed-conv phase + BN + ReLU + residual)" if bf

@@ -9,7 +9,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"conv3x3_stream_kernel": "conv3x3_stream_kernel", "conv1x1_stream_kernel": "conv1x1_stream_kernel",
+KERNELS = {"conv3x3_stream_kernel": "conv3x3_stream_kernel", "block64_stream_kernel": "block64_stream_kernel", "conv1x1_stream_kernel": "conv1x1_stream_kernel",
            "conv_taps_kernel": "conv_taps_kernel", "input_transform_kernel": "input_transform_kernel",
            "meta16_kernel": "meta_kernel", "meta_bf16_kernel": "meta_kernel", "head_out_mfma_kernel": "head_out_mfma_kernel"}
 batch = int(sys.argv[1])
