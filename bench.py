@@ -265,6 +265,10 @@ def main(argv=None):
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
     ap.add_argument("--wnms-cap", type=int, default=8192, help="rows per frame the weighted NMS is sized for (checked every step)")
+    ap.add_argument("--backbone-reps", type=int, default=10,
+                    help="replays of the Meta-Kernel + DLA backbone steps for the `meta_dla_forward` block (0: skip that block -- the rocprofv3 / PMC "
+                         "passes of tools/profile_round.sh use 0 so that every profiled launch belongs to a full forward and the per-kernel averages "
+                         "are those of the `roofline` block)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of --steps steps (barrier + synchronize on both sides) is run this many times back to back; "
                          "`value` / `ms_per_step` are the MEDIAN region, the spread is reported next to it (SURVEY.md 8d: median + p5/p95)")
@@ -546,17 +550,18 @@ def main(argv=None):
         meta_info["frac"] = meta_info["achieved"] / PEAK_HBM_GBPS
         meta_info["intensity_flop_per_byte"] = META_FLOP_PER_PX * NPIX * Bf / mbytes
         meta_info["traffic"] = measured_traffic("meta_kernel", Bf) if dt == rdlib.RD_BF16 else None
-        backbone_info = backbone_forward_roofline(pipe, frames[0], Bf, esz, reps=10)
+        backbone_info = backbone_forward_roofline(pipe, frames[0], Bf, esz, reps=args.backbone_reps) if args.backbone_reps > 0 else None
         # headline figure of the Meta-Kernel = the kernel with nothing else resident; in the pipeline the previous batch's NMS
         # kernels (side stream) co-run with it and its launch-to-end time is longer -- both are reported
-        alone = backbone_info.pop("meta_kernel_alone")
-        meta_info.update({"in_pipeline_avg_launch_ms": meta_info["avg_launch_ms"], "in_pipeline_gbps": meta_info["achieved"],
-                          "avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["gbps"], "frac": alone["frac_hbm_peak"],
-                          "tflops": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12,
-                          "frac_mfma_peak": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                          "binding_roof": "mfma (433 FLOP/B is above the ridge of 312 FLOP/B); in practice the latency of its dependent "
-                                          "MFMA -> vector -> MFMA chains at two waves per SIMD (DESIGN.md section 6.3)",
-                          "note": "achieved / avg_launch_ms: serial replay of the kernel alone (HIP events); in_pipeline_*: the "
+        alone = backbone_info.pop("meta_kernel_alone") if backbone_info else None
+        if alone:
+          meta_info.update({"in_pipeline_avg_launch_ms": meta_info["avg_launch_ms"], "in_pipeline_gbps": meta_info["achieved"],
+                            "avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["gbps"], "frac": alone["frac_hbm_peak"],
+                            "tflops": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12,
+                            "frac_mfma_peak": Bf * META_FLOP_PER_PX * NPIX / (alone["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                            "binding_roof": "mfma (433 FLOP/B is above the ridge of 312 FLOP/B); in practice the latency of its dependent "
+                                            "MFMA -> vector -> MFMA chains at two waves per SIMD (DESIGN.md section 6.3)",
+                            "note": "achieved / avg_launch_ms: serial replay of the kernel alone (HIP events); in_pipeline_*: the "
                                   "same launch inside the timed pipeline, where the previous batch's NMS kernels share the GPU"})
 
     if rank == 0:

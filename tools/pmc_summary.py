@@ -30,7 +30,7 @@ for d in sys.argv[2:]:
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rangedet_amd.build import source_hash  # noqa: E402
 res = {"csrc_sha16": source_hash(), "command": "rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -- python bench.py --steps 3 --warmup 1 "
-                  "--no-cpu-baseline  (one pass per counter group)", "batch": batch,
+                  "--repeats 1 --backbone-reps 0 --no-cpu-baseline --inflight 1  (one pass per counter group)", "batch": batch,
        "note": "per-dispatch means; FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 "
                "FETCH correction, MI355X_MICROARCH.md HBM section)"}
 for k, cs in acc.items():

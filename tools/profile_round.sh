@@ -2,11 +2,13 @@
 # flight, PMC passes (separate --pmc runs, kernel-trace only), per-plan-step timing.  Results under gpurun_out/p; copy the
 # summaries into profiles/ (see profiles/README.md).   usage: bash tools/profile_round.sh [tag, e.g. r04c]
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/p
+# (--backbone-reps 0 in the rocprofv3 / PMC passes: no stand-alone backbone replay, so every profiled launch belongs to a full forward and
+#  the per-kernel means are those of the bench's `roofline` block)
 # per-kernel durations: one batch in flight (kernels of two batches overlapping would inflate each other's durations; the
 # bench's roofline block times its kernels in a serial replay on one stream, which is what this pass must agree with)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats -- python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --inflight 1 > gpurun_out/p/stats.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats2 -- python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > gpurun_out/p/stats2.log 2>&1
-i=0; for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do i=$((i+1)); timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/p/pmc$i -- python bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --inflight 1 > gpurun_out/p/pmc$i.log 2>&1; done
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats -- python bench.py --steps 10 --warmup 3 --repeats 1 --backbone-reps 0 --no-cpu-baseline --inflight 1 > gpurun_out/p/stats.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p/stats2 -- python bench.py --steps 10 --warmup 3 --repeats 1 --backbone-reps 0 --no-cpu-baseline > gpurun_out/p/stats2.log 2>&1
+i=0; for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do i=$((i+1)); timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/p/pmc$i -- python bench.py --steps 3 --warmup 1 --repeats 1 --backbone-reps 0 --no-cpu-baseline --inflight 1 > gpurun_out/p/pmc$i.log 2>&1; done
 python tools/pmc_summary.py 8 gpurun_out/p/pmc1 gpurun_out/p/pmc2 gpurun_out/p/pmc3 > gpurun_out/p/pmc_traffic.json 2>gpurun_out/p/pmc_summary.err
 # (the bench line is taken AFTER the PMC passes so that it can quote their traffic: `profile_round.sh r04c` puts the summary where
 #  bench.py looks for it -- profiles/<tag>_pmc_traffic.json, keyed on the hash of the kernel sources)
