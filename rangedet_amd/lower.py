@@ -354,14 +354,19 @@ class Lowering:
             raise NotImplementedError("Convolution %s with bias followed by BatchNorm" % conv.name)
         x = self.emit_act(conv.inputs[0])
         k, sw, Wout = self._conv_geom(conv, x)
-        cout = conv.attrs["num_filter"]
-        if cout not in (64, 128):
+        cout_l = conv.attrs["num_filter"]          # logical output channels (BackboneParam.num_filter, dla_backbone.py:59-103,130-161)
+        # The conv kernels are instantiated for 64 and 128 output channels.  Any other width up to 128 runs on the next of the two:
+        # the packer gets zero weight rows and a zero shift for the padding channels, which therefore come out as exact zeros
+        # (relu(0 + 0), also through a residual add of two such tensors), and every consumer reads the logical channels only
+        # (x.C of a TRef is logical, its channel stride physical).
+        cout = 64 if cout_l <= 64 else 128 if cout_l <= 128 else None
+        if cout is None:
             raise NotImplementedError("Convolution %s: %d output channels.  The HIP conv kernels are instantiated for 64 and 128 output "
-                                      "channels only (the widths of the shipped configs: BackboneParam.num_filter = (64, 64, 128, 128, ...), "
-                                      "128-channel head towers); other dla_backbone.py num_filter values have no lowering" % (conv.name, cout))
-        if x.tail is not None and (k != (3, 3) or sw != 1 or residual is not None or sc is not None or os.environ.get("RD_NO_FOLD")):
-            raise NotImplementedError("Convolution %s reads a virtual concat: only 3x3 stride 1 without residual / shortcut" % conv.name)
-        out = self._out(cout, x.H, Wout, dest)
+                                      "channels (other widths up to 128 run zero-padded on those); more than 128 channels per layer "
+                                      "(dla_backbone.py num_filter) has no lowering" % (conv.name, cout_l))
+        if cout != cout_l and dest is not None:
+            raise NotImplementedError("Convolution %s: %d output channels inside a channel concat (only 64 / 128 there)" % (conv.name, cout_l))
+        out = self._out(cout, x.H, Wout, dest) if cout == cout_l else self.new_act(cout_l, x.H, Wout, cs=cout)
         # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
         # and, unless RD_NO_FOLD is set, every bf16 3x3 conv with the BatchNorm scale folded into its weights (RD_SCALE_FOLDED)
         fold = self.h16 and k == (3, 3) and not os.environ.get("RD_NO_FOLD")
@@ -377,7 +382,7 @@ class Lowering:
             kw["x2"] = x.tail                     # (top level: buffer liveness)
         self.step("conv", name=conv.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=residual,
                   cin=sum(1 for m in x.cmap if m >= 0) if x.tail is not None else x.C,   # (logical channels of a virtual concat)
-                  cout=cout, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw_fold, **kw)
+                  cout=cout, cout_logical=cout_l, k=k, stride_w=sw, flags=flags, cmap=x.cmap, ex=ex, **kw_fold, **kw)
         return out
 
     def _fusable_projection(self, main_conv, sc):
@@ -426,16 +431,19 @@ class Lowering:
                 if kh != 3 or sh != 1 or ph != 1:
                     raise NotImplementedError("Deconvolution %s: kernel/stride/pad height" % dc.name)
                 Wout = (x.W - 1) * sw - 2 * pw + kw
-                cout = dc.attrs["num_filter"]
-                out = self._out(cout, x.H, Wout, dest)
-                if (res.C, res.H, res.W) != (cout, x.H, Wout):
+                cout_l = dc.attrs["num_filter"]
+                cout = 64 if cout_l <= 64 else 128 if cout_l <= 128 else None        # (zero-padded to a kernel width like _conv_bn)
+                if cout is None or (cout != cout_l and dest is not None):
+                    raise NotImplementedError("Deconvolution %s: %d output channels (at most 128; 64 / 128 inside a concat)" % (dc.name, cout_l))
+                out = self._out(cout, x.H, Wout, dest) if cout == cout_l else self.new_act(cout_l, x.H, Wout, cs=cout)
+                if (res.C, res.H, res.W) != (cout_l, x.H, Wout) or (cout != cout_l and (res.cs != cout or res.co != 0)):
                     raise ValueError("agg add shape mismatch at %s" % add.name)
                 fold = self.h16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD")
                 # every phase a 3 x 2 tap set (kw = 2 sw, pad = sw / 2: k(3,8) s4 p2, k(3,4) s2 p1): all phases in ONE launch
                 # (rd_deconv2d_bn_act_all; the executor checks this against rd_deconv2d_all_phases_ok)
                 one = bool(fold and kw == 2 * sw and 2 * pw == sw and not os.environ.get("RD_DECONV_PER_PHASE"))
                 self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
-                          cout=cout, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD, fold=fold, one_launch=one)
+                          cout=cout, cout_logical=cout_l, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD, fold=fold, one_launch=one)
                 return out
         raise NotImplementedError("elemwise_add %s is not skip + relu(BN(Deconvolution))" % add.name)
 

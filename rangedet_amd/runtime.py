@@ -83,10 +83,24 @@ class TorchAllocator:
         self.torch.cuda.synchronize(self.device)
 
 
-def bn_affine(P, name, eps):
+def bn_affine(P, name, eps, pad_to=None):
+    """inference BatchNorm as scale / shift; pad_to: zero-padded output channels of a layer that runs on a wider kernel (scale 1, shift 0)"""
     g, b, m, v = (np.asarray(P[name + s], np.float64) for s in ("_gamma", "_beta", "_moving_mean", "_moving_var"))
     s = g / np.sqrt(v + eps)
-    return s.astype(np.float32), (b - m * s).astype(np.float32)
+    s, t = s.astype(np.float32), (b - m * s).astype(np.float32)
+    if pad_to is not None and pad_to > len(s):
+        s = np.concatenate([s, np.ones(pad_to - len(s), np.float32)])
+        t = np.concatenate([t, np.zeros(pad_to - len(t), np.float32)])
+    return s, t
+
+
+def pad_rows(w, n, axis=0):
+    """weights with zero rows appended along `axis` up to n (a layer whose logical width runs zero-padded on a 64 / 128-channel kernel)"""
+    if w.shape[axis] >= n:
+        return w
+    shp = list(w.shape)
+    shp[axis] = n - w.shape[axis]
+    return np.concatenate([w, np.zeros(shp, w.dtype)], axis)
 
 
 class Executor:
@@ -175,24 +189,25 @@ class Executor:
             b["cin"] = w1.shape[1]
             return b
         if k == "conv":
-            w = np.asarray(P[st["name"] + "_weight"], np.float32)
+            w = pad_rows(np.asarray(P[st["name"] + "_weight"], np.float32), st["cout"])
             if st.get("cmap"):   # the input is a concat buffer with alignment padding: zero weight columns there
                 wp = np.zeros((w.shape[0], len(st["cmap"])) + w.shape[2:], np.float32)
                 for pc, lc in enumerate(st["cmap"]):
                     if lc >= 0:
                         wp[:, pc] = w[:, lc]
                 w = wp
-            s, t = bn_affine(P, st["bn"], st["eps"])
+            s, t = bn_affine(P, st["bn"], st["eps"], pad_to=st["cout"])
             if st.get("sc"):      # fused projection shortcut: both BN scales folded into the weights, one shift for the sum
                 sc = st["sc"]
-                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32).reshape(w.shape[0], -1)
+                wsc = np.asarray(P[sc["name"] + "_weight"], np.float32)
+                wsc = pad_rows(wsc.reshape(wsc.shape[0], -1), st["cout"])
                 if sc.get("cmap"):
                     wq = np.zeros((w.shape[0], len(sc["cmap"])), np.float32)
                     for pc, lc in enumerate(sc["cmap"]):
                         if lc >= 0:
                             wq[:, pc] = wsc[:, lc]
                     wsc = wq
-                ss, ts = bn_affine(P, sc["bn"], sc["eps"])
+                ss, ts = bn_affine(P, sc["bn"], sc["eps"], pad_to=st["cout"])
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
                 b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload((t.astype(np.float64) + ts).astype(np.float32))
@@ -211,8 +226,8 @@ class Executor:
                 b["w"] = A.upload(L.pack_conv_weight(w, dt))
                 b["scale"], b["shift"] = A.upload(s), A.upload(t)
         elif k == "deconv":
-            w = P[st["name"] + "_weight"]
-            s, t = bn_affine(P, st["bn"], st["eps"])
+            w = pad_rows(np.asarray(P[st["name"] + "_weight"], np.float32), st["cout"], axis=1)      # (cin, cout, kh, kw)
+            s, t = bn_affine(P, st["bn"], st["eps"], pad_to=st["cout"])
             fs = s if st.get("fold") else None
             imgs = [L.pack_deconv_weight(w, st["stride_w"], st["pad_w"], ph, dt, fold_scale=fs) for ph in range(st["stride_w"])]
             # all phases in ONE launch when the library has that form for this layer (16-bit, folded scale, 3 x 2 phases):

@@ -75,9 +75,13 @@ CLS_STD, REG_STD = 0.5, 0.05  # head output weights: logits with O(0.5) spread, 
 CLS_BIAS = -1.807  # calibrated with the oracle (seed 18, frame 0): ~1500 of the valid pixels score > 0.5
 
 
-def make_weights(seed=18, width=2656, in_ch=8, cls_bias=CLS_BIAS, num_classes=1):
+def make_weights(seed=18, width=2656, in_ch=8, cls_bias=CLS_BIAS, num_classes=1, num_filter=None):
+    """num_filter: {stage: channels} overrides of NUM_FILTER (BackboneParam.num_filter of the reference config); the widths must be
+    consistent the way the reference's graph needs them (agg2 = res2, agg1 = res1, agg2a = res2a, agg3 = agg1: the stages a skip
+    connection adds, dla_backbone.py:117-127,143-150; res1 = 64: the Meta-Kernel unit's data channels)."""
     rng = np.random.default_rng(seed)
     P = {}
+    NF = dict(NUM_FILTER, **(num_filter or {}))
 
     def conv_w(name, o, i, kh, kw, bias=False, std=None):
         s = std if std is not None else np.sqrt(GAIN / (i * kh * kw))
@@ -115,18 +119,19 @@ def make_weights(seed=18, width=2656, in_ch=8, cls_bias=CLS_BIAS, num_classes=1)
         for i in range(2, nblk + 1):
             block("%s_unit%d" % (name, i), f, f, False, ("%s_unit%d" % (name, i)) in meta_units)
 
-    stage('res1', in_ch, 64, NUM_BLOCK['res1'], meta_units=('res1_unit2',))
-    stage('res2a', 64, 64, NUM_BLOCK['res2a'])
-    stage('res2', 64, 128, NUM_BLOCK['res2'])
-    stage('res3a', 128, 128, NUM_BLOCK['res3a'])
-    stage('res3', 128, 128, NUM_BLOCK['res3'])
-    for name, cin, f, k in (("agg2", 128, 128, (3, 8)), ("agg1", 128, 64, (3, 8)), ("agg2a", 128, 64, (3, 4)),
-                            ("agg3", 64, 64, (3, 4))):
+    stage('res1', in_ch, NF['res1'], NUM_BLOCK['res1'], meta_units=('res1_unit2',))
+    stage('res2a', NF['res1'], NF['res2a'], NUM_BLOCK['res2a'])
+    stage('res2', NF['res2a'], NF['res2'], NUM_BLOCK['res2'])
+    stage('res3a', NF['res2'], NF['res3a'], NUM_BLOCK['res3a'])
+    stage('res3', NF['res3a'], NF['res3'], NUM_BLOCK['res3'])
+    # (deconv input = the upsampled stage: res3 -> agg2, res2 -> agg1, agg2 -> agg2a, agg2a -> agg3; dla_backbone.py:143-150)
+    for name, cin, f, k in (("agg2", NF['res3'], NF['agg2'], (3, 8)), ("agg1", NF['res2'], NF['agg1'], (3, 8)),
+                            ("agg2a", NF['agg2'], NF['agg2a'], (3, 4)), ("agg3", NF['agg2a'], NF['agg3'], (3, 4))):
         s = np.sqrt(GAIN / (cin * k[0] * k[1] / (k[1] // 2)))
         P[name + "_deconv_weight"] = rng.normal(0, s, (cin, f, k[0], k[1])).astype(np.float32)  # (I,O,kh,kw)
         bn_p(name + "_deconv_bn", f)
         stage(name + "_res", f, f, NUM_BLOCK[name])
-    lvl_in = {0: 64 + in_ch, 1: 64, 2: 128}
+    lvl_in = {0: NF['agg3'] + in_ch, 1: NF['agg2a'], 2: NF['agg2']}
     for lvl in range(3):
         for tower in ("cls", "reg"):
             cin = lvl_in[lvl]

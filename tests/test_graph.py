@@ -95,8 +95,9 @@ def test_config_and_full_graph_lowering(monkeypatch):
 def test_unsupported_widths_fail_at_lowering_with_the_supported_set():
     """The reference's config surface lets BackboneParam.num_filter / meta_kernel_units vary (dla_backbone.py:59-103,130-161).  The symbol
     mirror builds any of them; the HIP lowering is welded to the shipped widths and must say which ones instead of mis-computing."""
-    sym = cfgmod.get_config(False, backbone={'num_filter': {'res2': 96}})[6].test_symbol
-    with pytest.raises(NotImplementedError, match=r"96 output channels.*64 and 128"):
+    # (widths up to 128 that are not 64 / 128 run zero-padded: test_e2e_other_stage_widths; beyond 128 there is no kernel)
+    sym = cfgmod.get_config(False, backbone={'num_filter': {'res3a': 160}})[6].test_symbol
+    with pytest.raises(NotImplementedError, match=r"160 output channels.*64 and 128"):
         lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
     mk = dict(stride=1, meta_func_param='meta_baseline_bias', data_channels=64, coord_channels=3, channel_list=[16, 64], kernel_size=3)
     sym = cfgmod.get_config(False, backbone={'meta_kernel_units': {'res1_unit2': mk}})[6].test_symbol
@@ -140,6 +141,55 @@ def test_api_surface_matches_reference():
     import mxnext.complicate
     import rangedet.symbol.head.builder as b2
     assert b2.RangeRCNN is RangeRCNN and callable(mxnext.complicate.normalizer_factory) and "processing_cxx" in names
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("dt", [R.RD_F32, R.RD_BF16], ids=["f32", "bf16"])
+def test_e2e_other_stage_widths(be, dt):
+    """BackboneParam.num_filter other than the shipped 64 / 128 (the reference's config surface lets it vary, dla_backbone.py:59-103,
+    130-161): a stage of 96 or 48 channels runs zero-padded on the 128- / 64-channel kernels (lower._conv_bn, runtime.pad_rows) and the
+    consumers read its logical channels.  Widths consistent the way the reference graph needs them (a skip connection adds the stages
+    agg2 = res2, agg2a = res2a): res2 = agg2 = 96, res3a = 96, res3 = 112, res2a = agg2a = 48 -- so every kind of consumer meets a padded
+    tensor: 3x3 convs stride 1 / 2, projection shortcuts, residual adds, transposed convs (input AND output), head tower convs.
+    fp32: against the graph oracle at the parity tolerance; bf16: the same graph within the 16-bit error model."""
+    emu = be.name == "emu"
+    H, Wr, W, k = (8, 30, 32, 150) if emu else (16, 250, 256, 2000)
+    nf = dict(G.Cfg.num_filter, res2a=48, agg2a=48, res2=96, agg2=96, res3a=96, res3=112)
+
+    class Cfg(G.Cfg):
+        num_filter = nf
+        num_block = dict({kk: 1 for kk in G.Cfg.num_block}, res1=2, res2=2, res2a=2)
+        head_layers = 1
+    cfg = cfgmod.get_config(False, feat_size=(H, Wr), pad_field=(H, W), pre_nms_top_n={'veh': k})
+    from rangedet_amd.symbol.backbone.dla_backbone import DLABackbone
+    from rangedet_amd.symbol.head.builder import RangeRCNN, RangeRpnHead
+    RP = cfg[2]
+    bp = type("BackboneParam", (), dict(fp16=True, normalizer=RP.normalizer, fpn_strides=(1, 2, 4), batch_image=1, range_image_shape_hw=(H, W),
+                                        add_data_sc=True, num_block=Cfg.num_block, num_filter=nf,
+                                        meta_kernel_units={'res1_unit2': dict(stride=1, meta_func_param='meta_baseline_bias', data_channels=64,
+                                                                              coord_channels=3, channel_list=[32, 64], kernel_size=3)}))
+    RP.head.cls_conv_layers = RP.head.reg_conv_layers = 1
+    dp = type("DetParam", (), dict(fpn_strides=(1, 2, 4), class_names=('veh',)))
+    sym = RangeRCNN(dp).get_test_symbol(DLABackbone(bp), RangeRpnHead(RP))
+    plan = lower(sym, small_shapes(H, W), dt, 1)
+    padded = [s for s, _ in conv_steps(plan.steps) if s.get("cout_logical") not in (None, s["cout"])]
+    assert {s["cout_logical"] for s in padded} == {48, 96, 112} and all(s["cout"] in (64, 128) and s["out"].cs == s["cout"] for s in padded)
+    assert any(s["kind"] == "deconv" for s in padded) and any(s.get("sc") or tuple(s["k"]) == (1, 1) for s in padded) and \
+        any(s["stride_w"] == 2 for s in padded if s["kind"] == "conv")
+    P = synth.make_weights(seed=18, width=W, cls_bias=-0.5, num_filter=nf)
+    fr = IR.make_frame(0, W=Wr, pad_W=W, H=H)
+    ex = Executor(plan, P, lib=be.lib, alloc=be.alloc)
+    ex.forward(fr)
+    ref = G.forward(fr, P, cfg=Cfg, num_fgs=k)
+    sfg = [s for s in plan.steps if s["kind"] == "sorted_fg"][0]
+    logit, delta = ex.read_flat(sfg["score"]), ex.read_flat(sfg["delta"])
+    if dt == R.RD_F32:
+        assert np.abs(logit - ref["logit"]).max() < 1e-4, np.abs(logit - ref["logit"]).max()
+        assert np.abs(delta - ref["delta"]).max() < 1e-4, np.abs(delta - ref["delta"]).max()
+    else:
+        for got, want in ((logit, ref["logit"]), (delta, ref["delta"])):
+            err = (got - want)
+            assert np.sqrt((err ** 2).mean()) < 0.03 * want.std() + 1e-3 and np.abs(err).max() < 0.25 * want.std() + 1e-2, (np.sqrt((err ** 2).mean()), want.std())
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
