@@ -194,6 +194,12 @@ def test_bench_rccl_gather_world1():
     assert gc["gather_matches_local"] is True                                  # the collective returned this rank's records bit for bit
     assert gc["results_sha256_last_step"] == pc["results_sha256_last_step"]    # ... and the results are those of the run without it
     assert gc["wnms_kept"] == pc["wnms_kept"] and gc["wnms_candidates"] == pc["wnms_candidates"]
+    # the weighted NMS's rejection test (k_wnms.h w_pair_skippable) on the production frames -- the whole run again with every
+    # pair clipped (RD_WNMS_NO_SKIP=1 is read once per process, hence a process): the same kept rows and indices, bit for bit
+    ns = subprocess.run(cmd, env=dict(env, RD_WNMS_NO_SKIP="1"), capture_output=True, text=True, timeout=900)
+    assert ns.returncode == 0, ns.stderr[-2000:]
+    nc = _json_line(ns.stdout)["config"]
+    assert nc["results_sha256_last_step"] == pc["results_sha256_last_step"] and nc["wnms_kept"] == pc["wnms_kept"]
     for d in (p, g):                                                           # the spread fields of the report
         assert d["repeats"] == 2 and len(d["region_ms"]) == 2 and d["steps"] == 3
         assert d["ms_per_step_p5"] <= d["ms_per_step_p50"] <= d["ms_per_step_p95"]
