@@ -230,3 +230,23 @@ def test_evaluate_rccl_merge_world1(tmp_path):
         assert o0[k]["meta_info"] == o1[k]["meta_info"]
         for c in o0[k]["det_xyzlwhyaws"]:
             assert np.array_equal(o0[k]["det_xyzlwhyaws"][c], o1[k]["det_xyzlwhyaws"][c])
+
+
+@pytest.mark.gpu
+def test_bench_results_independent_of_block_fusion():
+    """The timed pipeline itself -- two batches in flight on two launch streams plus the NMS side streams, i.e. the fused BasicBlock
+    kernels (csrc/k_block.h, counted LDS-DMA waits) running under contention -- gives bit for bit the detections of the same run with
+    every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RD_NO_FUSE_BLOCK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "2", "--backbone-reps", "0",
+           "--no-cpu-baseline"]
+    outs = []
+    for extra in ({}, {"RD_NO_FUSE_BLOCK": "1"}):
+        r = subprocess.run(cmd, env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(_json_line(r.stdout))
+    a, b = outs
+    assert a["block_kernel"] is not None and a["block_kernel"]["launches_per_step"] == 8 and b["block_kernel"] is None
+    assert a["config"]["results_sha256_last_step"] == b["config"]["results_sha256_last_step"]
+    assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
