@@ -24,6 +24,7 @@ def bind(path):
     m.rdm_block64_packed_bytes.argtypes = [c_int]
     m.rdm_pack_block64_host.argtypes = [c_void_p] * 4 + [c_int, c_int, c_void_p]
     m.rdm_block64.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    m.rdm_block64_tall.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     m.rdm_last_error.restype = ctypes.c_char_p
     return m
 
@@ -101,6 +102,17 @@ if mode == "emu":
         assert rc == 0, m.rdm_last_error()
         bad = y != yr
         print("B %d H %d W %d dt %d: %d of %d values differ from the unfused pair" % (B, H, W, dt, int(bad.sum()), bad.size), flush=True)
+        if dt == R.RD_BF16:     # the 16 x 32-tile experiment (tools/micro/k_block16.h)
+            y2 = np.full((B, H, W, 64), 0x7fc0, np.uint16)
+            rc = m.rdm_block64_tall(xb.ctypes.data, 64, 0, pk.ctypes.data, t1.ctypes.data, t2.ctypes.data, y2.ctypes.data, 64, 0, B, H, W, dt, None)
+            assert rc == 0, m.rdm_last_error()
+            bad2 = y2 != yr
+            print("   tall tiles: %d of %d values differ" % (int(bad2.sum()), bad2.size), flush=True)
+            if bad2.any():
+                idx = np.argwhere(bad2)
+                print("  first mismatches (b, h, w, c):", idx[:8].tolist())
+                print("  rows:", sorted(set(idx[:, 1].tolist()))[:24], "cols:", sorted(set(idx[:, 2].tolist()))[:40])
+                sys.exit(1)
         if bad.any():
             idx = np.argwhere(bad)
             print("  first mismatches (b, h, w, c):", idx[:8].tolist())
@@ -143,7 +155,20 @@ else:
             line = "dt %d B %d H %d W %-5d: %d values differ from the unfused pair" % (dt, B, H, W, nbad)
             if len(sys.argv) > 2 and B == 8:
                 res = {}
-                for name, fn in (("unfused", unfused), ("fused", fused), ("unfused2", unfused), ("fused2", fused)):
+                ytl = [torch.full((B, H, W, 64), float("nan"), device=dev, dtype=tdt) for _ in range(NB)]
+
+                def tall(i):
+                    rc = m.rdm_block64_tall(xs[i].data_ptr(), 64, 0, pk.data_ptr(), T1.data_ptr(), T2.data_ptr(), ytl[i].data_ptr(), 64, 0, B, H, W, dt, st)
+                    assert rc == 0, m.rdm_last_error()
+                variants = [("unfused", unfused), ("fused", fused)]
+                if dt == R.RD_BF16:
+                    for i in range(NB):
+                        tall(i)
+                    torch.cuda.synchronize()
+                    nb2 = sum(int((ytl[i].view(torch.int16) != yr[i].view(torch.int16)).sum()) for i in range(NB))
+                    line += "  [tall: %d differ]" % nb2
+                    variants.append(("tall", tall))
+                for name, fn in variants + [(n + "2", f) for n, f in variants]:
                     for i in range(3):
                         fn(i % NB)
                     torch.cuda.synchronize()
