@@ -250,3 +250,21 @@ def test_bench_results_independent_of_block_fusion():
     assert a["block_kernel"] is not None and a["block_kernel"]["launches_per_step"] == 8 and b["block_kernel"] is None
     assert a["config"]["results_sha256_last_step"] == b["config"]["results_sha256_last_step"]
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--config", "kitti", "--dtype", "f16"], ["--dtype", "f16"], ["--inflight", "1"]], ids=["kitti-f16", "waymo-f16", "inflight1"])
+def test_bench_other_configurations_run(extra):
+    """`bench.py` on the other configurations it names -- BASELINE configs[4] (KITTI-shaped two-class, fp16), the reference's arithmetic type
+    on the headline workload, one batch in flight -- prints a well-formed line (the driver only ever runs the default)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["value"] > 100 and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["repeats"] == 2
+    assert d["dtype"] == ("f16" if "f16" in extra else "bf16") and d["roofline"]["frac"] > 0.2 and d["block_kernel"]["launches_per_step"] == 8
+    assert 0.2 < d["meta_dla_forward"]["frac_hbm_peak"] < 0.6 and d["config"]["wnms_kept"] > 0
+    if "kitti" in extra:
+        assert "KITTI" in d["config"]["workload"] and set(d["config"]["per_class"]) == {"veh", "ped"}
