@@ -310,6 +310,11 @@ int rd_single_overlap(const float* dets_a, const float* dets_b, long n, int is3d
  * test).  Test / characterisation aid: results of rd_wnms_4c do not depend on it. */
 int rd_wnms_pair_skippable(const float* dets_a, const float* dets_b, long n, unsigned char* out, void* stream);
 
+/* out[i] = atan2f(y[i], x[i]) as the weighted NMS computes its edge angles (nms.h:71) and the score filter its yaw column: the C
+ * library's float routine -- glibc's fdlibm algorithm restated operation by operation on the device (not the device math library's
+ * atan2f, which differs from it in the last bit).  Test / characterisation aid: bit-equal to the host's atan2f (tests/test_kernels.py). */
+int rd_edge_atan2f(const float* y, const float* x, long n, float* out, void* stream);
+
 /* HOST: the reference's own ordering (std::sort, score descending, unstable) for dets_host (K,12). */
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host);
 

@@ -850,6 +850,18 @@ int rd_wnms_pair_skippable(const float* dets_a, const float* dets_b, long n, uns
   hipLaunchKernelGGL(pair_skippable_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dets_a, dets_b, n, out);
   return check_launch("wnms_pair_skippable");
 }
+namespace rd {
+__global__ void atan2f_kernel(const float* y, const float* x, long n, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fdlibm_atan2f(y[i], x[i]);
+}
+}  // namespace rd
+int rd_edge_atan2f(const float* y, const float* x, long n, float* out, void* stream) {
+  RD_REQUIRE(y && x && out && n >= 0, RD_EINVAL, "edge_atan2f: null pointer");
+  if (n == 0) return RD_OK;
+  hipLaunchKernelGGL(atan2f_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, n, out);
+  return check_launch("edge_atan2f");
+}
 int rd_wnms_order_host(const float* dets_host, int K, int* order_host) {
   RD_REQUIRE(K >= 0 && (K == 0 || (dets_host && order_host)), RD_EINVAL, "wnms_order_host: bad arguments");
   // the reference's ordering, literally (nms.h:786-792): std::sort is unstable, so equal scores come out in

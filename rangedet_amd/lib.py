@@ -95,6 +95,7 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_size_t, c_void_p]),
     "rd_single_overlap": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "rd_wnms_order_host": (c_int, [c_void_p, c_int, c_void_p]),
+    "rd_edge_atan2f": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rd_wnms_pair_skippable": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rd_dets12_to_8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rd_rotated_iou_8pt": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p]),

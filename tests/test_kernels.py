@@ -816,6 +816,44 @@ def test_pair_overlap_golden_through_hip(be):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_edge_atan2f_equals_the_c_library(be):
+    """rd_edge_atan2f = the atan2f of the weighted NMS's edge angles (nms.h:71: the C library's, through <cmath>) on the device: the fdlibm
+    algorithm glibc ships restated operation by operation (rd_common.h fdlibm_atan2f) must be BIT-EQUAL to this host's atan2f -- on box
+    edges, random bit patterns (all exponents, NaN, Inf, denormals), axis-aligned / zero arguments and ratios next to the routine's
+    argument-reduction thresholds (tools/atan2f_replay_check.c ran the same comparison over 2e9 inputs on the host)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    rng = np.random.default_rng(11)
+    n = 1 << 18
+    parts = []
+    th, ln = rng.uniform(-np.pi, np.pi, n), rng.uniform(0.2, 25, n)
+    c = rng.uniform(-100, 100, (n, 2)).astype(np.float32)
+    parts.append(((c[:, 1] + (ln * np.sin(th)).astype(np.float32)) - c[:, 1], (c[:, 0] + (ln * np.cos(th)).astype(np.float32)) - c[:, 0]))
+    parts.append((rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32), rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)))
+    sm = (rng.uniform(-0.5, 0.5, n) * np.where(rng.integers(0, 8, n) == 0, 0.0, 2.0 ** -rng.integers(0, 40, n))).astype(np.float32)
+    parts.append((sm, (rng.uniform(-0.5, 0.5, n) * np.where(rng.integers(0, 8, n) == 0, 0.0, 50.0)).astype(np.float32)))
+    xx = rng.uniform(-20, 20, n).astype(np.float32)
+    thr = np.array([0.4375, 0.6875, 1.1875, 2.4375], np.float32)[rng.integers(0, 4, n)]
+    parts.append(((xx * thr * (1 + rng.uniform(-5e-6, 5e-6, n)).astype(np.float32) * rng.choice([-1, 1], n)).astype(np.float32), xx))
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3e38, 1e-30], np.float32)
+    parts.append((np.repeat(sp, len(sp)), np.tile(sp, len(sp))))
+    y = np.ascontiguousarray(np.concatenate([p[0] for p in parts]).astype(np.float32))
+    x = np.ascontiguousarray(np.concatenate([p[1] for p in parts]).astype(np.float32))
+    out = be.empty(len(y) * 4)
+    be.lib.call("rd_edge_atan2f", be.ptr(be.up(y)), be.ptr(be.up(x)), len(y), be.ptr(out), be.stream)
+    got = be.down(out, np.float32, (len(y),))
+    # the host's atan2f over the same arrays (a tiny C loop through ctypes would need a compiler; libm's symbol called per chunk via numpy
+    # is not available, so: ctypes per element on a sample + every special value)
+    libm.atan2f.restype = ctypes.c_float
+    libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    idx = np.concatenate([rng.choice(len(y) - len(sp) ** 2, 60000, replace=False), np.arange(len(y) - len(sp) ** 2, len(y))])
+    want = np.array([libm.atan2f(float(y[i]), float(x[i])) for i in idx], np.float32)
+    g = got[idx]
+    same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), y[idx][~same][:4], x[idx][~same][:4], g[~same][:4], want[~same][:4])
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
 def test_spurious_overlaps_and_the_rejection_test(be):
     """pair_overlaps_spurious.npz: 1.6k pairs of boxes that do NOT intersect on which the reference's clipper (nms.h:96-149,195-249,
     no empty-intersection test) returns a positive "IoU" -- found by running the compiled reference over disjoint pairs of nine
