@@ -14,10 +14,15 @@
 // Pinning status:
 //   wnms / single_overlap : PINNED against the reference source compiled as-is (oracle/_ref, built by
 //                           `make -C oracle ref`; tests/test_oracle_pin.py + tests/golden/*.npz).
-//   decode / rotated IoU / NMS3D : PARITY UNPINNED.  The reference kernels live in headers / .cu files that
-//                           need MXNet's internal headers and CUDA (absent here; the CPU FCompute of NMS3D is
-//                           LOG(FATAL), nms_3d.cc:11-17) so they cannot be built; the reference has no
-//                           tests or golden vectors.  This file follows the cited lines literally.
+//   decode / rotated IoU / NMS3D : the reference kernels live in headers / .cu files that need MXNet's internal
+//                           headers and CUDA (absent here; the CPU FCompute of NMS3D is LOG(FATAL),
+//                           nms_3d.cc:11-17), so they cannot be built, and the reference has no tests or golden
+//                           vectors for them.  This file follows the cited lines literally.  Round 5:
+//                           decode is PINNED BY ROUND TRIP through the reference's own Python target encoder
+//                           (rangedet/core/input.py:452-507 -> tests/golden/decode_roundtrip.npz,
+//                           tests/test_ref_python_pins.py); rotated IoU and the NMS3D overlap stay PARITY UNPINNED
+//                           but are cross-checked against the pinned single_overlap, which computes the same
+//                           IoUs by another algorithm (tests/test_oracle_pin.py).
 //
 // Build: g++ -O3 -ffp-contract=off -shared -fPIC (baseline x86-64, no -march: matches the reference's
 // CMake flags `-O3`, operator_cxx/src_cxx/CMakeLists.txt:19, so no FMA contraction anywhere).

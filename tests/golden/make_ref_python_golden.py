@@ -15,7 +15,11 @@ travels: the outputs are data).  Two pins that need neither MXNet nor a GPU (VER
 Stand-ins installed for imports the reference makes at module scope but never calls on this path: `numba.jit/njit` (identity),
 `processing_cxx` (empty module: the test chain does not call it), `mxnet.*` submodules (inert).  No reference source is copied.
 
-    python tests/golden/make_ref_python_golden.py          # writes tests/golden/input_chain_*.npz, graph_veh_test.json
+  (d) decode_roundtrip.npz -- the reference's own regression-target ENCODER (rangedet/core/input.py:452-507) on chosen boxes / points: the
+      inverse of Decode3DBbox, so decode(encode(box)) = box pins the decode's layout and conventions (row a8).
+
+    python tests/golden/make_ref_python_golden.py          # writes tests/golden/input_chain_*.npz, graph_veh_test.json, box_formats.npz,
+                                                           #   decode_roundtrip.npz
 """
 import importlib
 import importlib.abc
@@ -247,6 +251,30 @@ def main():
     b8 = ref_test.bbox3d_12dim_to_8dim(b12)
     np.savez_compressed(os.path.join(HERE, "box_formats.npz"), b10=b10, b11=b11, b12=b12, b8=b8)
     print("box_formats.npz: %d boxes, 10->11 %s %s, 12->8 %s %s" % (b10.shape[0], b11.shape, b11.dtype, b8.shape, b8.dtype))
+    # (d) the reference's regression-TARGET encoder (rangedet/core/input.py:452-507, GenerateTarget.get_rpn_reg_target: per point the 8
+    # numbers the box head regresses -- sqrt-compressed offsets in the point's azimuth frame, log w, log l, cos / sin of the relative yaw,
+    # bottom height, log h) on boxes and points of our choice.  Decode3DBbox (operator_cxx/contrib/decode_3d_bbox-inl.h:170-262, needs
+    # MXNet to build) is its inverse: decode(encode(box, point), point) must give the box back -- the pin for the decode's delta layout,
+    # frame conventions and corner order that needs neither MXNet nor a GPU.
+    rng = np.random.default_rng(91)
+    M, PP = 40, 12
+    gt = np.stack([rng.uniform(-70, 70, M), rng.uniform(-70, 70, M), rng.uniform(-1.0, 2.5, M), rng.uniform(3.2, 12.0, M), rng.uniform(1.5, 3.0, M),
+                   rng.uniform(1.3, 3.5, M), rng.uniform(-np.pi, np.pi, M)], 1).astype(np.float32)            # x, y, z, l, w, h, yaw
+    off = rng.uniform(-0.5, 0.5, (M, PP, 3)) * gt[:, None, 3:6]                                                # inside the box, box frame
+    c, s_ = np.cos(gt[:, 6])[:, None], np.sin(gt[:, 6])[:, None]
+    pts = np.stack([gt[:, None, 0] + off[..., 0] * c - off[..., 1] * s_, gt[:, None, 1] + off[..., 0] * s_ + off[..., 1] * c,
+                    gt[:, None, 2] + off[..., 2]], 2).astype(np.float32)                                        # (M, PP, 3)
+    ind = np.repeat(np.arange(M), PP).astype(np.int64)
+    pts = pts.reshape(-1, 3)
+    pts[::37] = rng.uniform(-70, 70, (len(pts[::37]), 3)).astype(np.float32)                                    # a few background points
+    ind[::37] = -1
+    Hh, Ww = 16, (M * PP) // 16
+    enc = object.__new__(RI.GenerateTarget)
+    tgt = RI.GenerateTarget.get_rpn_reg_target(enc, pts.reshape(Hh, Ww, 3), gt, ind.reshape(Hh, Ww, 1))
+    assert tgt.shape == (M * PP, 8) and not np.any(tgt[ind == -1])
+    np.savez_compressed(os.path.join(HERE, "decode_roundtrip.npz"), pc=pts, gt=gt, ind=ind, deltas=np.asarray(tgt, np.float32),
+                        deltas_dtype=str(tgt.dtype))
+    print("decode_roundtrip.npz: %d points of %d boxes, targets %s %s" % (len(pts), M, tgt.shape, tgt.dtype))
     ops = {}
     for n in nodes:
         ops[n["op"]] = ops.get(n["op"], 0) + 1

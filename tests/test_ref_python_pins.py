@@ -138,3 +138,32 @@ def test_assigner_sees_the_state_the_reference_chain_leaves():
     CI.LoadRecord().apply(rec2)
     pc2, mask2 = CI.Bbox3dAssigner._state_after_earlier_stages(rec2)
     assert mask2.sum() < mask.sum()
+
+
+@pytest.mark.parametrize("be", BOTH, indirect=True)
+def test_decode3d_round_trip_with_the_reference_encoder(be):
+    """decode_roundtrip.npz: per-point regression targets made by the reference's own GenerateTarget.get_rpn_reg_target
+    (rangedet/core/input.py:452-507) for 40 boxes (x, y, z, l, w, h, yaw) and 12 points inside each.  Decode3DBbox
+    (operator_cxx/contrib/decode_3d_bbox-inl.h:170-262; it needs MXNet's headers to build, so no compiled reference exists here) is
+    that encoder's inverse: the device decode (rd_decode3d_bbox) and the oracle's restatement, followed by the reference's own
+    box-format helpers (tools/test.py:43-81, pinned bit for bit by box_formats.npz), must give every box back from every one of its
+    points -- which fixes the delta layout [dx, dy, log w, log l, cos, sin, z0, log h], the signed-square offsets, the azimuth frame and
+    its rotation direction, and the corner order the 10 -> 11 -> 8 conversion reads the heading and the length / width from."""
+    from oracle import cpu_ops as O
+    g = np.load(os.path.join(GOLD, "decode_roundtrip.npz"))
+    pc, gt, ind, deltas = g["pc"], g["gt"], g["ind"], g["deltas"]
+    fg = ind >= 0
+    assert fg.sum() > 400 and not np.any(deltas[~fg]) and len(set(ind[fg].tolist())) == len(gt)
+    n = len(pc)
+    out = be.empty(n * 40)
+    be.lib.call("rd_decode3d_bbox", be.ptr(be.up(deltas)), be.ptr(be.up(pc)), be.ptr(out), 1, n, 8, 0, be.stream)
+    dev10 = be.down(out, np.float32, (n, 10))
+    for name, b10 in (("device", dev10), ("oracle", O.decode3d(deltas[None], pc[None])[0])):
+        b11 = O.bbox3d_10dim_to_11dim(b10[fg])
+        b8 = O.bbox3d_12dim_to_8dim(np.concatenate([b11, np.ones((b11.shape[0], 1), np.float32)], 1))     # x, y, z, l, w, h, heading, score
+        want = gt[ind[fg]]
+        err = np.abs(b8[:, :6] - want[:, :6]).max(axis=0)
+        dyaw = np.abs((b8[:, 6] - want[:, 6] + np.pi) % (2 * np.pi) - np.pi).max()
+        # float32 round trip through sqrt / square, log / exp, cos / sin / atan2 at coordinates of up to 70 m: 1e-4 m, 1e-5 rad
+        assert err.max() < 1e-4 and dyaw < 2e-5, (name, err, dyaw)
+    assert np.abs(dev10 - O.decode3d(deltas[None], pc[None])[0]).max() < 1e-4
