@@ -1,6 +1,7 @@
-// A whole 64-channel BasicBlock (dla_backbone.py:18-56 without projection shortcut, stride 1) as ONE persistent launch:
+// A whole 64-channel BasicBlock at stride 1 (dla_backbone.py:18-56) as ONE persistent launch:
 //     t = relu(BN1(conv1_3x3(x)))        y = relu(BN2(conv2_3x3(t)) + x)                     (units 2.. of a stage)
 //                                        y = relu(BN2(conv2_3x3(t)) + BNs(conv_1x1(x)))      (SC: unit 1, projection shortcut :44-51)
+// (FIRST: the network's first block, x with <= 16 channels: conv1 as five two-tap steps on one 16-channel k-slot instead of U0 / U1 below.)
 // The unfused pair (k_conv3.h, twice) moves 5.5 tile-sized passes through HBM per block (x with its halo, t written, t read back
 // with its halo, the residual x again, y); here t never leaves the CU: conv1 is evaluated on the 10 x 34 pixels conv2 needs for an
 // 8 x 32 output tile and its rounded result is written straight into LDS in the halo-image layout conv2 reads.  Price: conv1 runs
