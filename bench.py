@@ -389,7 +389,8 @@ def main(argv=None):
                 hc["nkeep"].copy_(A.view_i32(bp.nkeep, (Bf,)), non_blocking=True)
                 hc["count"].copy_(A.view_i32(bp.count, (Bf,)), non_blocking=True)
             if gather:
-                # the ONE collective of the path, enqueued behind this batch's post-processing on its side stream: the next
+                # the ONE collective of the path, enqueued behind this batch's post-processing on its post-processing stream (the batch's
+                # own launch stream with two batches in flight, pipeline.InterleavedPipelines): the other
                 # batch's forward overlaps it, nothing on a launch stream waits for it
                 for g_ in gathers[j]:
                     g_.enqueue(pj._post_stream)

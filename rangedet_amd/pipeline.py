@@ -187,6 +187,7 @@ class RangeDetPipeline:
         self.ks = {c: RpnParam.all_proposal.rpn_pre_nms_top_n[c] for c in self.class_names}
         self.batch = batch
         self._post_stream = None
+        self.post_on_launch_stream = False       # one pipeline alone: score filter + NMS on a side stream (overlaps the next batch's forward)
         self._filter_done = None
         self._post_done = None
         assert self.wnms or len(self.class_names) == 1, "the NMS3D branch is single-class (tools/test.py:182)"
@@ -213,7 +214,13 @@ class RangeDetPipeline:
         one-CU) greedy scan of frame i overlaps the convolutions of frame i+1."""
         A = self.alloc
         side = hasattr(A, "new_stream")
-        if side and self._post_stream is None:
+        if side and self.post_on_launch_stream:
+            # (set by InterleavedPipelines with two or more batches in flight) post-processing on the batch's own launch stream: the
+            # next batch on this stream starts behind this batch's NMS while the OTHER pipeline's forward has the GPU -- the overlap the
+            # side stream exists for is already there, and two streams fewer compete for workgroup slots: 942.3 vs 939.1 frames/s over
+            # nine same-box alternations (profiles/EXPERIMENTS.md, round 5)
+            self._post_stream = A.torch.cuda.current_stream(A.device)
+        elif side and self._post_stream is None:
             self._post_stream = A.new_stream(priority=_stream_prio("RD_POST_STREAM_PRIO"))
         if side and self._filter_done is not None:
             A.wait_event(self._filter_done)          # previous frame's filter has consumed the score / box buffers
@@ -269,6 +276,8 @@ class InterleavedPipelines:
 
     def __init__(self, params, n=2, **kw):
         self.pipes = [RangeDetPipeline(params, **kw) for _ in range(n)]
+        for p in self.pipes:      # (RD_POST_SIDE_STREAM=1: a side stream per pipeline as in rounds 1 - 4, for A/B runs)
+            p.post_on_launch_stream = n >= 2 and not os.environ.get("RD_POST_SIDE_STREAM")
         A = self.pipes[0].alloc
         self.streams = [A.new_stream(priority=_stream_prio("RD_LAUNCH_STREAM_PRIO")) for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
         self._i = 0
