@@ -260,7 +260,10 @@ def main(argv=None):
                          "kitti = BASELINE configs[4]: 64x2048x5 range images, vehicle + pedestrian heads (named in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=2, help="distinct synthetic batches cycled through")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU (pipelines on separate streams)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight per GPU (pipelines on separate streams).  3 since round 5: with the post-processing on each batch's own "
+                         "launch stream, a third batch keeps two on the GPU while the host waits for the oldest one and enqueues the next "
+                         "(960 - 972 vs 945 - 953 frames/s on one box; with side streams 3 was slower than 2)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")

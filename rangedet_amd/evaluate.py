@@ -71,7 +71,7 @@ def meta_info(rec, rid):
     return {'name': name, 'timestamp_micros': int(url.split('/')[-1][:-4])}
 
 
-def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms_top_n=50000, shard=None, inflight=2,
+def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms_top_n=50000, shard=None, inflight=3,
         wnms_cap=None, loader_threads=4):
     """-> (annotation_dict, output_dict) exactly as tools/test.py:166-233 builds them (frames without detections are absent).
 

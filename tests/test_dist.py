@@ -234,7 +234,7 @@ def test_evaluate_rccl_merge_world1(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_results_independent_of_block_fusion():
-    """The timed pipeline itself -- two batches in flight on two launch streams plus the NMS side streams, i.e. the fused BasicBlock
+    """The timed pipeline itself -- three batches in flight on three launch streams, each with its NMS behind its forward, i.e. the fused BasicBlock
     kernels (csrc/k_block.h, counted LDS-DMA waits) running under contention -- gives bit for bit the detections of the same run with
     every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames."""
     import subprocess
