@@ -182,7 +182,7 @@ def test_bench_rccl_gather_world1():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RD_BENCH_GATHER")}
     env["MASTER_PORT"] = str(_free_port())
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
     plain = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert plain.returncode == 0, plain.stderr[-2000:]
     gath = subprocess.run(cmd, env=dict(env, RD_BENCH_GATHER="1"), capture_output=True, text=True, timeout=900)
@@ -201,7 +201,7 @@ def test_bench_rccl_gather_world1():
     nc = _json_line(ns.stdout)["config"]
     assert nc["results_sha256_last_step"] == pc["results_sha256_last_step"] and nc["wnms_kept"] == pc["wnms_kept"]
     for d in (p, g):                                                           # the spread fields of the report
-        assert d["repeats"] == 2 and len(d["region_ms"]) == 2 and d["steps"] == 3
+        assert d["repeats"] == 2 and len(d["region_ms"]) == 2 and d["steps"] == 5
         assert d["ms_per_step_p5"] <= d["ms_per_step_p50"] <= d["ms_per_step_p95"]
         assert d["value_min"] <= d["value"] <= d["value_max"]
 
