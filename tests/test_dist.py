@@ -72,6 +72,8 @@ def _worker(rank, world, port, nframes, B, out):
 @pytest.mark.parametrize("world", [2, 4])
 def test_frame_sharding_and_gather_gloo(world):
     from oracle import cpu_ops as O
+    from emu_util import emu_lib
+    emu_lib()            # (build the CPU emulation of the HIP sources HERE if it is stale: minutes, which the workers' queue timeout would not survive)
     nframes, B = 8, 2 if world == 2 else 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
