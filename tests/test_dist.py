@@ -241,7 +241,7 @@ def test_bench_results_independent_of_block_fusion():
     every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RD_NO_FUSE_BLOCK")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "2", "--backbone-reps", "0",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "3", "--repeats", "3", "--backbone-reps", "0",
            "--no-cpu-baseline"]
     outs = []
     for extra in ({}, {"RD_NO_FUSE_BLOCK": "1"}):
@@ -251,6 +251,7 @@ def test_bench_results_independent_of_block_fusion():
     a, b = outs
     assert a["block_kernel"] is not None and a["block_kernel"]["launches_per_step"] == 8 and b["block_kernel"] is None
     assert a["config"]["results_sha256_last_step"] == b["config"]["results_sha256_last_step"]
+    assert a["config"]["results_sha256_all_steps"] == b["config"]["results_sha256_all_steps"]      # every step's host results, warm-up included
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
 
 
