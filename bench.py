@@ -360,6 +360,7 @@ def main(argv=None):
     done_events = []
     import hashlib
     all_steps_sha = hashlib.sha256()      # every harvested step's host results (boxes of the kept detections, keep counts), in step order
+    step_digests = []
 
     def harvest(j):
         """Host side of a finished batch: wait for its copies, check the WNMS capacity (K <= cap is what makes the
@@ -374,10 +375,12 @@ def main(argv=None):
                 raise RuntimeError("step %d: %d %s candidates above min_score exceed --wnms-cap %d" % (h["step"], kmax, c, multi.pipes[j].bposts[c].cap))
             max_cand[0] = max(max_cand[0], kmax)
             nk = h[c]["nkeep"].numpy()
-            all_steps_sha.update(nk.tobytes())
+            one = hashlib.sha256(nk.tobytes())
             d8 = h[c]["d8"].numpy()
             for b_ in range(Bf):
-                all_steps_sha.update(d8[b_, :min(int(nk[b_]), rdist.MAX_DET)].tobytes())
+                one.update(d8[b_, :min(int(nk[b_]), rdist.MAX_DET)].tobytes())
+            all_steps_sha.update(one.digest())
+            step_digests.append((h["step"], c, one.hexdigest()[:8], [int(v) for v in nk], [int(v) for v in h[c]["count"].numpy()]))
         h["done"] = None
         return h
 
@@ -602,7 +605,8 @@ def main(argv=None):
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames, "gather_matches_local": gather_matches_local,
-                       "results_sha256_last_step": results_sha256, "results_sha256_all_steps": all_steps_sha.hexdigest()[:16], "ranks_seen": ranks_seen, "rccl_version": rccl_version,
+                       "results_sha256_last_step": results_sha256, "results_sha256_all_steps": all_steps_sha.hexdigest()[:16],
+                       "step_digests": step_digests if os.environ.get("RD_BENCH_STEP_DIGESTS") else None, "ranks_seen": ranks_seen, "rccl_version": rccl_version,
                        "cpus_per_rank": len(cpus) if cpus else None,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("self (mp.spawn)" if world > 1 else "single process")},

@@ -238,7 +238,9 @@ def test_evaluate_rccl_merge_world1(tmp_path):
 def test_bench_results_independent_of_block_fusion():
     """The timed pipeline itself -- three batches in flight on three launch streams, each with its NMS behind its forward, i.e. the fused BasicBlock
     kernels (csrc/k_block.h, counted LDS-DMA waits) running under contention -- gives bit for bit the detections of the same run with
-    every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames."""
+    every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames, and the digest over
+    EVERY step's host results (120+ steps, warm-up included).  Two separate runs: so this is also the run-to-run determinism check of the
+    whole pipeline under three batches in flight (it failed before the build dropped the swapped packed-fp32 form)."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RD_NO_FUSE_BLOCK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "3", "--repeats", "3", "--backbone-reps", "0",
@@ -253,6 +255,56 @@ def test_bench_results_independent_of_block_fusion():
     assert a["config"]["results_sha256_last_step"] == b["config"]["results_sha256_last_step"]
     assert a["config"]["results_sha256_all_steps"] == b["config"]["results_sha256_all_steps"]      # every step's host results, warm-up included
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
+
+
+@pytest.mark.gpu
+def test_wnms_chain_unaffected_by_concurrent_convs():
+    """Round 5: with two or more batches in flight the keep counts of a frame differed by one or two from run to run.  Cause: the SLP
+    vectoriser's packed-fp32 form with a swapped second source (v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]) returns a wrong low half in
+    lanes 48-63 while another wave of the SIMD issues MFMA instructions (tools/micro/pkform_test.py).  The library is built
+    without that form (rangedet_amd/build.py); here the batched NMS chain is replayed on one stream while 64->64 convolutions (two
+    workgroups per CU, room left on every SIMD) run on another, and must reproduce the idle GPU's result every time.  (The old build
+    failed 15 of 20 such replays.)"""
+    import torch
+    from rangedet_amd import lib as R, synth
+    from rangedet_amd.pipeline import RangeDetPipeline
+    B = 8
+    P = synth.make_weights(seed=18)
+    pipe = RangeDetPipeline(P, dtype=R.RD_BF16, batch=B, wnms_cap=8192)
+    L, A, bp = pipe.lib, pipe.alloc, pipe.bpost
+    pipe.enqueue(synth.make_batch(list(range(B)), lib=L, alloc=A))
+    torch.cuda.synchronize()
+
+    def snap():
+        torch.cuda.synchronize()
+        nk = np.array(A.to_numpy(A.view_i32(bp.nkeep, (B,))))
+        keep = np.array(A.to_numpy(A.view_i32(bp.keep, (B, bp.cap))))
+        rows = np.array(A.to_numpy(A.view_f32(bp.out, (B, bp.cap, 12))))
+        return nk, [keep[b, :nk[b]].copy() for b in range(B)], [rows[b, :nk[b]].view(np.uint32).copy() for b in range(B)]
+
+    def same(s, t):
+        return np.array_equal(s[0], t[0]) and all(np.array_equal(a, b) for a, b in zip(s[1], t[1])) and all(np.array_equal(a, b) for a, b in zip(s[2], t[2]))
+
+    bp.enqueue_nms()
+    base = snap()
+    assert int(base[0].min()) > 100
+    bp.enqueue_nms()
+    assert same(snap(), base)
+    c, H, W = 64, 64, 2656
+    x = torch.randn(B * H * W * c, device="cuda").to(torch.bfloat16)
+    y = torch.empty_like(x)
+    w = torch.from_numpy(L.pack_conv3x3_ex(np.random.RandomState(0).randn(c, c, 3, 3).astype(np.float32) * 0.05, 1, c, fold_scale=np.ones(c, np.float32),
+                                           dtype=R.RD_BF16)).cuda()
+    sh = torch.zeros(c, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for _ in range(16):
+        for _ in range(8):
+            L.call("rd_conv3x3_bn_act_ex", x.data_ptr(), c, 0, w.data_ptr(), None, sh.data_ptr(), None, 0, 0, None, 0, 0, 0, None,
+                   y.data_ptr(), c, 0, B, H, W, c, c, 1, R.RD_RELU_POST | R.RD_SCALE_FOLDED, R.RD_BF16, s1.cuda_stream)
+        bp.enqueue_nms(stream=s2)
+        bad += not same(snap(), base)
+    assert bad == 0, "%d of 16 replays next to the convolutions differ from the idle result" % bad
 
 
 @pytest.mark.gpu
