@@ -548,7 +548,7 @@ def main(argv=None):
                                "forward's wall time comes from the same replay without the per-launch events (serial_forward_ms; the event "
                                "packets between the kernels cost event_overhead_factor).  The kernel alone: agrees with the rocprofv3 "
                                "--inflight 1 summary under profiles/.  serial_ms_per_step = avg_launch_ms x launches_per_step may exceed "
-                               "ms_per_step: the timed region overlaps two batches on two launch streams, which fills the tail rounds and "
+                               "ms_per_step: the timed region overlaps the batches in flight (--inflight, default 3) on their launch streams, which fills the tail rounds and "
                                "launch gaps of the serial order.  in_step_launch_ms / achieved_in_step: the step's measured wall time shared "
                                "out over all kernels in proportion to their stand-alone durations (the shares add up to ms_per_step)",
                 "share_of_conv_flops": fl / fl_all,

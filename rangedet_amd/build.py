@@ -13,7 +13,7 @@ OUT = os.path.join(HERE, "librangedet_hip.so")
 # -fno-slp-vectorize (device side): the SLP vectoriser turns the cross products of the rotated-box code into packed-fp32 instructions
 # whose second source has its halves SWAPPED (v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]), and on the MI355X boxes of this project that
 # form returns a wrong low half in lanes 48-63 whenever ANOTHER wave of the same SIMD is issuing MFMA instructions -- i.e. whenever the
-# weighted NMS of one batch overlaps the convolutions of the next (DESIGN.md 6.6; reproducer: tools/micro/pkform_test.py, aggr_test.py).
+# weighted NMS of one batch overlaps the convolutions of the next (DESIGN.md 6.4; reproducer: tools/micro/pkform_test.py, aggr_test.py).
 # packed_swap_lint() below fails the build if such an instruction is left in the code object.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Xarch_device", "-fno-slp-vectorize"]
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -97,7 +97,7 @@ def build(force=False, verbose=True):
     if bad and not os.environ.get("RD_ALLOW_PACKED_SWAP"):        # (the switch exists for the A/B of the fault itself)
         os.remove(tmp_out)
         raise RuntimeError("librangedet_hip.so: %d packed-fp32 instructions with swapped source halves (wrong next to MFMA waves on gfx950, "
-                           "DESIGN.md 6.6), first: %s in %s" % (len(bad), bad[0][1], bad[0][0]))
+                           "DESIGN.md 6.4), first: %s in %s" % (len(bad), bad[0][1], bad[0][0]))
     os.replace(tmp_out, OUT)
     return OUT
 

@@ -52,7 +52,7 @@ struct DevSwitches {
   int conv_body;           // RD_CONV_BODY (default 1): heterogeneous tile bodies (k_conv3.h c3_body) for stride 2 / <= 16-channel chunks
   bool sort_no_select;     // RD_SORT_NO_SELECT
   bool wnms_one_round;     // RD_WNMS_ONE_ROUND
-  int wnms_bal;            // RD_WNMS_BAL (default 0; measured slower): the candidate pairs of a pair tile are dealt out evenly over the wave's lanes
+  int wnms_bal;            // RD_WNMS_BAL (default 0; measured slower, profiles/EXPERIMENTS.md round 3): the candidate pairs of a pair tile are dealt out evenly over the wave's lanes
   bool wnms_scan1;         // RD_WNMS_SCAN1: the single-wave scan at every capacity (default: four waves with grouped staging up to 8 192 rows)
   int wnms_ct;             // RD_WNMS_CT (8 default, 16, 32): columns per pair tile
   bool wnms_no_skip;       // RD_WNMS_NO_SKIP: clip every pair the reference clips (no rejection test, k_wnms.h w_pair_skippable)

@@ -240,7 +240,7 @@ def test_bench_results_independent_of_block_fusion():
     kernels (csrc/k_block.h, counted LDS-DMA waits) running under contention -- gives bit for bit the detections of the same run with
     every block as its two launches (RD_NO_FUSE_BLOCK=1): digest of the last step's kept rows and indices of all 8 frames, and the digest over
     EVERY step's host results (120+ steps, warm-up included).  Two separate runs: so this is also the run-to-run determinism check of the
-    whole pipeline under three batches in flight (it failed before the build dropped the swapped packed-fp32 form, DESIGN.md 6.6)."""
+    whole pipeline under three batches in flight (it failed before the build dropped the swapped packed-fp32 form, DESIGN.md 6.4)."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RD_NO_FUSE_BLOCK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "3", "--repeats", "3", "--backbone-reps", "0",
@@ -261,7 +261,7 @@ def test_bench_results_independent_of_block_fusion():
 def test_wnms_chain_unaffected_by_concurrent_convs():
     """Round 5: with two or more batches in flight the keep counts of a frame differed by one or two from run to run.  Cause: the SLP
     vectoriser's packed-fp32 form with a swapped second source (v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]) returns a wrong low half in
-    lanes 48-63 while another wave of the SIMD issues MFMA instructions (DESIGN.md 6.6; tools/micro/pkform_test.py).  The library is built
+    lanes 48-63 while another wave of the SIMD issues MFMA instructions (DESIGN.md 6.4; tools/micro/pkform_test.py).  The library is built
     without that form (rangedet_amd/build.py); here the batched NMS chain is replayed on one stream while 64->64 convolutions (two
     workgroups per CU, room left on every SIMD) run on another, and must reproduce the idle GPU's result every time.  (The old build
     failed 15 of 20 such replays.)"""

@@ -32,3 +32,19 @@ for kind, name in enumerate(kinds):
         torch.cuda.synchronize()
     c = cnt.cpu().numpy().reshape(10, 2, 4)[0]
     print("co-resident %-34s (%6.0f us alone): victim mismatches by lane quarter  lo %s | hi %s" % (name, us, c[0].tolist(), c[1].tolist()), flush=True)
+
+# ---- 16-bit packed forms with the same crossing, next to the MFMA spin kernel --------------------------------------------------
+V.pk16_run.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+n16 = ["v_pk_mul_f16 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_fma_f16 op_sel:[0,1,0] op_sel_hi:[1,0,1]", "v_pk_max_i16 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_mul_f16 (default)"]
+cnt.zero_()
+torch.cuda.synchronize()
+for r in range(reps):
+    V.aggr_run(8, src.data_ptr(), sink.data_ptr(), 512, iters[8], s1.cuda_stream)
+    for pat in range(4):
+        V.pk16_run(pat, cnt.data_ptr(), 1024, 1000, s2.cuda_stream)
+    V.pkform_run(0, cnt.data_ptr() + 4 * 32, 1024, 1000, s2.cuda_stream)        # the fp32 form in the same overlap, as the positive control
+    torch.cuda.synchronize()
+c = cnt.cpu().numpy().reshape(10, 2, 4)
+for p in range(4):
+    print("next to v_mfma_f32_16x16x32_bf16: %-46s lo %s | hi %s" % (n16[p], c[p, 0].tolist(), c[p, 1].tolist()))
+print("next to v_mfma_f32_16x16x32_bf16: %-46s lo %s | hi %s" % ("v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (control)", c[4, 0].tolist(), c[4, 1].tolist()), flush=True)

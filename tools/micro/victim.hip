@@ -1,4 +1,4 @@
-// Probe kernels of the round-5 co-residency study (DESIGN.md 6.6, profiles/r05h_packed_swap_fault.txt):
+// Probe kernels of the round-5 co-residency study (DESIGN.md 6.4, profiles/r05h_packed_swap_fault.txt):
 //   victim_kernel   do long-lived registers / scalar, packed, division chains of a plain kernel survive next to the conv kernels?  (yes)
 //   war_kernel      write-after-read probes around 64-bit VALU operands                                                            (clean)
 //   pk_kernel       the instruction sequence of wnms_prep_kernel's area computation                                               (reproduces)
@@ -252,6 +252,43 @@ extern "C" int aggr_run(int kind, const float* src, float* sink, int nblocks, in
     case 4: aggr_go<4>(src, sink, nblocks, iters, st); break; case 5: aggr_go<5>(src, sink, nblocks, iters, st); break;
     case 6: aggr_go<6>(src, sink, nblocks, iters, st); break; case 7: aggr_go<7>(src, sink, nblocks, iters, st); break;
     case 8: aggr_go<8>(src, sink, nblocks, iters, st); break; default: aggr_go<9>(src, sink, nblocks, iters, st); break;
+  }
+  return (int)hipGetLastError();
+}
+
+// ---- the 16-bit packed forms with the same operand crossing (documentation of the lint's scope: are they affected too?) ---------------
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+// PAT 0: v_pk_mul_f16 swapped src1   1: v_pk_fma_f16 swapped src1   2: v_pk_max_i16 swapped src1   3: v_pk_mul_f16 default (control)
+template <int PAT>
+__global__ __launch_bounds__(256) void pk16_kernel(unsigned* __restrict__ out, int iters) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned badlo = 0, badhi = 0;
+  for (int t = 0; t < iters; ++t) {
+    h2v a = {(_Float16)(1 + ((i + t) & 7)), (_Float16)(2 + ((i * 3 + t) & 7))}, b = {(_Float16)(3 + (t & 3)), (_Float16)(5 + (i & 3))}, c = {(_Float16)1, (_Float16)2};
+    h2v r, x;
+    if (PAT == 0) { asm volatile("s_nop 4\n\tv_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 4" : "=v"(r) : "v"(a), "v"(b)); x = (h2v){a.x * b.y, a.y * b.x}; }
+    else if (PAT == 1) { asm volatile("s_nop 4\n\tv_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\ts_nop 4" : "=v"(r) : "v"(a), "v"(b), "v"(c)); x = (h2v){a.x * b.y + c.x, a.y * b.x + c.y}; }
+    else if (PAT == 2) {
+      s2v ai = {(short)(i + t), (short)(7 * i - t)}, bi = {(short)(3 * t - i), (short)(i ^ t)}, ri;
+      asm volatile("s_nop 4\n\tv_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 4" : "=v"(ri) : "v"(ai), "v"(bi));
+      badlo += ri.x != (ai.x > bi.y ? ai.x : bi.y); badhi += ri.y != (ai.y > bi.x ? ai.y : bi.x);
+      continue;
+    } else { asm volatile("s_nop 4\n\tv_pk_mul_f16 %0, %1, %2\n\ts_nop 4" : "=v"(r) : "v"(a), "v"(b)); x = (h2v){a.x * b.x, a.y * b.y}; }
+    badlo += r.x != x.x;
+    badhi += r.y != x.y;
+  }
+  const int qd = (threadIdx.x & 63) >> 4;
+  if (badlo) atomicAdd(&out[PAT * 8 + qd], badlo);
+  if (badhi) atomicAdd(&out[PAT * 8 + 4 + qd], badhi);
+}
+template <int P>
+static void pk16_go(unsigned* out, int nb, int it, hipStream_t st) { hipLaunchKernelGGL(pk16_kernel<P>, dim3(nb), dim3(256), 0, st, out, it); }
+extern "C" int pk16_run(int pat, unsigned* out, int nblocks, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (pat) {
+    case 0: pk16_go<0>(out, nblocks, iters, st); break; case 1: pk16_go<1>(out, nblocks, iters, st); break;
+    case 2: pk16_go<2>(out, nblocks, iters, st); break; default: pk16_go<3>(out, nblocks, iters, st); break;
   }
   return (int)hipGetLastError();
 }

@@ -1,6 +1,6 @@
 """Does the batched weighted-NMS chain give the same result when other kernels share the GPU?
 Round 5: bench.py's per-step digests differed from run to run with more than one batch in flight -- same candidates, keep counts off by one
-or two.  This tool found the cause (DESIGN.md 6.6): the chain (rd_wnms_4c_batched on one pipeline's filtered detections) is replayed REPS
+or two.  This tool found the cause (DESIGN.md 6.4): the chain (rd_wnms_4c_batched on one pipeline's filtered detections) is replayed REPS
 times on a side stream while another pipeline's forward runs on a second stream, and compared with the result of the same call on an
 idle GPU; on a difference the intermediate arrays in the workspace (prep records, processing order, thr / vote matrices, alive list)
 are compared stage by stage.
