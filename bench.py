@@ -438,8 +438,8 @@ def main(argv=None):
             step(nstep)
             nstep += 1
         barrier()
-        for j in range(len(multi.pipes)):
-            harvest(j)
+        for j in sorted(range(len(multi.pipes)), key=lambda j_: host[j_].get("step", -1)):     # in step order: the all-steps digest does not
+            harvest(j)                                                                             # depend on --inflight
         region_s.append(time.perf_counter() - t0)
         # steady-state time per step from the completion events: with n batches in flight on n pipelines the completions come in
         # bursts of n (the streams share the GPU and finish together), so the interval is taken over a window of n steps and divided

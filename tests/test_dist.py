@@ -254,6 +254,11 @@ def test_bench_results_independent_of_block_fusion():
     assert a["block_kernel"] is not None and a["block_kernel"]["launches_per_step"] == 8 and b["block_kernel"] is None
     assert a["config"]["results_sha256_last_step"] == b["config"]["results_sha256_last_step"]
     assert a["config"]["results_sha256_all_steps"] == b["config"]["results_sha256_all_steps"]      # every step's host results, warm-up included
+    # ... and of the same steps with ONE batch in flight: what runs overlapped gives what runs alone
+    r = subprocess.run(cmd + ["--inflight", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = _json_line(r.stdout)
+    assert c["config"]["results_sha256_all_steps"] == a["config"]["results_sha256_all_steps"]
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
 
 
