@@ -1440,3 +1440,52 @@ def test_error_conventions(be):
     rc = L.raw("rd_decode3d_bbox")(None, p, p, 1, 10, 8, 0, be.stream)
     assert rc == R.RD_EINVAL
     assert L.raw("rd_version")() >= 100
+
+
+@pytest.mark.gpu
+def test_rotated_box_kernels_unaffected_by_concurrent_convs():
+    """Rotated IoU ('bev' and '3d') and NMS3D are cross-product code like the weighted NMS, and the round-4 build had the swapped packed-fp32
+    form in them too (wrong next to MFMA waves).  Each op's result on an idle GPU must come back bit for bit while
+    64->64 convolutions run on a second stream.  (The WNMS chain has its own test of this kind in tests/test_dist.py.)"""
+    L = R.get_lib()
+    dev = "cuda"
+    cur = torch.cuda.current_stream().cuda_stream
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    B, N, c, H, W = 2, 60000, 64, 64, 2656
+    prop, gt = _riou_case(B, N, 40, seed=11)
+    dp, dg = torch.from_numpy(prop).to(dev), torch.from_numpy(gt).to(dev)
+    g7 = torch.from_numpy(np.stack([_gt7_from_corners(gt[b], -1.2, 0.6) for b in range(B)])).to(dev)          # (B, 200, 7)
+    boxes = torch.from_numpy(nms3d_boxes(4, 60, 40, seed=3)).to(dev)                       # (4, 2400, 10)
+    nb, nn = boxes.shape[:2]
+    wb = L.raw("rd_nms3d_workspace_bytes")(nn, nb)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    outs = dict(bev=torch.zeros(B, N, device=dev), bev_arg=torch.zeros(B, N, dtype=torch.int32, device=dev), i3d=torch.zeros(B, N, device=dev),
+                keep=torch.zeros(nb, 500, dtype=torch.int32, device=dev), rows=torch.zeros(nb, 500, 10, device=dev))
+
+    def ops(st):
+        L.call("rd_batch_rotated_iou", dp.data_ptr(), 10, dg.data_ptr(), outs["bev"].data_ptr(), outs["bev_arg"].data_ptr(), B, N, 200, st)
+        L.call("rd_batch_rotated_iou_3d", dp.data_ptr(), 10, g7.data_ptr(), outs["i3d"].data_ptr(), None, B, N, 200, st)
+        L.call("rd_nms3d", boxes.data_ptr(), nb, nn, 0.3, 500, 0, outs["keep"].data_ptr(), outs["rows"].data_ptr(), ws.data_ptr(), wb, st)
+
+    ops(cur)
+    torch.cuda.synchronize()
+    base = {k: v.clone() for k, v in outs.items()}
+    assert float(base["bev"].max()) > 0.5 and float(base["i3d"].max()) > 0.3 and int((base["keep"] >= 0).sum()) > 100
+    x = torch.randn(8 * H * W * c, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    w = torch.from_numpy(L.pack_conv3x3_ex(np.random.RandomState(0).randn(c, c, 3, 3).astype(np.float32) * 0.05, 1, c, fold_scale=np.ones(c, np.float32),
+                                           dtype=R.RD_BF16)).to(dev)
+    sh = torch.zeros(c, device=dev)
+    bad = {k: 0 for k in outs}
+    for _ in range(12):
+        for v in outs.values():
+            v.zero_()
+        torch.cuda.synchronize()
+        for _ in range(8):
+            L.call("rd_conv3x3_bn_act_ex", x.data_ptr(), c, 0, w.data_ptr(), None, sh.data_ptr(), None, 0, 0, None, 0, 0, 0, None,
+                   y.data_ptr(), c, 0, 8, H, W, c, c, 1, R.RD_RELU_POST | R.RD_SCALE_FOLDED, R.RD_BF16, s1.cuda_stream)
+        ops(s2.cuda_stream)
+        torch.cuda.synchronize()
+        for k in outs:
+            bad[k] += not torch.equal(outs[k].view(torch.int32), base[k].view(torch.int32))
+    assert not any(bad.values()), "replays next to the convolutions that differ from the idle result, of 12: %r" % bad
