@@ -292,3 +292,35 @@ extern "C" int pk16_run(int pat, unsigned* out, int nblocks, int iters, void* st
   }
   return (int)hipGetLastError();
 }
+
+// ---- stand-alone reproducer (no Python, no torch, nothing of the library) -----------------------------------------------------------
+//   hipcc --offload-arch=gfx950 -O3 -DFAULT_REPRO_MAIN tools/micro/victim.hip -o tools/micro/fault_repro && tools/micro/fault_repro
+// Two streams: an MFMA spin kernel on one, single-instruction victims on the other.  Prints mismatches by lane quarter for the swapped
+// second-source form and for the default form, next to the MFMA kernel and on an idle GPU.
+#ifdef FAULT_REPRO_MAIN
+#include <cstdio>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main() {
+  hipStream_t s1, s2;
+  CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+  float *src, *sink; unsigned* cnt;
+  CK(hipMalloc(&src, (size_t)(64 * 262144 + 512 * 256 * 4 + 1024) * 4)); CK(hipMalloc(&sink, 512 * 256 * 4)); CK(hipMalloc(&cnt, 80 * 4));
+  CK(hipMemset(src, 0, (size_t)(64 * 262144 + 512 * 256 * 4 + 1024) * 4));
+  hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+  printf("%s (%s), %d CUs\n", pr.name, pr.gcnArchName, pr.multiProcessorCount);
+  const char* what[2] = {"next to v_mfma_f32_16x16x32_bf16 waves", "idle GPU"};
+  for (int idle = 0; idle < 2; ++idle) {
+    CK(hipMemset(cnt, 0, 80 * 4));
+    for (int r = 0; r < 5; ++r) {
+      if (!idle) aggr_run(8, src, sink, 512, 80000, s1);
+      for (int k = 0; k < 3; ++k) { pkform_run(0, cnt, 1024, 1000, s2); pkform_run(9, cnt, 1024, 1000, s2); }
+      CK(hipDeviceSynchronize());
+    }
+    unsigned h[80]; CK(hipMemcpy(h, cnt, sizeof h, hipMemcpyDeviceToHost));
+    printf("%-40s v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]: lo [%u, %u, %u, %u] hi [%u, %u, %u, %u]   default form: lo [%u, %u, %u, %u] hi [%u, %u, %u, %u]"
+           "   (mismatches of %.1e executions per lane quarter)\n", what[idle], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7],
+           h[72], h[73], h[74], h[75], h[76], h[77], h[78], h[79], 5.0 * 3 * 1024 * 64 * 1000);
+  }
+  return 0;
+}
+#endif
