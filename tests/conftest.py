@@ -60,12 +60,28 @@ _BACKENDS = {}
 
 @pytest.fixture
 def be(request):
+    """'emu' / 'hip' as above; 'emu_late' = the emu backend with LDS-DMA transfers landing as LATE as the hardware allows (only when a
+    counted s_waitcnt of the issuing wave forces them, tests/emu/hip/hip_runtime.h dma_late): a wait that is too weak reads stale LDS
+    deterministically.  (The default emu mode lands them when issued -- the earliest the hardware allows.)"""
     name = request.param
-    if name not in _BACKENDS:
-        _BACKENDS[name] = Backend(name)
-    _BACKENDS[name]._keep.clear()
-    return _BACKENDS[name]
+    late = name == "emu_late"
+    key = "emu" if late else name
+    if key not in _BACKENDS:
+        _BACKENDS[key] = Backend(key)
+    b = _BACKENDS[key]
+    b._keep.clear()
+    if not late:
+        yield b
+        return
+    b.lib.cdll.hipemu_set_dma_late(1)
+    try:
+        yield b
+    finally:
+        b.lib.cdll.hipemu_set_dma_late(0)
 
 
 BOTH = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 HIP_ONLY = [pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+# the kernels that move data with LDS-DMA under counted waits (persistent 3x3 conv, fused block, streaming 1x1 conv, generic tap conv, Meta-Kernel)
+# also run with the transfers landing late
+WITH_LATE_DMA = BOTH + [pytest.param("emu_late", id="emu-late-dma")]

@@ -83,13 +83,33 @@ inline int2 make_int2(int a, int b) { return {a, b}; }
 inline int4 make_int4(int a, int b, int c, int d) { return {a, b, c, d}; }
 
 namespace hipemu {
+struct PendingDma { const void* src; void* dst; unsigned size; };
 struct Fiber {
   ucontext_t ctx;
   std::vector<char> stack;
   uint3_ tid;
   bool done = false;
   int wave = 0, lane = 0;
+  std::vector<PendingDma> dmaq;   // LDS-DMA transfers issued and not yet retired (late-DMA mode only), oldest first
+  size_t dma_head = 0;
 };
+// LDS-DMA completion model.  0 (default): a transfer lands when it is issued -- the EARLIEST the hardware allows (exposes ring slots
+// overwritten while still being read).  1 ("late", hipemu_set_dma_late / HIPEMU_DMA_LATE=1): a transfer lands only when an s_waitcnt
+// vmcnt(N) of its own wave forces it, i.e. when more than N younger LDS-DMA instructions of that lane's wave have been issued -- the
+// LATEST the hardware allows.  A counted wait that is too weak then reads stale LDS deterministically, on the CPU.  (Only LDS-DMA
+// instructions are counted: other vector-memory instructions in the hardware queue can only make a wait stricter.  The kernels issue
+// their DMA instructions wave-uniformly -- padding lanes fetch from a zero page -- so the per-lane queue equals the wave's.)
+inline int& dma_late() {
+  static int v = [] { const char* e = getenv("HIPEMU_DMA_LATE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+inline void dma_retire(Fiber* f, size_t keep) {
+  while (f->dmaq.size() - f->dma_head > keep) {
+    const PendingDma& d = f->dmaq[f->dma_head++];
+    memcpy(d.dst, d.src, d.size);
+  }
+  if (f->dma_head == f->dmaq.size()) { f->dmaq.clear(); f->dma_head = 0; }
+}
 struct Wave {
   int count = 0, alive = 0;
   unsigned gen = 0;
@@ -113,6 +133,7 @@ inline void trampoline() {
   Block* b = blk();
   b->body();
   Fiber* f = cur();
+  dma_retire(f, 0);
   f->done = true;
   b->alive--;
   b->w[f->wave].alive--;
@@ -144,6 +165,8 @@ inline void run_block(Block& b, int nthreads) {
   for (int t = 0; t < nthreads; ++t) {
     Fiber& f = b.f[t];
     f.done = false;
+    f.dmaq.clear();
+    f.dma_head = 0;
     f.stack.resize(256 * 1024);
     f.tid.x = t % b.bdim.x;
     f.tid.y = (t / b.bdim.x) % b.bdim.y;
@@ -261,12 +284,20 @@ inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_fence(int, const char*, ...) {}
-inline void __builtin_amdgcn_s_waitcnt(int) {}
-// LDS-DMA: destination = wave-uniform LDS base + lane * size (the emu copies synchronously)
+// s_waitcnt immediate (gfx9): vmcnt = imm[3:0] | imm[15:14] << 4.  Early mode: nothing to do.  Late mode: retire this lane's oldest
+// LDS-DMA transfers until at most vmcnt are outstanding.
+inline void __builtin_amdgcn_s_waitcnt(int imm) {
+  if (hipemu::dma_late()) hipemu::dma_retire(hipemu::cur(), (size_t)((imm & 15) | (((imm >> 14) & 3) << 4)));
+}
+// LDS-DMA: destination = wave-uniform LDS base + lane * size
 template <class SrcPtr, class DstPtr>
 inline void __builtin_amdgcn_global_load_lds(SrcPtr src, DstPtr lds_base, unsigned size, int offset, unsigned) {
-  memcpy((unsigned char*)(uintptr_t)lds_base + offset + (size_t)hipemu::cur()->lane * size, (const void*)(uintptr_t)src, size);
+  void* dst = (unsigned char*)(uintptr_t)lds_base + offset + (size_t)hipemu::cur()->lane * size;
+  if (hipemu::dma_late()) hipemu::cur()->dmaq.push_back({(const void*)(uintptr_t)src, dst, size});
+  else memcpy(dst, (const void*)(uintptr_t)src, size);
 }
+extern "C" __attribute__((visibility("default"), used)) inline void hipemu_set_dma_late(int v) { hipemu::dma_late() = v; }
+extern "C" __attribute__((visibility("default"), used)) inline int hipemu_get_dma_late() { return hipemu::dma_late(); }
 inline bool isinf(float v) { return std::isinf(v); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline unsigned long long wall_clock64() { return 0; }

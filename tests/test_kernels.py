@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import BOTH, HIP_ONLY
+from conftest import BOTH, HIP_ONLY, WITH_LATE_DMA
 from emu_util import bf16_round, empty_nhwc, from_nhwc, h16_round, to_nhwc, bf16_bits_to_f32
 from oracle import cpu_ops as O
 from oracle import graph_ref as G
@@ -262,7 +262,7 @@ def test_deconv2d_bn_act(be, case):
         assert np.abs(got2 - ref).max() <= 1.5 * _tol(dt, ref)
 
 
-@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("be", WITH_LATE_DMA, indirect=True)
 @pytest.mark.parametrize("case", [(BF16, 2, 9, 70, 128, 128, (3, 8), 4, 2), (BF16, 3, 17, 40, 128, 64, (3, 4), 2, 1), (BF16, 1, 20, 45, 64, 64, (3, 4), 2, 1),
                                   (F16, 2, 9, 70, 128, 64, (3, 8), 4, 2), (F16, 1, 11, 33, 64, 64, (3, 4), 2, 1)])
 def test_deconv2d_all_phases_in_one_launch(be, case):
@@ -347,7 +347,7 @@ def test_deconv2d_phase_pairs_equal_all_phases(be, case):
     assert f(buf, 128, 0, buf, 4096, buf, buf, 64, 0, buf, 64, 0, 1, 4, 8, 128, 64, 3, 8, 4, 2, fl, dt, be.stream) == R.RD_EINVAL          # pair images overlap
 
 
-@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("be", WITH_LATE_DMA, indirect=True)
 @pytest.mark.parametrize("case", [(F32, 1, 3, 40), (F32, 1, 9, 33), (BF16, 2, 10, 40), (F16, 2, 10, 40), (BF16, 8, 17, 70), (BF16, 4, 8, 33)])
 def test_meta_kernel_unit(be, case):
     """Fused Meta-Kernel unit vs the un-fused restatement of meta_kernel.py:166-240 + dla_backbone.py:92-97.  (8 images x 3 column
@@ -653,7 +653,7 @@ def test_conv3x3_ex_fp16(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), dt=F16)
 
 
-@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("be", WITH_LATE_DMA, indirect=True)
 @pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_conv3x3_ex_folded_scale(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True)
@@ -710,7 +710,7 @@ def test_conv3x3_cat_two_tensor_input(be, case):
     assert f(buf, 64, 0, 64, buf, 16, 8, 16, buf, buf, buf, 128, 0, 1, 4, 8, 128, fl, dt, be.stream) == R.RD_ESHAPE        # x2 channels exceed its stride
 
 
-@pytest.mark.parametrize("be", BOTH, indirect=True)
+@pytest.mark.parametrize("be", WITH_LATE_DMA, indirect=True)
 @pytest.mark.parametrize("case", [(BF16, 2, 16, 72, False, 64, 64), (BF16, 1, 11, 33, True, 64, 64), (F16, 1, 8, 100, False, 80, 64), (BF16, 3, 24, 64, True, 80, 64),
                                   (F16, 2, 9, 40, True, 64, 64), (BF16, 2, 16, 72, True, 16, 8), (F16, 1, 11, 33, True, 16, 5), (BF16, 3, 24, 64, True, 16, 16)],
                          ids=lambda c: "-".join(str(v) for v in c))
