@@ -346,6 +346,7 @@ def main(argv=None):
     A = pipe.alloc
     # one gather per pipeline and class (the two-class KITTI variant has two post-processors per pipeline)
     gathers = [[rdist.DetectionGather(p.bposts[c], shard, A, L) for c in p.class_names] for p in multi.pipes] if gather else None
+    comm_streams = [torch.cuda.Stream(device=dev) for _ in multi.pipes] if gather else None   # one communication stream per pipeline
     # every step's results go to the host like the reference's loop materialises every frame (tools/test.py:151-153):
     # per pipeline, pinned host buffers for the (B, 200, 8) boxes, the keep counts and the candidate counts, filled by async
     # copies on the batch's post-processing stream
@@ -401,14 +402,15 @@ def main(argv=None):
                 hc["d8"].copy_(A.view_f32(hc["stage"], (Bf, rdist.MAX_DET, 8)), non_blocking=True)
                 hc["nkeep"].copy_(A.view_i32(bp.nkeep, (Bf,)), non_blocking=True)
                 hc["count"].copy_(A.view_i32(bp.count, (Bf,)), non_blocking=True)
+            done_on = pj._post_stream
             if gather:
-                # the ONE collective of the path, enqueued behind this batch's post-processing on its post-processing stream (the batch's
-                # own launch stream with two batches in flight, pipeline.InterleavedPipelines): the other
-                # batch's forward overlaps it, nothing on a launch stream waits for it
+                # the ONE collective of the path: packed behind this batch's post-processing on its post-processing stream (the batch's own
+                # launch stream with two or more batches in flight), but ENQUEUED ON THE PIPELINE'S COMMUNICATION STREAM behind the pack's
+                # event -- no launch stream carries a collective, so a late rank delays only this batch's harvest, not the kernels behind it
                 for g_ in gathers[j]:
-                    g_.enqueue(pj._post_stream)
+                    done_on = g_.enqueue(pj._post_stream, comm_streams[j])
             h["done"] = torch.cuda.Event(enable_timing=True)
-            h["done"].record(pj._post_stream)
+            h["done"].record(done_on)
             h["step"] = i
             done_events.append(h["done"])      # (completion time of every step: the per-step percentiles of the report)
 
@@ -446,8 +448,14 @@ def main(argv=None):
         # by n -- (steps - n) samples per region
         nw = len(multi.pipes)
         step_ms += [done_events[i].elapsed_time(done_events[i + nw]) / nw for i in range(len(done_events) - nw)]
+    region_by_rank = None
     if gather:
         t = torch.tensor(region_s, device=dev, dtype=torch.float64)
+        allr = torch.empty(world * len(region_s), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, t)                  # every rank's own clock around every region: stragglers show as a spread
+        per = allr.view(world, -1).cpu().numpy() * 1e3
+        region_by_rank = {"median_ms_per_rank": [round(float(np.median(r_)), 3) for r_ in per],
+                          "min_ms": round(float(per.min()), 3), "max_ms": round(float(per.max()), 3)}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.cpu()]
     elapsed = float(np.median(region_s))
@@ -587,7 +595,7 @@ def main(argv=None):
             # ms_per_step_p5/p50/p95 come from the completion events of the individual steps (interval between the completions of
             # steps i and i + n over n = batches in flight, (steps - n) x repeats samples; own-rank events -- rank 0 for N > 1)
             "repeats": repeats, "value_min": args.steps * world * Bf / max(region_s), "value_max": args.steps * world * Bf / min(region_s),
-            "region_ms": [round(v * 1e3, 3) for v in region_s],
+            "region_ms": [round(v * 1e3, 3) for v in region_s], "region_ms_by_rank": region_by_rank,
             "ms_per_step_p5": float(np.percentile(step_ms, 5)) if step_ms else None,
             "ms_per_step_p50": float(np.percentile(step_ms, 50)) if step_ms else None,
             "ms_per_step_p95": float(np.percentile(step_ms, 95)) if step_ms else None,

@@ -1,12 +1,14 @@
 """Frame-parallel multi-GPU execution: one process per GPU, frame f -> rank f % world, weights replicated, NO data-path
 collective -- the reference's eval driver does the same with one DetModule per GPU fed from a shared queue
 (tools/test.py:117-161).  The only exchange is the gather of the final detections, one `all_gather` of a fixed-size padded
-record per step (RCCL over xGMI on the GPUs: latency-only, 77 KB per rank for 8 frames), enqueued on the batch's
-post-processing stream behind its NMS so that no launch stream ever waits for it.
+record per step (RCCL over xGMI on the GPUs: latency-only, 77 KB per rank for 8 frames).  The pack (two strided device copies) runs
+behind the batch's NMS on its post-processing stream; the COLLECTIVE runs on a communication stream of its own that waits for the
+pack's event (round 6): no launch stream ever carries a collective, so a rank that arrives late stalls only the peers' communication
+streams (and, through the completion event, the host's harvest of THAT batch), never the kernels of the batches behind it.
 
     shard    = FrameSharding(rank, world)             which frames are mine / where a gathered record belongs
     gatherer = DetectionGather(post, shard, alloc)    pack (rd_copy_rows) + all_gather of a BatchPostProcessor's results
-    gatherer.enqueue(stream)   ...   frames = gatherer.unpack()     # {global frame index: (rows (M,12), M)} on every rank
+    gatherer.enqueue(stream, comm_stream)   ...   frames = gatherer.unpack()     # {global frame index: (rows (M,12), M)} on every rank
 
 The backend is whatever process group is initialised ("nccl" == RCCL on the GPUs; "gloo" in the CPU test tier, where the
 buffers are host memory and the same code runs).
@@ -166,6 +168,7 @@ class DetectionGather:
         self.nrow = min(max_det, post.cap)
         self.src = alloc.alloc(self.B * self.rec * 4, zero=True)
         self.dst = alloc.alloc(shard.world * self.B * self.rec * 4, zero=True)
+        self._work = None
 
     def _as_torch(self, buf, shape):
         import torch
@@ -173,8 +176,10 @@ class DetectionGather:
             return torch.from_numpy(buf[: int(np.prod(shape)) * 4].view(np.float32).reshape(shape))
         return self.A.view_f32(buf, shape)
 
-    def enqueue(self, stream=None):
-        """On `stream` (the batch's post-processing stream; None = current): pack, then the collective."""
+    def enqueue(self, stream=None, comm_stream=None):
+        """pack on `stream` (the batch's post-processing stream; None = current), then the collective on `comm_stream` behind the pack's
+        event (None: on `stream` itself -- host buffers / gloo, or a caller with a single stream).  Returns the stream whose completion
+        covers the gathered buffer (record the batch's done event THERE)."""
         import torch.distributed as dist
         A, L, p = self.A, self.L, self.post
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
@@ -182,14 +187,26 @@ class DetectionGather:
         L.call("rd_copy_rows", A.ptr(p.nkeep), 4, A.ptr(self.src), self.rec * 4, self.max_det * 48, 4, self.B, st)
         src = self._as_torch(self.src, (self.B * self.rec,))
         dst = self._as_torch(self.dst, (self.shard.world * self.B * self.rec,))
+        if comm_stream is not None and hasattr(A, "torch"):
+            A.wait_event(A.record_event(stream), comm_stream)
+            with A.torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(dst, src)
+            return comm_stream
         if stream is not None and hasattr(A, "torch"):
             with A.torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(dst, src)
-        else:
+        elif hasattr(A, "torch"):
             dist.all_gather_into_tensor(dst, src)
+        else:
+            # host buffers (gloo): the same contract as on the GPU -- enqueue returns at once, unpack() waits for THIS gather only
+            self._work = dist.all_gather_into_tensor(dst, src, async_op=True)
+        return stream
 
     def unpack(self, step=0, sync=True):
         """{global frame index: (rows (M,12) float32, M)} for the B frames of every rank at `step` (host copy)."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         if sync:
             self.A.sync()
         buf = self._as_torch(self.dst, (self.shard.world, self.B, self.rec))

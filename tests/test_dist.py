@@ -100,6 +100,74 @@ def test_frame_sharding_and_gather_gloo(world):
         assert np.abs(rows[:, 8] - ref[:rows.shape[0], 8]).max() < 1e-5     # yaw column: atan2f of the score filter
 
 
+def _late_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    from rangedet_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    shard = rdist.FrameSharding()
+    B, cap = 2, 32
+
+    def make(step):
+        class _Post:      # the fields of pipeline.BatchPostProcessor the gather reads
+            pass
+        post = _Post()
+        post.B, post.cap = B, cap
+        rows = np.zeros((B, cap, 12), np.float32)
+        nk = np.zeros(B, np.int32)
+        for j, f in enumerate(shard.frames_of_step(step, B)):
+            nk[j] = 1 + f % 7
+            rows[j, :nk[j]] = 100.0 * f + np.arange(nk[j], dtype=np.float32)[:, None]
+        post.out, post.nkeep = rows.view(np.uint8).reshape(-1), nk.view(np.uint8)
+        return rdist.DetectionGather(post, shard, rdist.HostAlloc, rdist.HostCopyLib, max_det=8), (rows, nk)
+    dist.barrier()
+    g0, keep0 = make(0)          # two pipelines' gathers, as bench.py / evaluate hold them
+    g1, keep1 = make(1)
+    if rank == 1:
+        time.sleep(1.5)          # the late rank: its batch 0 is not ready yet
+    t0 = time.perf_counter()
+    g0.enqueue()                 # rank 0: its peer has not arrived -- the enqueue must return, ...
+    t_enq0 = time.perf_counter() - t0
+    g1.enqueue()                 # ... and so must the NEXT batch's (nothing queues up behind the first collective)
+    t_enq1 = time.perf_counter() - t0
+    got0 = g0.unpack(0)          # only the harvest of batch 0 waits for the late rank
+    t_done0 = time.perf_counter() - t0
+    got1 = g1.unpack(1)
+    ok = True
+    for step, got in ((0, got0), (1, got1)):
+        ok = ok and sorted(got) == sorted(f for r in range(world) for f in shard.frames_of_step(step, B, rank=r))
+        for f, (rw, M) in got.items():
+            ok = ok and M == 1 + f % 7 and np.array_equal(rw[:, 0], 100.0 * f + np.arange(M, dtype=np.float32))
+    out.put((rank, t_enq0, t_enq1, t_done0, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_enqueue_does_not_wait_for_a_late_rank():
+    """the collective lives on its own communication stream (GPU) / is asynchronous (host buffers): a rank whose
+    peer is 1.5 s late gets both of its enqueues back at once; only the harvest (unpack) of that batch waits.  (tools/test.py:139-170
+    has no collective at all -- its result queue never blocks a GPU thread.)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    enq0, enq1, done0, ok = res[0]
+    assert ok and res[1][3]
+    assert enq0 < 0.5 and enq1 < 0.5, "rank 0's enqueues waited for the late rank: %.2f s, %.2f s" % (enq0, enq1)
+    assert done0 > 1.0, "rank 0's harvest of batch 0 cannot complete before the late rank arrived (%.2f s)" % done0
+
+
 def test_sharding_arithmetic():
     from rangedet_amd.dist import FrameSharding, record_floats
     s = FrameSharding(rank=3, world=8)
