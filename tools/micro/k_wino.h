@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void wino3x3_stream_kernel(WinoArgs a) {
   {                                                                                                                \
     constexpr int ks_ = (O) >> 2, mi_ = (O) & 3, on_ = ((O) + 1) & 7, nks_ = on_ >> 2, nmi_ = on_ & 3;             \
     constexpr int cur_ = (O) & 1, nxt_ = cur_ ^ 1;                                                                 \
-    constexpr bool job_ = mi_ < 3;                                                                                 \
+    constexpr bool job_ = mi_ < 3 && !(DBG & 64);                                                                                 \
     constexpr bool z_ = (FIRST) && ks_ == 0 && (mi_ == 1 || mi_ == 2);                                             \
     constexpr int nraw_ = wn_nraw(O), rf_ = wn_raw_first(O);                                                       \
     const int jraw_ = ks_ == 0 ? rawcur : WN_RAWB - rawcur;   /* window ks 0 transforms raw(u) -> V half 1, ks 1 raw(u+1) -> V half 0 */ \
@@ -420,15 +420,33 @@ inline int wino_num_cus() {
 #endif
 }
 
-template <int DT>
-inline int launch_wino_dt(const WinoArgs& a0, hipStream_t st) {
-  WinoArgs a = a0;
-  auto k = wino3x3_stream_kernel<DT, 0>;
+template <int DT, int DBG>
+inline int launch_wino_dbg(const WinoArgs& a, hipStream_t st) {
+  auto k = wino3x3_stream_kernel<DT, DBG>;
   static std::atomic<unsigned long long> seen{0};
   once_per_device(seen, [&] { allow_big_lds(k); });
   const int grid = std::min(a.ntiles, wino_num_cus());
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), WN_LDS, st, a);
   return check_launch("wino3x3_stream_kernel");
+}
+template <int DT>
+inline int launch_wino_dt(const WinoArgs& a, hipStream_t st) {
+#ifdef WN_ABLATIONS   // WINO_DBG=n (harness only): 4 no DMA after the prologue, 8 no MFMAs, 64 no transform jobs, 2 no barriers, 1 no stores
+  static const int dbg = getenv("WINO_DBG") ? atoi(getenv("WINO_DBG")) : 0;
+  if (DT == RD_BF16) {
+    switch (dbg) {
+      case 4: return launch_wino_dbg<RD_BF16, 4>(a, st);
+      case 8: return launch_wino_dbg<RD_BF16, 8>(a, st);
+      case 64: return launch_wino_dbg<RD_BF16, 64>(a, st);
+      case 68: return launch_wino_dbg<RD_BF16, 68>(a, st);
+      case 70: return launch_wino_dbg<RD_BF16, 70>(a, st);
+      case 12: return launch_wino_dbg<RD_BF16, 12>(a, st);
+      case 76: return launch_wino_dbg<RD_BF16, 76>(a, st);
+      default: break;
+    }
+  }
+#endif
+  return launch_wino_dbg<DT, 0>(a, st);
 }
 
 // x (B, H, W, x_cs) 16-bit, cin % 32 == 0, cout = 128; w = pack_wino_frag image; shift (128) or null; res / y like rd_conv3x3_bn_act_ex

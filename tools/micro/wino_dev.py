@@ -163,8 +163,8 @@ else:
     st = torch.cuda.current_stream().cuda_stream
     dev = "cuda"
     bench = len(sys.argv) > 2
-    shapes = ((8, 64, 2656, 128), (8, 64, 1328, 128), (8, 64, 664, 128), (8, 64, 332, 128), (8, 64, 166, 128), (3, 64, 2650, 64), (1, 21, 77, 32))
-    for dt, tdt in ((R.RD_BF16, torch.bfloat16), (R.RD_F16, torch.float16)):
+    shapes = ((8, 64, 2656, 128),) if os.environ.get("WINO_DBG") else ((8, 64, 2656, 128), (8, 64, 1328, 128), (8, 64, 664, 128), (8, 64, 332, 128), (8, 64, 166, 128), (3, 64, 2650, 64), (1, 21, 77, 32))
+    for dt, tdt in ((R.RD_BF16, torch.bfloat16),) if os.environ.get("WINO_DBG") else ((R.RD_BF16, torch.bfloat16), (R.RD_F16, torch.float16)):
         for (B, H, W, cin) in shapes:
             for flags in (R.RD_RELU_POST, R.RD_ADD | R.RD_RELU_POST):
                 if flags & R.RD_ADD and not (W in (664, 77)):
@@ -228,4 +228,5 @@ else:
                         res[name] = e0.elapsed_time(e1) * 1e3 / n
                     line += "   us: " + "  ".join("%s %.1f" % kv for kv in res.items())
                 print(line, flush=True)
-                assert nan == 0 and ew < 4 * ed + 1e-3 and mw < 0.2, "Winograd result out of tolerance"
+                if not os.environ.get("WINO_DBG"):
+                    assert nan == 0 and ew < 4 * ed + 1e-3 and mw < 0.2, "Winograd result out of tolerance"
