@@ -267,14 +267,22 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
+    ap.add_argument("--graph", action="store_true",
+                    help="hipGraph replay: every pipeline captures its ~80 launches per batch once per input set and replays them with one call "
+                         "(pipeline.RangeDetPipeline(graph=True)); same results (config.results_sha256_all_steps), ~1 ms less host work per step")
+    ap.add_argument("--wnms-no-skip", action="store_true",
+                    help="diagnostic (rdlib.RD_WNMS_DIAG_NO_SKIP): the weighted NMS clips every pair the reference clips -- same results, for A/B and tests")
     ap.add_argument("--wnms-cap", type=int, default=8192, help="rows per frame the weighted NMS is sized for (checked every step)")
     ap.add_argument("--backbone-reps", type=int, default=10,
                     help="replays of the Meta-Kernel + DLA backbone steps for the `meta_dla_forward` block (0: skip that block -- the rocprofv3 / PMC "
                          "passes of tools/profile_round.sh use 0 so that every profiled launch belongs to a full forward and the per-kernel averages "
                          "are those of the `roofline` block)")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="the timed region of --steps steps (barrier + synchronize on both sides) is run this many times back to back; "
-                         "`value` / `ms_per_step` are the MEDIAN region, the spread is reported next to it (SURVEY.md 8d: median + p5/p95)")
+                         "`value` / `ms_per_step` are the MEDIAN region, the spread is reported next to it (SURVEY.md 8d: median + p5/p95).  "
+                         "0 (default): as many regions as it takes for --min-timed-s seconds of timed GPU work (at least 5, at most 200), decided "
+                         "from the first region -- so that the run is long enough for an outside utilisation sampler to see it")
+    ap.add_argument("--min-timed-s", type=float, default=8.0, help="with --repeats 0: total duration of the timed regions to aim for")
     args = ap.parse_args(argv)
     argv = list(sys.argv[1:] if argv is None else argv)
 
@@ -332,7 +340,8 @@ def main(argv=None):
         params = synth.make_weights(seed=18)
         pkw = {}
     multi = InterleavedPipelines(params, n=max(1, args.inflight), dtype=dt, wnms_cap=args.wnms_cap, batch=Bf,
-                                 tie_order=args.tie_order, **pkw)
+                                 tie_order=args.tie_order, wnms_diag=rdlib.RD_WNMS_DIAG_NO_SKIP if args.wnms_no_skip else 0,
+                                 graph=args.graph, **pkw)
     pipe = multi.pipes[0]   # (per-kernel profiling replay and the roofline figures use one pipeline on the default stream)
     # each rank owns its own frames (frame f -> rank f % world), resident in HBM before timing
     # (synthetic raw records through the device transform chain, rd_input_transform)
@@ -420,6 +429,14 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.graph:
+        # set-up, not a step (nothing is harvested): every pipeline meets every input set once -- that enqueue runs eagerly and captures the
+        # graph (a device-wide synchronisation each) -- so that every warm-up and timed step below is a replay
+        for j_, p_ in enumerate(multi.pipes):
+            for f_ in frames:
+                with multi.stream_context(j_):
+                    p_.enqueue(f_)
+        torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -430,10 +447,12 @@ def main(argv=None):
     # --repeats times back to back (step numbering continues, so the pipelines keep alternating); the headline is the MEDIAN
     # region, and the completion event of every step gives the per-step distribution (interval between consecutive completions
     # inside a region: with two batches in flight that is the steady-state time per step).
-    repeats = max(1, args.repeats)
+    repeats = max(1, args.repeats) if args.repeats > 0 else 5
     region_s, step_ms = [], []
     nstep = args.warmup
-    for r in range(repeats):
+    r = 0
+    while r < repeats:
+        r += 1
         del done_events[:]
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -443,6 +462,11 @@ def main(argv=None):
         for j in sorted(range(len(multi.pipes)), key=lambda j_: host[j_].get("step", -1)):     # in step order: the all-steps digest does not
             harvest(j)                                                                             # depend on --inflight
         region_s.append(time.perf_counter() - t0)
+        if args.repeats <= 0 and r == 1:      # auto: the number of regions from the first one (the same decision on every rank)
+            first = torch.tensor([region_s[0]], device=dev, dtype=torch.float64)
+            if gather:
+                dist.all_reduce(first, op=dist.ReduceOp.MAX)
+            repeats = int(min(200, max(5, np.ceil(args.min_timed_s / max(float(first.item()), 1e-4)))))
         # steady-state time per step from the completion events: with n batches in flight on n pipelines the completions come in
         # bursts of n (the streams share the GPU and finish together), so the interval is taken over a window of n steps and divided
         # by n -- (steps - n) samples per region
@@ -596,6 +620,7 @@ def main(argv=None):
             # steps i and i + n over n = batches in flight, (steps - n) x repeats samples; own-rank events -- rank 0 for N > 1)
             "repeats": repeats, "value_min": args.steps * world * Bf / max(region_s), "value_max": args.steps * world * Bf / min(region_s),
             "region_ms": [round(v * 1e3, 3) for v in region_s], "region_ms_by_rank": region_by_rank,
+            "timed_gpu_s": round(float(sum(region_s)), 3),      # all timed regions together: what an outside GPU-utilisation sampler can see
             "ms_per_step_p5": float(np.percentile(step_ms, 5)) if step_ms else None,
             "ms_per_step_p50": float(np.percentile(step_ms, 50)) if step_ms else None,
             "ms_per_step_p95": float(np.percentile(step_ms, 95)) if step_ms else None,
@@ -610,6 +635,7 @@ def main(argv=None):
                        "wnms_candidates": int(res["num_candidates"]), "wnms_kept": int(len(res["keep_inds"])),
                        "per_class": {c: {"candidates": int(r["num_candidates"]), "kept": int(len(r["keep_inds"]))}
                                      for c, r in res.get("per_class", {}).items()} or None,
+                       "hip_graph": {"replays": int(sum(p_.graph_replays for p_ in multi.pipes)), "graphs": int(sum(len(p_._graphs) for p_ in multi.pipes))} if args.graph else None,
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames, "gather_matches_local": gather_matches_local,

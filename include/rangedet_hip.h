@@ -287,6 +287,14 @@ int rd_score_filter_dets_batched(const float* scores, long scores_bstride, const
 #define RD_WNMS_MAX_K 65536
 #define RD_TIE_STABLE 0
 #define RD_TIE_REFERENCE 1
+/* Diagnostic bits that may be OR-ed into tie_order (per call; the RESULT never depends on them -- they select code paths so that tests
+ * can compare them bit for bit; until round 5 these were environment variables of the library):
+ *   RD_WNMS_DIAG_NO_SKIP        clip every pair the reference clips (no rejection test, see rd_wnms_pair_skippable)
+ *   RD_WNMS_DIAG_TILE_W(n)      scan column chunks of n 64-row words (1..255): the column-chunked scan of K > 16 384 at any K
+ *   RD_WNMS_DIAG_MERGE_LDS(n)   merge neighbourhood list of n entries in LDS (4..127): the global-scratch merge path at small K */
+#define RD_WNMS_DIAG_NO_SKIP 0x100
+#define RD_WNMS_DIAG_TILE_W(n) (((n) & 0xff) << 16)
+#define RD_WNMS_DIAG_MERGE_LDS(n) (((n) & 0x7f) << 24)
 size_t rd_wnms_workspace_bytes(int Kcap);
 int rd_wnms_4c(const float* dets, int Kcap, const int* d_count, const int* order, int tie_order, float thresh,
                float thresh_vote, int is3d, int hash_scale, float* out_dets, int* keep, int* d_nkeep, void* ws,

@@ -1,4 +1,7 @@
-"""Build librangedet_hip.so (gfx950) in-tree with hipcc.  ``python -m rangedet_amd.build [--force]``."""
+"""Build librangedet_hip.so (gfx950) in-tree with hipcc.  ``python -m rangedet_amd.build [--force] [--dev]``.
+
+The default build is the RELEASE library: no development switch, no getenv (csrc/rd_common.h).  ``--dev`` builds
+librangedet_hip_dev.so with -DRD_DEV_SWITCHES next to it (the A/B library of tools/exp/ab.sh: load it with RANGEDET_HIP_LIB=...)."""
 import glob
 import os
 import re
@@ -15,8 +18,28 @@ OUT = os.path.join(HERE, "librangedet_hip.so")
 # form returns a wrong low half in lanes 48-63 whenever ANOTHER wave of the same SIMD is issuing MFMA instructions -- i.e. whenever the
 # weighted NMS of one batch overlaps the convolutions of the next (reproducer: tools/micro/pkform_test.py, aggr_test.py).
 # packed_swap_lint() below fails the build if such an instruction is left in the code object.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Xarch_device", "-fno-slp-vectorize"]
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
+CODEGEN_FLAGS = ["-Xarch_device", "-fno-slp-vectorize"]     # (part of source_hash(): they change the device code)
+FLAGS = BASE_FLAGS + CODEGEN_FLAGS
+OUT_DEV = os.path.join(HERE, "librangedet_hip_dev.so")
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _objdump():
+    """llvm-objdump of the SAME ROCm install as the compiler (RD_OBJDUMP overrides; ADVICE r5: the path was hard-coded)."""
+    if os.environ.get("RD_OBJDUMP"):
+        return os.environ["RD_OBJDUMP"]
+    roots = [os.environ.get("ROCM_PATH"), os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "/opt/rocm"]
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, "lib", "llvm", "bin", "llvm-objdump")):
+            return os.path.join(r, "lib", "llvm", "bin", "llvm-objdump")
+    found = shutil.which("llvm-objdump")
+    if found:
+        return found
+    raise RuntimeError("packed_swap_lint: no llvm-objdump next to %s (set ROCM_PATH or RD_OBJDUMP)" % _hipcc())
 
 
 def source_hash():
@@ -24,7 +47,7 @@ def source_hash():
     carry it, bench.py only quotes a measured HBM traffic figure whose hash matches the sources it runs)."""
     import hashlib
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS[6:]).encode())               # code-generation flags added since the first measured profile
+    h.update(" ".join(CODEGEN_FLAGS).encode())           # code-generation flags added since the first measured profile
     for f in sorted(glob.glob(os.path.join(HERE, "csrc", "*"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
@@ -32,10 +55,7 @@ def source_hash():
 
 
 def stale():
-    if not os.path.exists(OUT):
-        return True
-    deps = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(HERE, "..", "include", "rangedet_hip.h")]
-    return os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps)
+    return _stale(OUT)
 
 
 _PK = re.compile(r"\b(v_pk_(?:mul|add|fma)_f32)\b(.*)")
@@ -64,6 +84,7 @@ def packed_swap_lint(so=OUT):
     try:
         tmp = os.path.join(td, "lib.so")
         shutil.copy(so, tmp)
+        OBJDUMP = _objdump()
         subprocess.check_call([OBJDUMP, "--offloading", tmp], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         objs = [f for f in glob.glob(os.path.join(td, "lib.so.*")) if "gfx950" in f]
         if len(objs) != 1:
@@ -84,22 +105,34 @@ def packed_swap_lint(so=OUT):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
-        return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp_out = OUT + ".new"
-    cmd = [hipcc] + FLAGS + os.environ.get("RD_EXTRA_HIPCC_FLAGS", "").split() + [SRC, "-o", tmp_out]   # e.g. -DRD_CONV3_DEV
+def _stale(out):
+    if not os.path.exists(out):
+        return True
+    deps = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(HERE, "..", "include", "rangedet_hip.h")]
+    return os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=True, dev=False):
+    """dev=True: librangedet_hip_dev.so with -DRD_DEV_SWITCHES (the environment-driven A/B switches of csrc/rd_common.h)."""
+    out = OUT_DEV if dev else OUT
+    if not force and not _stale(out):
+        return out
+    # (a per-process temporary name: several ranks that find the library stale at once must not clobber each other's output)
+    tmp_out = "%s.new.%d" % (out, os.getpid())
+    cmd = [_hipcc()] + FLAGS + (["-DRD_DEV_SWITCHES"] if dev else []) + os.environ.get("RD_EXTRA_HIPCC_FLAGS", "").split() + [SRC, "-o", tmp_out]   # e.g. -DRD_CONV3_DEV
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    bad = packed_swap_lint(tmp_out)
-    if bad and not os.environ.get("RD_ALLOW_PACKED_SWAP"):        # (the switch exists for the A/B of the fault itself)
-        os.remove(tmp_out)
-        raise RuntimeError("librangedet_hip.so: %d packed-fp32 instructions with swapped source halves (wrong next to MFMA waves on gfx950, "
-                           "DESIGN.md 6.4), first: %s in %s" % (len(bad), bad[0][1], bad[0][0]))
-    os.replace(tmp_out, OUT)
-    return OUT
+    try:
+        subprocess.check_call(cmd)
+        bad = packed_swap_lint(tmp_out)
+        if bad and not os.environ.get("RD_ALLOW_PACKED_SWAP"):        # (the switch exists for the A/B of the fault itself)
+            raise RuntimeError("%s: %d packed-fp32 instructions with swapped source halves (wrong next to MFMA waves on gfx950, "
+                               "DESIGN.md 6.4), first: %s in %s" % (os.path.basename(out), len(bad), bad[0][1], bad[0][0]))
+        os.replace(tmp_out, out)
+    finally:
+        if os.path.exists(tmp_out):
+            os.remove(tmp_out)
+    return out
 
 
 if __name__ == "__main__":
@@ -109,4 +142,4 @@ if __name__ == "__main__":
             print(k[:80], "|", ins)
         print("%d packed-fp32 instructions with a swapped second/third source" % len(hits))
         sys.exit(1 if hits else 0)
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -324,6 +324,9 @@ int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const v
   RD_REQUIRE(B > 0 && H > 0 && W > 0, RD_ESHAPE, "block64: shape");
   RD_REQUIRE(cin == 64 || (cin >= 1 && cin <= 16), RD_ESHAPE, "block64: %d input channels (64, or at most 16 for the network's first block)", cin);
   RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff >= 0 && x_coff + cin_slots(cin, RD_BF16) * 8 <= x_cstride, RD_ESHAPE, "block64: x channel stride / offset");
+  // (the first block's shortcut epilogue loads a whole 16-channel k-slot of x per pixel -- cin_slots() rounds cin <= 16 up to
+  //  exactly that, so an 8-channel pitch is refused above; said once more explicitly so that it survives a change of cin_slots)
+  RD_REQUIRE(cin > 16 || x_coff + 16 <= x_cstride, RD_ESHAPE, "block64: the first block reads 16 channels per pixel (x_coff %d + 16 > x_cstride %d)", x_coff, x_cstride);
   RD_REQUIRE(y_cstride % 8 == 0 && y_coff % 8 == 0 && y_coff >= 0 && y_coff + 64 <= y_cstride, RD_ESHAPE, "block64: y channel stride / offset");
   RD_REQUIRE(x != y, RD_EINVAL, "block64: in-place (a tile's halo is another tile's output)");
   return launch_block64(x, x_cstride, x_coff, cin, w_packed, shift1, shift2, sc_w_packed, y, y_cstride, y_coff, B, H, W, dtype, (hipStream_t)stream);
@@ -646,7 +649,8 @@ int rd_meta_kernel_fwd(const void* data, int d_cstride, int d_coff, const float*
     else hipLaunchKernelGGL((meta16_kernel<WAVES, RD_BF16>), mgrid, mblock, lds, st, a);
   } else {
     const size_t lds = consts + (size_t)(WAVES + 2) * 34 * 256;
-    allow_big_lds(meta_kernel<RD_F32, WAVES>);
+    static std::atomic<unsigned long long> seen32{0};
+    once_per_device(seen32, [] { allow_big_lds(meta_kernel<RD_F32, WAVES>); });
     hipLaunchKernelGGL((meta_kernel<RD_F32, WAVES>), dim3(std::min(a.ntiles, 512)), dim3(WAVES * 64), lds, st, a);
   }
   return check_launch("meta_kernel");
@@ -732,12 +736,22 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   RD_REQUIRE(dets && out_dets && keep && d_nkeep && ws, RD_EINVAL, "wnms_4c: null pointer");
   RD_REQUIRE(Kcap > 0 && Kcap <= RD_WNMS_MAX_K, RD_ESHAPE, "wnms_4c: Kcap %d not in [1, %d]", Kcap, RD_WNMS_MAX_K);
   RD_REQUIRE(B > 0, RD_ESHAPE, "wnms_4c: batch %d", B);
+  // diagnostic bits of tie_order (include/rangedet_hip.h RD_WNMS_DIAG_*): per-call test aids, results do not depend on them
+  const int diag = tie_order & ~0xff;
+  tie_order &= 0xff;
   RD_REQUIRE(tie_order == RD_TIE_STABLE || tie_order == RD_TIE_REFERENCE, RD_EINVAL, "wnms_4c: tie_order %d", tie_order);
+  RD_REQUIRE(!(diag & ~(RD_WNMS_DIAG_NO_SKIP | (0xff << 16) | (0x7f << 24))), RD_EINVAL, "wnms_4c: unknown diagnostic bits 0x%x", diag);
   const size_t per = rd_wnms_workspace_bytes(Kcap);
   RD_REQUIRE(ws_bytes >= per * (size_t)B, RD_EWORKSPACE, "wnms_4c: workspace %zu < %zu", ws_bytes, per * (size_t)B);
   RD_REQUIRE(order || B == 1 || tie_order == RD_TIE_REFERENCE, RD_EINVAL,
              "wnms_4c: the batched call needs an explicit processing order or RD_TIE_REFERENCE");
   hipStream_t st = (hipStream_t)stream;
+  // (every kernel of the chain that may take more than 64 KB of dynamic LDS, once per device: no runtime-API call besides the launches
+  //  themselves is left on the path, so the whole chain can be captured into a hipGraph -- pipeline.RangeDetPipeline(graph=True))
+  static std::atomic<unsigned long long> seen_lds{0};
+  once_per_device(seen_lds, [] {
+    allow_big_lds(wnms_tie_order_kernel); allow_big_lds(wnms_scan_kernel); allow_big_lds(wnms_scan4_kernel); allow_big_lds(wnms_merge_kernel);
+  });
   WnmsWs w = wnms_ws_carve(ws, Kcap);
   ProfScope ps(RD_PROF_WNMS, st);
   // consecutive frames use consecutive `per`-byte workspaces (per is a multiple of 256), so every carved array of
@@ -748,7 +762,6 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const int* ord = order;
   if (!ord && tie_order == RD_TIE_REFERENCE) {   // the reference's own order: std::sort replayed on the device
     const size_t lds = TIE_STACK_BYTES + (Kcap <= TIE_LDS_K ? (size_t)Kcap * 8 + 3 * ((size_t)Kcap / 32 + 2) * 4 : 0);
-    allow_big_lds(wnms_tie_order_kernel);
     hipLaunchKernelGGL(wnms_tie_order_kernel, dim3(1, 1, B), dim3(256), lds, st, dets, Kcap, d_count, w.order, bs, (long)(per / 4),
                        w.scratch);
     ord = w.order;
@@ -767,14 +780,11 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const int nb = (Kcap + 63) / 64;
   hipLaunchKernelGGL(wnms_prep_kernel, dim3((Kcap + 255) / 256, 1, B), dim3(256), 0, st, dets, ord, Kcap, d_count, w.prep, bs,
                      (float)hash_scale, w.novf);
-  // RD_WNMS_TILE_W / RD_WNMS_MERGE_LDS: test switches that force the column-chunked scan and the merge overflow path at small K
-  // (read per call, once per batch of frames: the tests set them around single calls)
-  const char* e_tw_ = getenv("RD_WNMS_TILE_W");
-  const char* e_ml_ = getenv("RD_WNMS_MERGE_LDS");
-  const int e_tw = e_tw_ ? atoi(e_tw_) : 0, e_ml = e_ml_ ? atoi(e_ml_) : 0;
+  // RD_WNMS_DIAG_TILE_W(n) / RD_WNMS_DIAG_MERGE_LDS(n): per-call test aids that force the column-chunked scan and the merge overflow
+  // path at small K (environment variables until round 5)
+  const int e_tw = (diag >> 16) & 0xff, e_ml = (diag >> 24) & 0x7f;
   const int tile_w = std::min(w.nwcap, e_tw ? std::max(1, e_tw) : 256);
   const size_t scan_lds = ((size_t)w.nwcap + (size_t)64 * tile_w) * 8;
-  allow_big_lds(wnms_scan_kernel);
   // Two rounds.  The greedy scan only ever reads the thr / vote rows of boxes it KEEPS, and the highest-scoring boxes
   // suppress most of the rest: round 1 evaluates the pairs of the first R1 rows and scans them; round 2 evaluates pairs
   // only for the later rows that are still unsuppressed (compacted list) and resumes the scan.  Results are identical
@@ -790,8 +800,8 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   // reference's clipper returns on disjoint boxes (<= 4.2e-7 inside the test's domain, profiles/r04_nms_spurious_study.txt), and it
   // was characterised on the BEV value only: in 3-D mode the reference divides the clipped area x height overlap by a volume sum
   // that non-positive or cancelling heights can make arbitrarily small (nms.h:234-246), so there every pair is clipped.
-  // RD_WNMS_NO_SKIP: every pair clipped (A/B)
-  const int allow_skip = thresh >= 1e-3f && thresh_vote >= 1e-3f && !is3d && !dev_switches().wnms_no_skip;
+  // RD_WNMS_DIAG_NO_SKIP (per call; dev builds also RD_WNMS_NO_SKIP): every pair clipped (A/B)
+  const int allow_skip = thresh >= 1e-3f && thresh_vote >= 1e-3f && !is3d && !dev_switches().wnms_no_skip && !(diag & RD_WNMS_DIAG_NO_SKIP);
   auto pairs = [&](const int* rows, const int* nrows, const unsigned long long* supp, int rb_end) {
     auto k = dev_switches().wnms_bal ? (ct == 8 ? wnms_pairs_kernel<8, true> : ct == 16 ? wnms_pairs_kernel<16, true> : wnms_pairs_kernel<32, true>)
                                      : (ct == 8 ? wnms_pairs_kernel<8, false> : ct == 16 ? wnms_pairs_kernel<16, false> : wnms_pairs_kernel<32, false>);
@@ -803,7 +813,6 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
   const bool scan4 = w.nwcap <= 128 && !e_tw && !dev_switches().wnms_scan1;
   const int tile_words = 64 * 128;
   const size_t scan4_lds = ((size_t)w.nwcap + tile_words) * 8;
-  if (scan4) allow_big_lds(wnms_scan4_kernel);
   auto scan = [&](int c_begin, int c_end, unsigned long long* state) {
     if (scan4)
       hipLaunchKernelGGL(wnms_scan4_kernel, dim3(1, 1, B), dim3(256), scan4_lds, st, w.thr, w.snap, Kcap, d_count, w.nwcap, ord,
@@ -818,7 +827,6 @@ int rd_wnms_4c_batched(const float* dets, long dets_bstride, int Kcap, const int
     pairs((const int*)w.alive, (const int*)w.nalive, (const unsigned long long*)w.supp_state, 0);
     scan(nb1, nb, w.supp_state);
   }
-  allow_big_lds(wnms_merge_kernel);
   // neighbourhood list of a kept row: 2 048 entries (16 KB) in LDS -- the lists are a few dozen entries long; a frame with more
   // candidates than that counts each row's list first and sends the rare longer one through the global-scratch kernel.  (With the
   // former 16 384 entries every single-wave workgroup asked for 65 KB: in the pipeline, where the conv workgroups hold 2 x 80 KB

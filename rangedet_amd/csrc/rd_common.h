@@ -57,10 +57,16 @@ struct DevSwitches {
   int wnms_ct;             // RD_WNMS_CT (8 default, 16, 32): columns per pair tile
   bool wnms_no_skip;       // RD_WNMS_NO_SKIP: clip every pair the reference clips (no rejection test, k_wnms.h w_pair_skippable)
 };
+// RELEASE BUILD (the default since round 6): the switches are compile-time constants -- the library reads no environment variable, so
+// what a process launches never depends on who started it (VERDICT r5 / ADVICE r4: a packed weight image and the launch that reads it
+// chose their tap order from RD_CONV_BODY independently).  -DRD_DEV_SWITCHES (RD_EXTRA_HIPCC_FLAGS of rangedet_amd.build, the emulator
+// build of the test tier) brings the environment back for A/B runs of one change on one box.
+constexpr DevSwitches kDevSwitchDefaults = {false, 1, 2, 1, 1, 1, 1, 1, false, false, 0, false, 8, false};
+#ifdef RD_DEV_SWITCHES
 inline const DevSwitches& dev_switches() {
   static const DevSwitches s = [] {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    DevSwitches d;
+    DevSwitches d = kDevSwitchDefaults;
     d.conv_v1 = getenv("RD_CONV_V1") != nullptr;
     d.conv_th4 = num("RD_CONV_TH4", 1);
     d.conv_w30 = num("RD_CONV_W30", 2);
@@ -79,6 +85,9 @@ inline const DevSwitches& dev_switches() {
   }();
   return s;
 }
+#else
+inline constexpr const DevSwitches& dev_switches() { return kDevSwitchDefaults; }
+#endif
 
 // A kernel that takes more than 64 KB of dynamic LDS must say so once.  (A kernel with static LDS cannot take the full 160 KB as
 // dynamic: the attribute call then fails while the launch with the size actually requested still works -- do not leave that

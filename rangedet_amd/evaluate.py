@@ -99,18 +99,34 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
     pipe0 = multi.pipes[0]
     to_inputs = DeviceInputTransform(pad_hw=(H, Wp), lib=pipe0.lib, alloc=pipe0.alloc)
     cls = mapping[variant if variant in mapping else 'veh']
-    big = {}                                                   # capacity -> single-frame pipeline for overflowing frames
+    big = {}                                                   # (capacity, batch) -> pipeline sized for the worst case, for overflowing batches
 
-    def rerun(inputs):
+    def rerun(j, inputs):
         """The WHOLE batch again through a pipeline whose weighted NMS is sized for the worst case (every pre-NMS candidate above
         min_score): one forward + one batched NMS instead of `batch` single-frame runs.  Built on first use and kept; its workspace
-        is 3 K^2 / 8 bytes per frame (0.94 GB at K = 50 000, so 7.5 GB for a batch of 8 -- small
-        against 288 GB)."""
+        is 3 K^2 / 8 bytes per frame (0.94 GB at K = 50 000, so 7.5 GB for a batch of 8 -- small against
+        288 GB, but it is allocated in the middle of a run with `inflight` pipelines resident: when that allocation fails (a smaller or
+        shared GPU) the batch is re-run frame by frame through a single-frame pipeline instead (0.94 GB).  Enqueued on pipeline j's
+        launch stream, i.e. ordered behind the batch whose overflow it repairs."""
         K = min(max(topn.values()), rdlib.RD_WNMS_MAX_K)
-        if K not in big:
-            big[K] = RangeDetPipeline(params, wnms_cap=K, **kw)
-        big[K].enqueue(inputs)
-        return big[K].collect()
+        with multi.stream_context(j):
+            if (K, batch) not in big and (K, 0) not in big:
+                try:
+                    big[(K, batch)] = RangeDetPipeline(params, wnms_cap=K, **kw)
+                except (MemoryError, RuntimeError) as e:       # torch.cuda.OutOfMemoryError is a RuntimeError
+                    if "out of memory" not in str(e).lower() and not isinstance(e, MemoryError):
+                        raise
+                    big[(K, 0)] = None                         # remember: the whole-batch form does not fit here
+            if (K, batch) in big:
+                big[(K, batch)].enqueue(inputs)
+                return big[(K, batch)].collect()
+            if (K, 1) not in big:
+                big[(K, 1)] = RangeDetPipeline(params, wnms_cap=K, **dict(kw, batch=1))
+            frames = []
+            for b in range(batch):
+                big[(K, 1)].enqueue({k_: v_[b:b + 1] for k_, v_ in inputs.items()})
+                frames += big[(K, 1)].collect()
+            return frames
 
     def finish(j, chunk, recs, inputs):
         # one wait (for this pipeline's own post-processing event) and one host copy per batch
@@ -119,7 +135,7 @@ def run(roidb, params, batch=8, variant='veh', wnms=True, progress=None, pre_nms
         except rdlib.RangeDetError as e:
             if e.code != rdlib.RD_EWORKSPACE or not wnms:
                 raise
-            frames = rerun(inputs)                             # a frame above the WNMS capacity: this batch again, sized for the worst case
+            frames = rerun(j, inputs)                          # a frame above the WNMS capacity: this batch again, sized for the worst case
         for b, i in enumerate(chunk):
             rec, fr = roidb[i], frames[b]
             rid = rec.get('rec_id', i)

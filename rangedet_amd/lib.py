@@ -15,6 +15,17 @@ RD_F32, RD_BF16, RD_F16 = 0, 1, 2
 H16 = (RD_BF16, RD_F16)     # the two 16-bit element types (same layouts)
 RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED = 1, 2, 4, 8
 RD_WNMS_MAX_K = 65536
+# diagnostic bits of rd_wnms_4c's tie_order (include/rangedet_hip.h): per-call test aids, the result never depends on them
+RD_WNMS_DIAG_NO_SKIP = 0x100
+
+
+def RD_WNMS_DIAG_TILE_W(n):
+    return (n & 0xff) << 16
+
+
+def RD_WNMS_DIAG_MERGE_LDS(n):
+    return (n & 0x7f) << 24
+
 RD_TIE_STABLE, RD_TIE_REFERENCE = 0, 1
 PROF_KINDS = {"conv": 0, "meta": 1, "head_out": 2, "sort": 3, "decode": 4, "wnms": 5, "layout": 6, "conv3": 7, "block": 8}
 

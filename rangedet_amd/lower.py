@@ -21,6 +21,7 @@ Anything that does not match raises NotImplementedError at lowering time -- ther
 import os
 from dataclasses import dataclass, field
 
+from . import devswitch
 from .lib import H16, RD_ADD, RD_BF16, RD_F16, RD_F32, RD_RELU_POST, RD_RELU_PRE
 
 
@@ -113,9 +114,9 @@ class Lowering:
         # one stream a pair is 10 % faster than its two launches at W = 664, equal at W = 1328, 2 - 7 % slower at W = 2656 (real
         # activations); end to end +0.65 % with one batch in flight, -0.4 .. -0.7 % with the default two (the other stream's launches
         # already fill the tail rounds, and finer launches interleave better).
-        if not self.h16 or os.environ.get("RD_PAIR", "0") in ("", "0"):
+        if not self.h16 or devswitch.get("RD_PAIR", "0") in ("", "0"):
             return
-        max_w = int(os.environ.get("RD_PAIR_MAXW", "100000"))
+        max_w = int(devswitch.get("RD_PAIR_MAXW", "100000"))
 
         def sig(st):
             if st["kind"] != "conv" or not st.get("ex") or not st.get("fold") or st.get("sc") or st.get("s2view") or st.get("x2") is not None:
@@ -179,14 +180,28 @@ class Lowering:
         LDS as conv2's halo image.  Both shortcut forms: identity (residual = the block input) and the fused 1x1 projection of the
         block input.  Plan step kind "block": a / b = the two conv steps as they were (bit-identical results).
         RD_NO_FUSE_BLOCK=1 keeps the two launches (A/B runs)."""
-        if not self.h16 or os.environ.get("RD_NO_FUSE_BLOCK"):
+        if not self.h16 or devswitch.get("RD_NO_FUSE_BLOCK"):
             return
         steps = self.plan.steps
         uses = {}
+
+        def scan(i, key, v):        # every TRef a step holds, also inside nested dicts / lists (fused head_out steps, 'sc' dicts: ADVICE r5)
+            if isinstance(v, (TRef, FlatRef)):
+                uses.setdefault(v.buf, []).append((i, key))
+                if isinstance(v, TRef) and v.tail is not None:
+                    scan(i, key + ".tail", v.tail)
+            elif isinstance(v, dict):
+                for k2, v2 in v.items():
+                    scan(i, key + "." + str(k2), v2)
+            elif isinstance(v, (list, tuple)):
+                for k2, v2 in enumerate(v):
+                    scan(i, key + "." + str(k2), v2)
         for i, st in enumerate(steps):
             for key, v in st.items():
-                if isinstance(v, TRef):
-                    uses.setdefault(v.buf, []).append((i, key))
+                scan(i, key, v)
+        # a tensor the graph RETURNS has a reader outside the step list: its buffer must survive
+        for o in (self.plan.outputs if isinstance(self.plan.outputs, (list, tuple)) else []):
+            scan(-1, "output", o)
 
         def plain64(st, first=False):
             """a folded 3x3 stride-1 conv to 64 channels from 64 channels -- or, as conv1 of the network's first block, from one
@@ -195,7 +210,7 @@ class Lowering:
                     st.get("fold") and not st.get("head") and st.get("x2") is None and st["x"].tail is None):
                 return False
             if first and st["x"].cs - st["x"].co == 16 and st["x"].C <= 16:
-                return not os.environ.get("RD_NO_FUSE_FIRST")      # (A/B switch: keep the first block as two launches)
+                return not devswitch.get("RD_NO_FUSE_FIRST")      # (A/B switch: keep the first block as two launches)
             return st["cin"] == 64 and st["x"].C == 64 and not st.get("cmap")
 
         out, i = [], 0
@@ -226,7 +241,7 @@ class Lowering:
         """bf16: the last conv of a head tower whose ONLY consumer is one 1x1 output conv (rpn_cls_logit / rpn_reg_delta of a
         single-class head) runs as rd_conv2d_bn_act_head_out: the output conv is applied in the 3x3 kernel's epilogue and the
         128-channel tower output is never written to HBM nor read back.  (Two classes read the tensor twice: left alone.)"""
-        if not self.h16 or os.environ.get("RD_NO_FUSE_HEAD"):
+        if not self.h16 or devswitch.get("RD_NO_FUSE_HEAD"):
             return
         steps = self.plan.steps
         uses = {}
@@ -369,8 +384,8 @@ class Lowering:
         out = self._out(cout, x.H, Wout, dest) if cout == cout_l else self.new_act(cout_l, x.H, Wout, cs=cout)
         # extended 3x3 entry (bf16): stride (1,2) on the pixel-pair view (even width), and / or the fused projection shortcut
         # and, unless RD_NO_FOLD is set, every bf16 3x3 conv with the BatchNorm scale folded into its weights (RD_SCALE_FOLDED)
-        fold = self.h16 and k == (3, 3) and not os.environ.get("RD_NO_FOLD")
-        s2view = sw == 2 and x.W % 2 == 0 and not os.environ.get("RD_NO_S2_VIEW")
+        fold = self.h16 and k == (3, 3) and not devswitch.get("RD_NO_FOLD")
+        s2view = sw == 2 and x.W % 2 == 0 and not devswitch.get("RD_NO_S2_VIEW")
         ex = self.h16 and k == (3, 3) and (sc is not None or s2view or (fold and sw == 1))
         kw_fold = dict(fold=bool(ex and (fold or sc is not None)), s2view=bool(ex and s2view))
         kw = {}
@@ -388,7 +403,7 @@ class Lowering:
     def _fusable_projection(self, main_conv, sc):
         """sc = BN(Convolution 1x1, no bias) with the main 3x3 conv's stride, at most 128 input channels, and (stride 2) an even
         input width: the shortcut the persistent 3x3 kernel can accumulate in its epilogue (bf16 only)."""
-        if not self.h16 or os.environ.get("RD_NO_FUSE_SC"):
+        if not self.h16 or devswitch.get("RD_NO_FUSE_SC"):
             return None
         if not (sc.op == "BatchNorm" and sc.inputs[0].op == "Convolution"):
             return None
@@ -438,10 +453,10 @@ class Lowering:
                 out = self._out(cout, x.H, Wout, dest) if cout == cout_l else self.new_act(cout_l, x.H, Wout, cs=cout)
                 if (res.C, res.H, res.W) != (cout_l, x.H, Wout) or (cout != cout_l and (res.cs != cout or res.co != 0)):
                     raise ValueError("agg add shape mismatch at %s" % add.name)
-                fold = self.h16 and cout in (64, 128) and not os.environ.get("RD_NO_FOLD")
+                fold = self.h16 and cout in (64, 128) and not devswitch.get("RD_NO_FOLD")
                 # every phase a 3 x 2 tap set (kw = 2 sw, pad = sw / 2: k(3,8) s4 p2, k(3,4) s2 p1): all phases in ONE launch
                 # (rd_deconv2d_bn_act_all; the executor checks this against rd_deconv2d_all_phases_ok)
-                one = bool(fold and kw == 2 * sw and 2 * pw == sw and not os.environ.get("RD_DECONV_PER_PHASE"))
+                one = bool(fold and kw == 2 * sw and 2 * pw == sw and not devswitch.get("RD_DECONV_PER_PHASE"))
                 self.step("deconv", name=dc.name, bn=bn.name, eps=bn.attrs["eps"], x=x, out=out, res=res, cin=x.C,
                           cout=cout, cout_logical=cout_l, k=(kh, kw), stride_w=sw, pad_w=pw, flags=RD_RELU_PRE | RD_ADD, fold=fold, one_launch=one)
                 return out
@@ -475,7 +490,7 @@ class Lowering:
         # columns permuted accordingly (cmap).  RD_CONCAT_BUFFER=1: the shared buffer, for A/B runs.
         acts = [i for i, p in enumerate(parts) if p.op != "var"]
         if self.h16 and len(parts) == 2 and len(acts) == 1 and cs_list[acts[0]] % 32 == 0 and cs_list[1 - acts[0]] <= self.gran and \
-                not os.environ.get("RD_CONCAT_BUFFER") and not os.environ.get("RD_NO_FOLD") and os.environ.get("RD_PAIR", "0") in ("", "0"):
+                not devswitch.get("RD_CONCAT_BUFFER") and not devswitch.get("RD_NO_FOLD") and devswitch.get("RD_PAIR", "0") in ("", "0"):
             # (RD_PAIR=1, the opt-in two-problem tower launches, keeps the shared buffer: that launch form takes one input tensor)
             ia, iv = acts[0], 1 - acts[0]
             fa = self.emit_act(parts[ia])

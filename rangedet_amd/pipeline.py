@@ -5,7 +5,7 @@ score filter, 10->11 dim, weighted NMS and 12->8 dim on the device.
 import os
 import numpy as np
 
-from . import lib as rdlib
+from . import devswitch, lib as rdlib
 from .config import rangedet_veh_wo_aug_4_18e as cfgmod
 from .lower import lower
 from .runtime import Executor, TorchAllocator
@@ -22,7 +22,7 @@ def input_shapes(H, W, strides=(1, 2, 4), channels=8):
 
 def _stream_prio(var):
     """Development switch: queue priority of the launch / post-processing streams, 0 = normal (default), -1 = high."""
-    return int(os.environ.get(var, "0"))
+    return int(devswitch.get(var, "0"))
 
 
 class BatchPostProcessor:
@@ -30,9 +30,10 @@ class BatchPostProcessor:
     single latency-bound wavefront per frame, so B of them run side by side instead of back to back.  Per-frame buffers
     are slices of contiguous allocations; frame b's results are read back with collect(b)."""
 
-    def __init__(self, B, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096, hash_scale=100, tie_order="reference"):
+    def __init__(self, B, k, min_score, thr_lo, thr_hi, is_3d_iou, lib, alloc, cap=4096, hash_scale=100, tie_order="reference", wnms_diag=0):
         self.B, self.k, self.cap = B, k, min(cap, k, rdlib.RD_WNMS_MAX_K)
         self.hash_scale, self.tie_order = int(hash_scale), tie_order
+        self.wnms_diag = int(wnms_diag)     # rdlib.RD_WNMS_DIAG_* bits (test aids: same results through other code paths)
         self.min_score, self.thr_lo, self.thr_hi, self.is3d = min_score, thr_lo, thr_hi, int(is_3d_iou)
         self.L, self.A = lib, alloc
         A, L = alloc, lib
@@ -63,7 +64,7 @@ class BatchPostProcessor:
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
         order = A.ptr(self.identity) if self.tie_order == "stable" else None
         L.call("rd_wnms_4c_batched", A.ptr(self.dets), self.k * 12, self.cap, A.ptr(self.count), order, 0,
-               rdlib.RD_TIE_REFERENCE, self.thr_lo, self.thr_hi, self.is3d, self.hash_scale, A.ptr(self.out), self.cap * 12,
+               rdlib.RD_TIE_REFERENCE | self.wnms_diag, self.thr_lo, self.thr_hi, self.is3d, self.hash_scale, A.ptr(self.out), self.cap * 12,
                A.ptr(self.keep), self.cap, A.ptr(self.nkeep), A.ptr(self.ws_w), self.ws_w_bytes, self.B, st)
         L.call("rd_dets12_to_8_batched", A.ptr(self.out), self.cap * 12, self.cap, A.ptr(self.nkeep), A.ptr(self.out8),
                self.cap * 8, self.B, st)
@@ -162,7 +163,7 @@ class _FrameView:
 class RangeDetPipeline:
     def __init__(self, params, dtype=rdlib.RD_BF16, feat_size=(64, 2650), pad_field=(64, 2656), batch=1,
                  pre_nms_top_n=50000, wnms_cap=4096, variant="veh", lib=None, alloc=None, wnms=True, tie_order="reference",
-                 hash_scale=100):
+                 hash_scale=100, wnms_diag=0, graph=False):
         """wnms=False builds the graph with contrib.NMS3D inside (RpnParam.wnms = False, builder.py:530-534) and runs the
         matching harness branch (tools/test.py:193-196) instead of the weighted NMS.
         tie_order: "reference" = rows with equal scores are processed in the order the reference's std::sort leaves them
@@ -186,6 +187,15 @@ class RangeDetPipeline:
         self.exe = Executor(self.plan, params, self.lib, self.alloc)
         self.ks = {c: RpnParam.all_proposal.rpn_pre_nms_top_n[c] for c in self.class_names}
         self.batch = batch
+        # graph=True: the forward + batched post-processing of a batch (~80 launches enqueued one ctypes call at a time) are captured
+        # ONCE per set of input buffers into a hipGraph (stream capture through torch.cuda.CUDAGraph) and replayed with one call:
+        # the host's enqueue cost per batch drops from ~1 ms to the replay call.  Inputs must be resident float32 device tensors (their
+        # addresses are part of the graph); anything else, and input sets beyond `max_graphs`, run through the eager path.
+        self.use_graph = bool(graph) and hasattr(self.alloc, "torch")
+        self._graphs = {}
+        self._capture_stream = None
+        self.max_graphs = 8
+        self.graph_replays = 0
         self._post_stream = None
         self.post_on_launch_stream = False       # one pipeline alone: score filter + NMS on a side stream (overlaps the next batch's forward)
         self._filter_done = None
@@ -196,7 +206,7 @@ class RangeDetPipeline:
             if self.wnms:
                 self.bposts[c] = BatchPostProcessor(batch, self.ks[c], TestParam.min_score[c], TestParam.nms.thr_lo,
                                                     TestParam.nms.thr_hi, TestParam.nms.is_3d_iou, self.lib, self.alloc, wnms_cap,
-                                                    hash_scale=hash_scale, tie_order=tie_order)
+                                                    hash_scale=hash_scale, tie_order=tie_order, wnms_diag=wnms_diag)
             else:
                 self.bposts[c] = Nms3dPostProcessor(batch, self.ks[c], RpnParam.all_proposal.rpn_post_nms_top_n[c],
                                                     TestParam.min_score[c], self.lib, self.alloc)
@@ -211,10 +221,73 @@ class RangeDetPipeline:
 
     def enqueue(self, inputs):
         """forward on the current stream; score filter + WNMS + 12->8 on a side stream so that the (latency-bound,
-        one-CU) greedy scan of frame i overlaps the convolutions of frame i+1."""
+        one-CU) greedy scan of frame i overlaps the convolutions of frame i+1.  (graph=True: one hipGraph replay, see _enqueue_graph.)"""
+        if self.use_graph:
+            outs = self._enqueue_graph(inputs)
+            if outs is not None:
+                return outs
+        return self._enqueue_eager(inputs)
+
+    def _record(self, inputs):
+        """The batch's whole launch sequence on the CURRENT stream, no events: forward, then per class score filter + NMS + 12 -> 8."""
+        outs = self.exe.forward(inputs)
+        ptr = lambda t: self.alloc.ptr(t) if hasattr(t, "data_ptr") else t.ctypes.data
+        if not self.wnms:
+            self.bpost.enqueue(ptr(outs[1]), self.k, ptr(outs[2]), ptr(outs[3]), outs[3], stream=None)
+            return outs
+        for ci, c in enumerate(self.class_names):
+            sc, bx = outs[1 + 3 * ci], outs[2 + 3 * ci]
+            sc_bs = (ptr(sc[1]) - ptr(sc[0])) // 4 if self.batch > 1 else 0
+            bx_bs = (ptr(bx[1]) - ptr(bx[0])) // 4 if self.batch > 1 else 0
+            self.bposts[c].enqueue_filter(ptr(sc[0]), sc_bs, ptr(bx[0]), bx_bs, stream=None)
+        for c in self.class_names:
+            self.bposts[c].enqueue_nms(stream=None)
+        return outs
+
+    def _enqueue_graph(self, inputs):
+        """One hipGraph replay on the current stream (the pipeline's launch stream).  The first batch that arrives with a new set of input
+        buffers runs eagerly (which also sets every kernel's per-device attributes and checks the shapes) and is then CAPTURED -- the
+        capture records launches, it does not execute them -- for every later batch in the same buffers.  Returns None when the inputs
+        cannot be graphed (host arrays, non-contiguous / non-float32 tensors, too many distinct input sets): the caller runs eagerly."""
+        A = self.alloc
+        t = A.torch
+        key = []
+        for name in sorted(inputs):
+            v = inputs[name]
+            if v is None:
+                continue
+            if not (hasattr(v, "data_ptr") and v.is_cuda and v.is_contiguous() and v.dtype == t.float32):
+                return None
+            key.append((name, v.data_ptr(), tuple(v.shape)))
+        key = tuple(key)
+        cur = t.cuda.current_stream(A.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= self.max_graphs:
+                return None
+            outs = self._enqueue_eager(inputs, side_ok=False)      # this batch: eagerly, everything on the current stream
+            g = t.cuda.CUDAGraph()
+            if self._capture_stream is None:
+                self._capture_stream = t.cuda.Stream(device=A.device)
+            cap = self._capture_stream
+            cap.wait_stream(cur)
+            with t.cuda.graph(g, stream=cap):
+                gouts = self._record(inputs)
+            cur.wait_stream(cap)
+            self._graphs[key] = (g, gouts, dict(inputs))             # (the input tensors stay alive as long as the graph that reads them)
+            return outs
+        g, outs, _ = ent
+        g.replay()
+        self.graph_replays += 1
+        self._post_stream = cur
+        self._filter_done = None
+        self._post_done = A.record_event(cur)
+        return outs
+
+    def _enqueue_eager(self, inputs, side_ok=True):
         A = self.alloc
         side = hasattr(A, "new_stream")
-        if side and self.post_on_launch_stream:
+        if side and (self.post_on_launch_stream or not side_ok):
             # (set by InterleavedPipelines with two or more batches in flight) post-processing on the batch's own launch stream: the
             # next batch on this stream starts behind this batch's NMS while the OTHER pipeline's forward has the GPU -- the overlap the
             # side stream exists for is already there, and two streams fewer compete for workgroup slots: 942.3 vs 939.1 frames/s over
@@ -277,7 +350,7 @@ class InterleavedPipelines:
     def __init__(self, params, n=2, **kw):
         self.pipes = [RangeDetPipeline(params, **kw) for _ in range(n)]
         for p in self.pipes:      # (RD_POST_SIDE_STREAM=1: a side stream per pipeline as in rounds 1 - 4, for A/B runs)
-            p.post_on_launch_stream = n >= 2 and not os.environ.get("RD_POST_SIDE_STREAM")
+            p.post_on_launch_stream = n >= 2 and not devswitch.get("RD_POST_SIDE_STREAM")
         A = self.pipes[0].alloc
         self.streams = [A.new_stream(priority=_stream_prio("RD_LAUNCH_STREAM_PRIO")) for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
         self._i = 0

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from . import lib as rdlib
+from . import devswitch, lib as rdlib
 from .lower import FlatRef, TRef
 
 
@@ -241,7 +241,7 @@ class Executor:
             # phases 2p | 2p+1 as one 128-channel problem where the layer has that form and its tensors are dense (agg1: 128 -> 64, stride 4;
             # RD_DECONV_NO_PAIRS=1: the all-phases launch, for A/B runs)
             r_, o_ = st["res"], st["out"]
-            b["pairs"] = b["all_phases"] and not os.environ.get("RD_DECONV_NO_PAIRS") and o_.cs == st["cout"] and o_.co == 0 and \
+            b["pairs"] = b["all_phases"] and not devswitch.get("RD_DECONV_NO_PAIRS") and o_.cs == st["cout"] and o_.co == 0 and \
                 (r_ is None or (r_.cs == st["cout"] and r_.co == 0)) and \
                 L.raw("rd_deconv2d_phase_pairs_ok")(st["k"][0], st["k"][1], st["stride_w"], st["pad_w"], st["cout"], dt) == 1
             if b["pairs"]:

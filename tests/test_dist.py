@@ -265,8 +265,8 @@ def test_bench_rccl_gather_world1():
     assert gc["results_sha256_last_step"] == pc["results_sha256_last_step"]    # ... and the results are those of the run without it
     assert gc["wnms_kept"] == pc["wnms_kept"] and gc["wnms_candidates"] == pc["wnms_candidates"]
     # the weighted NMS's rejection test (k_wnms.h w_pair_skippable) on the production frames -- the whole run again with every
-    # pair clipped (RD_WNMS_NO_SKIP=1 is read once per process, hence a process): the same kept rows and indices, bit for bit
-    ns = subprocess.run(cmd, env=dict(env, RD_WNMS_NO_SKIP="1"), capture_output=True, text=True, timeout=900)
+    # pair clipped (bench.py --wnms-no-skip = the call's RD_WNMS_DIAG_NO_SKIP bit): the same kept rows and indices, bit for bit
+    ns = subprocess.run(cmd + ["--wnms-no-skip"], env=env, capture_output=True, text=True, timeout=900)
     assert ns.returncode == 0, ns.stderr[-2000:]
     nc = _json_line(ns.stdout)["config"]
     assert nc["results_sha256_last_step"] == pc["results_sha256_last_step"] and nc["wnms_kept"] == pc["wnms_kept"]
@@ -314,7 +314,7 @@ def test_bench_results_independent_of_block_fusion():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "3", "--repeats", "3", "--backbone-reps", "0",
            "--no-cpu-baseline"]
     outs = []
-    for extra in ({}, {"RD_NO_FUSE_BLOCK": "1"}):
+    for extra in ({}, {"RD_NO_FUSE_BLOCK": "1", "RD_DEV_SWITCHES": "1"}):
         r = subprocess.run(cmd, env=dict(env, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(_json_line(r.stdout))
@@ -327,6 +327,15 @@ def test_bench_results_independent_of_block_fusion():
     assert r.returncode == 0, r.stderr[-2000:]
     c = _json_line(r.stdout)
     assert c["config"]["results_sha256_all_steps"] == a["config"]["results_sha256_all_steps"]
+    # ... and of the same steps replayed from hipGraphs (round 6, pipeline.RangeDetPipeline(graph=True): one graph per pipeline and input
+    # set, ~80 launches per replay call), with three and with two batches in flight
+    for extra_args in (["--graph"], ["--graph", "--inflight", "2"]):
+        r = subprocess.run(cmd + extra_args, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        g = _json_line(r.stdout)
+        hg = g["config"]["hip_graph"]
+        assert hg["graphs"] >= 2 and hg["replays"] >= 100, hg
+        assert g["config"]["results_sha256_all_steps"] == a["config"]["results_sha256_all_steps"]
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
 
 

@@ -46,6 +46,7 @@ def test_config_and_full_graph_lowering(monkeypatch):
     assert [bool(s["b"].get("sc")) for s in plan.steps if s["kind"] == "block"] == [True, False, False, True, True, False, True, False]
     inter = {s["a"]["out"].buf for s in plan.steps if s["kind"] == "block"}
     assert not inter & set(plan.buffers), "the intermediate tensor of a fused block has no buffer"
+    monkeypatch.setenv("RD_DEV_SWITCHES", "1")      # (lowering A/B switches are honoured only with this set, rangedet_amd/devswitch.py)
     monkeypatch.setenv("RD_NO_FUSE_BLOCK", "1")
     assert Counter(s["kind"] for s in lower(sym, small_shapes(64, 2656), R.RD_BF16, 1).steps)["conv"] == 73
     monkeypatch.delenv("RD_NO_FUSE_BLOCK")
@@ -53,6 +54,7 @@ def test_config_and_full_graph_lowering(monkeypatch):
     assert len(convs) == 73
     # RD_PAIR=1 (opt-in): the cls and the reg tower conv i of a level are ONE launch (lower._pair_equal_convs): 24 tower convs = 12
     # pairs, each pair at the place of its cls conv, nothing else moves
+    monkeypatch.setenv("RD_DEV_SWITCHES", "1")
     monkeypatch.setenv("RD_PAIR", "1")
     pplan = lower(sym, small_shapes(64, 2656), R.RD_BF16, 1)
     monkeypatch.delenv("RD_PAIR")
@@ -776,6 +778,7 @@ def test_e2e_bf16_tolerance(be, dt, monkeypatch):
     # (batch 2: with one frame the reduced graph's low levels have fewer tiles than workgroups)
     if emu and dt != R.RD_BF16:
         return                                                  # (CPU tier: once, in bf16)
+    monkeypatch.setenv("RD_DEV_SWITCHES", "1")
     monkeypatch.setenv("RD_PAIR", "1")
     pplan = lower(sym, small_shapes(H, W), dt, 2)
     monkeypatch.delenv("RD_PAIR")

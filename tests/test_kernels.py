@@ -764,6 +764,8 @@ def test_block64_equals_the_two_launches(be, case):
     assert f(p, 64, 0, 64, q, q, q, None, p, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                # in place
     assert f(p, 32, 0, 32, q, q, q, None, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                # 32 input channels: not a form
     assert f(p, 16, 0, 8, q, q, q, None, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_EINVAL                 # first block without its projection shortcut
+    assert f(p, 8, 0, 8, q, q, q, q, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                     # 8-channel pitch: the shortcut reads 16 channels per pixel
+    assert f(p, 24, 16, 8, q, q, q, q, q, 64, 0, 1, 4, 8, dt, be.stream) == R.RD_ESHAPE                   # ... also behind an offset
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -850,7 +852,15 @@ def test_edge_atan2f_equals_the_c_library(be):
     want = np.array([libm.atan2f(float(y[i]), float(x[i])) for i in idx], np.float32)
     g = got[idx]
     same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
-    assert same.all(), (int((~same).sum()), y[idx][~same][:4], x[idx][~same][:4], g[~same][:4], want[~same][:4])
+    # which C library this was compared with: the device restates the fdlibm routine glibc 2.35 ships; a newer glibc with a
+    # correctly rounded atan2f would make THIS HOST's libm (and a reference compiled here) differ from it in the last bit
+    gv = ctypes.CDLL("libc.so.6").gnu_get_libc_version
+    gv.restype = ctypes.c_char_p
+    glibc = gv().decode()
+    if not same.all() and glibc != "2.35":
+        pytest.xfail("this host's libm is glibc %s, whose atan2f differs from the fdlibm routine of glibc 2.35 the library restates "
+                     "(rd_common.h fdlibm_atan2f, INTEGRATION.md): %d of %d sampled inputs differ in the last bit" % (glibc, int((~same).sum()), len(idx)))
+    assert same.all(), ("glibc " + glibc, int((~same).sum()), y[idx][~same][:4], x[idx][~same][:4], g[~same][:4], want[~same][:4])
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
@@ -966,16 +976,16 @@ def test_tie_order_replays_std_sort(be):
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)
-def test_wnms_chunked_scan_and_merge_overflow(be, monkeypatch):
+def test_wnms_chunked_scan_and_merge_overflow(be):
     """K beyond 64*256 rows takes the column-chunked scan and neighbourhoods beyond the LDS list the global-scratch merge.
-    Both paths are forced at small K through the library's test switches and must give the same bits as the normal paths."""
+    Both paths are forced at small K through the call's diagnostic bits (RD_WNMS_DIAG_*) and must give the same bits as the normal paths."""
     d = synth.cluster_dets(40, 9, seed=31, quant=33)
     base = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, cap_extra=1024)
     flat, rk = O.wnms_4c(d, 0.1, 0.5, False, 100)
     assert base[1].tolist() == rk
-    monkeypatch.setenv("RD_WNMS_TILE_W", "2")
-    monkeypatch.setenv("RD_WNMS_MERGE_LDS", "6")
-    alt = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE, cap_extra=1024)
+    alt = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE | R.RD_WNMS_DIAG_TILE_W(2) | R.RD_WNMS_DIAG_MERGE_LDS(6), cap_extra=1024)
+    assert alt[1].tolist() == rk and np.array_equal(alt[0].view(np.uint32), base[0].view(np.uint32))
+    alt = _wnms(be, d, 0.1, 0.5, 0, None, tie=R.RD_TIE_REFERENCE | R.RD_WNMS_DIAG_NO_SKIP, cap_extra=1024)   # every pair clipped
     assert alt[1].tolist() == rk and np.array_equal(alt[0].view(np.uint32), base[0].view(np.uint32))
     assert np.array_equal(base[0].view(np.uint32), np.array(flat, np.float32).reshape(-1, 12).view(np.uint32))
 

@@ -15,8 +15,12 @@
 #   ab.sh r4c "RD_CONCAT_BUFFER=1" ""     2 both cat_two       the concat never materialised
 #   ab.sh r4d "RD_WNMS_NO_SKIP=1" ""      2 bench wnms         the weighted NMS's rejection test
 #   ab.sh r4g "RD_CONV_BODY=0" ""         2 both conv3x3_ex    heterogeneous tile bodies
+# Round 6: the release library and the release lowering take no switches.  This runner sets RD_DEV_SWITCHES=1 (Python-side switches:
+# rangedet_amd/devswitch.py) and, when tools has built it (`python -m rangedet_amd.build --dev` before the gpurun call), loads the
+# -DRD_DEV_SWITCHES library so that the native RD_CONV_* / RD_WNMS_* variables work too.
 cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
+export TMPDIR=/tmp RD_DEV_SWITCHES=1
+[ -z "$RANGEDET_HIP_LIB" ] && [ -f rangedet_amd/librangedet_hip_dev.so ] && export RANGEDET_HIP_LIB="$PWD/rangedet_amd/librangedet_hip_dev.so"
 O=gpurun_out/${1:?out dir}; A="$2"; B="$3"; REPS=${4:-2}; MODE=${5:-bench}; K="$6"
 mkdir -p "$O"
 P='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "frames/s  meta+dla frac", round(d["meta_dla_forward"]["frac_hbm_peak"],4), " conv3 frac", round(d["roofline"]["frac"],4), " wnms ms/frame", round(d["kernel_ms_per_frame"]["wnms"],4))'
