@@ -117,6 +117,7 @@ class Lowering:
         if not self.h16 or devswitch.get("RD_PAIR", "0") in ("", "0"):
             return
         max_w = int(devswitch.get("RD_PAIR_MAXW", "100000"))
+        same_input_only = devswitch.get("RD_PAIR", "0") == "2"    # (round 6 experiment: only the tower convs that read the SAME tensor -- conv_0 of a level)
 
         def sig(st):
             if st["kind"] != "conv" or not st.get("ex") or not st.get("fold") or st.get("sc") or st.get("s2view") or st.get("x2") is not None:
@@ -139,7 +140,7 @@ class Lowering:
                 # the tensor it reads was written before place j, and nothing from place j on touches what it writes
                 ready = written.get(st["x"].buf, -1)
                 clear = max((touched.get(v.buf, -1) for v in (st["out"], st.get("head_out")) if v is not None), default=-1)
-                j = next((j for j in open_.get(k, []) if ready < j and clear < j), None)
+                j = next((j for j in open_.get(k, []) if ready < j and clear < j and (not same_input_only or out[j]["x"] == st["x"])), None)
                 if j is not None:
                     open_[k].remove(j)
                     a = out[j]

@@ -41,6 +41,29 @@ def test_product_library_loads_and_exports_every_symbol():
     assert L.raw("rd_meta_packed_bytes")(R.RD_BF16) == 36864 + 73728 + 2 * 2304 + 512 + 512 + 1024   # ... + the hidden layer as an MFMA fragment
 
 
+def test_release_library_reads_no_environment():
+    """Round 6: the shipped library's code paths do not depend on the environment of the process -- the development
+    switches are compile-time constants unless built with -DRD_DEV_SWITCHES (csrc/rd_common.h), and the Python-side lowering switches are
+    ignored unless RD_DEV_SWITCHES=1 (rangedet_amd/devswitch.py).  Checked on the binary: it does not even import getenv."""
+    import subprocess
+    from rangedet_amd import build, devswitch
+    path = build.build(verbose=False)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", syms), "the release library imports getenv"
+    # the Python side: a lowering switch without the master switch is not seen
+    old = {k: os.environ.pop(k, None) for k in ("RD_DEV_SWITCHES", "RD_NO_FUSE_BLOCK")}
+    try:
+        os.environ["RD_NO_FUSE_BLOCK"] = "1"
+        assert devswitch.get("RD_NO_FUSE_BLOCK") is None
+        os.environ["RD_DEV_SWITCHES"] = "1"
+        assert devswitch.get("RD_NO_FUSE_BLOCK") == "1"
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         R.Lib(str(tmp_path / "librangedet_hip.so"))

@@ -32,7 +32,7 @@ if [ "$MODE" = steps ] || [ "$MODE" = both ]; then
   env $B timeout -s KILL 200 python tools/profile_steps.py bf16 5 8 > "$O/steps_B.txt" 2>&1
   echo "A: [$A] $(tail -1 "$O/steps_A.txt")"; echo "B: [$B] $(tail -1 "$O/steps_B.txt")"
   # the steps whose time differs by more than 3 us
-  paste <(awk '$2 ~ /conv|deconv|meta|nchw|sorted|concat/ {print $3, $(NF-10)}' "$O/steps_A.txt" 2>/dev/null) <(awk '$2 ~ /conv|deconv|meta|nchw|sorted|concat/ {print $3, $(NF-10)}' "$O/steps_B.txt" 2>/dev/null) |
+  paste <(awk '$2 ~ /conv|deconv|meta|nchw|sorted|concat/ {print $3, $(NF-18)}' "$O/steps_A.txt" 2>/dev/null) <(awk '$2 ~ /conv|deconv|meta|nchw|sorted|concat/ {print $3, $(NF-18)}' "$O/steps_B.txt" 2>/dev/null) |
     awk '{d=$4-$2; if (d>3||d<-3) print}' | head -40
 fi
 if [ "$MODE" = bench ] || [ "$MODE" = both ]; then

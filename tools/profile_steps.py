@@ -18,6 +18,7 @@ fr = synth.make_batch(list(range(B)))
 pipe.enqueue(fr)
 torch.cuda.synchronize()
 ex = pipe.exe
+esz = 2 if dt in rdlib.H16 else 4
 tot = 0.0
 rows = []
 for i, st in enumerate(pipe.plan.steps):
@@ -34,23 +35,36 @@ for i, st in enumerate(pipe.plan.steps):
     tot += us
     k = st["kind"]
     fl = 0.0
-    desc = ""
+    by = 0.0          # bytes THIS launch form has to move (fused form: input once incl. a stride-2 conv's skipped columns, output once,
+    desc = ""         # residual / shortcut input once) -- against the HBM roof next to the FLOPs against the MFMA roof
     if k == "conv_pair":   # two tower convs of one shape in one launch
         a = st["a"]
         o = a["out"]
         fl = 2 * B * 2.0 * o.H * o.W * a["cin"] * a["cout"] * 9
+        by = 2 * B * esz * o.H * o.W * (a["cin"] + (0 if a.get("head") else a["cout"]))
         desc = "%s %d->%d x2 W%d" % (st["name"].replace("rpn_", "").replace("_conv", ""), a["cin"], a["cout"], o.W)
     elif k == "block":     # a fused 64-channel BasicBlock: the FLOPs of its two convs (+ the 1x1 shortcut)
         o = st["out"]
         c1 = st["a"]["cin"]
         fl = B * 2.0 * o.H * o.W * 64 * (9 * c1 + 9 * 64 + (c1 if st["b"].get("sc") else 0))
+        by = B * esz * o.H * o.W * (st["x"].cs - st["x"].co if c1 <= 16 else c1) + B * esz * o.H * o.W * 64
         desc = "%s %d->64->64 W%d%s" % (st["name"].replace("_conv1 + ", " + ").split(" + ")[0] + " block", c1, o.W, " +sc" if st["b"].get("sc") else "")
     elif k in ("conv", "deconv"):
         o = st["out"]
         fl = B * 2.0 * o.H * o.W * st["cin"] * st["cout"] * st["k"][0] * st["k"][1] / (st["stride_w"] if k == "deconv" else 1)
+        x = st["x"]
+        by = B * esz * (x.H * x.W * st["cin"] + (0 if st.get("head") else o.H * o.W * st["cout"]))
+        if st.get("res") is not None:
+            by += B * esz * o.H * o.W * st["cout"]
+        if st.get("sc"):       # the fused 1x1 projection shortcut reads the block input at the conv's stride: every 128-byte line of it is touched
+            sx = st["sc_x"]
+            by += B * esz * sx.H * sx.W * st["sc"]["cin"]
+        if st.get("x2") is not None:
+            by += B * esz * x.H * x.W * (st["x2"].cs - st["x2"].co)
         desc = "%s %d->%d k%s W%d->%d s%d" % (st["name"], st["cin"], st["cout"], st["k"], st["x"].W, o.W, st["stride_w"])
     elif k == "meta":
         fl = B * 19.29e9
+        by = B * 64 * 2656 * (128 * esz + 12)
         desc = "meta unit"
     else:
         desc = st.get("name", "")
@@ -74,5 +88,10 @@ for i, st in enumerate(pipe.plan.steps):
         tw, slots = (62, cus) if wide_head else (32 if os.environ.get("RD_CONV_WIDE", "1") != "0" else 30, 2 * cus)
         ntiles = -(-Wt // tw) * -(-st["out"].H // 8) * B
         tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, slots, ntiles / slots) + (" per phase" if k == "deconv" else "")
-    print("%3d %-9s %-52s %8.1f us %8.1f TFLOP/s%s" % (i, k, desc[:52], us, fl / us / 1e6 if fl else 0, tps), flush=True)
+    tf, tbs = (fl / us / 1e6 if fl else 0), (by / us / 1e6 if by else 0)
+    roof = ""
+    if fl or by:
+        fm, fh = tf / 2500.0, tbs / 8.0
+        roof = "  %5.2f TB/s  %4.1f %% of the %s roof" % (tbs, 100 * max(fm, fh), "MFMA" if fm >= fh else "HBM")
+    print("%3d %-9s %-52s %8.1f us %8.1f TFLOP/s%s%s" % (i, k, desc[:52], us, tf, roof, tps), flush=True)
 print("sum of steps: %.1f us" % tot)
