@@ -282,7 +282,7 @@ def main(argv=None):
                          "`value` / `ms_per_step` are the MEDIAN region, the spread is reported next to it (SURVEY.md 8d: median + p5/p95).  "
                          "0 (default): as many regions as it takes for --min-timed-s seconds of timed GPU work (at least 5, at most 200), decided "
                          "from the first region -- so that the run is long enough for an outside utilisation sampler to see it")
-    ap.add_argument("--min-timed-s", type=float, default=8.0, help="with --repeats 0: total duration of the timed regions to aim for")
+    ap.add_argument("--min-timed-s", type=float, default=15.0, help="with --repeats 0: total duration of the timed regions to aim for")
     args = ap.parse_args(argv)
     argv = list(sys.argv[1:] if argv is None else argv)
 
