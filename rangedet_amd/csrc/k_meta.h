@@ -355,7 +355,11 @@ __global__ __launch_bounds__(WAVES * 64) void meta_kernel(MetaArgs a) {
 constexpr int META_FORM = 219;
 template <int WAVES, int DT = RD_BF16, int V = META_FORM>
 __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
-  static_assert((V & ~0xFF) == 0, "meta16_kernel: unknown form flag");
+  static_assert((V & ~0x1FF) == 0, "meta16_kernel: unknown form flag");
+  // 256 (round 6 experiment, harness only -- tools/micro/meta_w12.hip): the 36 KB of W1 fragments are read from global memory (L2 / L1
+  // resident, every wave of the chip reads the same 4 KB per tap) instead of LDS, which frees the LDS a 12-wave workgroup needs for its
+  // 14-row halo: three waves per SIMD at <= 168 registers instead of two ("the W1-ring + third-wave form")
+  constexpr bool W1G = (V & 256) != 0;
   using HT = H16<DT>;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -363,8 +367,9 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   constexpr size_t W1S_B = 9 * 2 * 2 * 64 * 16, A2_B = 9 * 2 * 2 * 2 * 64 * 16, WB = W1S_B + A2_B;
   constexpr size_t CONST_B = 9 * 64 * 4 * 2 + 512 + 512;
+  constexpr size_t WBL = W1G ? A2_B : WB;         // weight bytes held in LDS
   unsigned char* lw = smem;
-  unsigned char* lc = smem + WB;
+  unsigned char* lc = smem + WBL;
   unsigned char* halo = lc + CONST_B;
   float* chalo = (float*)(halo + HR * HC * PXB);  // [3][HR][HC]
   const float* cb1 = (const float*)lc;            // [9][64]
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int px = lane & 31, hi = lane >> 5;
 
-  for (size_t i = tid; i < WB / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)a.packed)[i];
+  for (size_t i = tid; i < WBL / 16; i += NT) ((Slot16*)lw)[i] = ((const Slot16*)(a.packed + (W1G ? W1S_B : 0)))[i];
   for (size_t i = tid; i < CONST_B / 16; i += NT) ((Slot16*)lc)[i] = ((const Slot16*)(a.packed + WB))[i];
   const bf16_t* data = (const bf16_t*)a.data;
   bf16_t* yout = (bf16_t*)a.y;
@@ -440,8 +445,9 @@ __global__ __launch_bounds__(WAVES * 64) void meta16_kernel(MetaArgs a) {
   // A operand of the hidden-layer MFMA (see pack_meta): four registers for the whole kernel
   const s16x8 w0frag = *(const s16x8*)(a.packed + meta_layout(DT).w0f + lane * 16);
   // per-lane LDS addresses that do not depend on the tile: everything a tap adds to them is a compile-time constant
-  const unsigned char* w1l = lw + lane * 16;                 // + ((k*2 + mt)*2 + ks) * 1024
-  const unsigned char* a2l = lw + W1S_B + lane * 16;         // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
+  const unsigned char* w1l;                                  // + ((k*2 + mt)*2 + ks) * 1024
+  if constexpr (W1G) w1l = a.packed + lane * 16; else w1l = lw + lane * 16;
+  const unsigned char* a2l = lw + (W1G ? 0 : W1S_B) + lane * 16;   // + (((k*2 + ot)*2 + mt)*2 + s2) * 1024
   const float* cbl = cb1 + 16 * hi;                          // + k*64 + 32*mt + 4*q
   const float* ctl = ct1 + 16 * hi;
   const int pl0 = (wv + 1) * HC + (px + 1);                  // centre pixel of this lane in the halo
