@@ -12,7 +12,8 @@ DLA backbone + fused Meta-Kernel + 3-level heads + sigmoid/top-50000/sort + 3D b
 (config `rangedet_veh_wo_aug_4_18e`, bf16 activations/weights with fp32 accumulation; BASELINE configs[1] plus the WNMS
 of configs[2]).  Inputs are resident in HBM before the timed region.  Frames shard across ranks with no data-path
 collective (weak scaling); for N > 1 every step ends with the one RCCL all_gather of the padded detections
-(SURVEY.md 8e), enqueued on the post-processing stream.  Rank 0 prints ONE JSON line.
+(SURVEY.md 8e), packed behind the batch's NMS and enqueued on the pipeline's communication stream (no launch stream carries it).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json

@@ -2,7 +2,10 @@
 TFLOP/s and TB/s of algorithmic bytes, with and without the residual.  Tuning aid; dev switches (RD_CONV_HB3, and RD_CONV3_DBG
 with a -DRD_CONV3_DEV build selected through RANGEDET_HIP_LIB) are read by the library.
     [B=8] [WS=2656,1328] [C128=1] [RES=0|1|both] [ITER=30] python tools/conv64_bench.py
-(RES / ITER / WS select ONE launch class for a counter pass: tools/pmc_conv_classes.sh)"""
+(RES / ITER / WS select ONE launch class for a counter pass: tools/pmc_conv_classes.sh)
+(Round 6: the RD_* variables named here are DEVELOPMENT switches -- the release library ignores them.  Build the A/B library with
+`python -m rangedet_amd.build --dev` and run with RANGEDET_HIP_LIB=rangedet_amd/librangedet_hip_dev.so RD_DEV_SWITCHES=1; tools/exp/ab.sh does both.)
+"""
 import os
 import sys
 

@@ -6,7 +6,10 @@ idle GPU; on a difference the intermediate arrays in the workspace (prep records
 are compared stage by stage.
     [TIE=stable] [LOAD=forward|none|matmul|kind:<plan step kind>|sweep] [LREP=3] [RD_WNMS_...=1] python tools/nms_race.py [reps]
   LOAD=sweep   every plan step on its own as the concurrent load (which launches matter: the cout-64 ones, two workgroups per CU)
-  RANGEDET_HIP_LIB=<a build with the SLP vectoriser>  reproduces the fault; the shipped build gives 0 of N"""
+  RANGEDET_HIP_LIB=<a build with the SLP vectoriser>  reproduces the fault; the shipped build gives 0 of N
+(Round 6: the RD_* variables named here are DEVELOPMENT switches -- the release library ignores them.  Build the A/B library with
+`python -m rangedet_amd.build --dev` and run with RANGEDET_HIP_LIB=rangedet_amd/librangedet_hip_dev.so RD_DEV_SWITCHES=1; tools/exp/ab.sh does both.)
+"""
 import os
 import sys
 

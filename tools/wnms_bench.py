@@ -1,5 +1,8 @@
 """Batched post-processing on the bench's own candidates (dev tool): python tools/wnms_bench.py
-   RD_WNMS_ONE_ROUND=1 switches the weighted NMS back to a single pairs/scan round."""
+   RD_WNMS_ONE_ROUND=1 switches the weighted NMS back to a single pairs/scan round.
+(Round 6: the RD_* variables named here are DEVELOPMENT switches -- the release library ignores them.  Build the A/B library with
+`python -m rangedet_amd.build --dev` and run with RANGEDET_HIP_LIB=rangedet_amd/librangedet_hip_dev.so RD_DEV_SWITCHES=1; tools/exp/ab.sh does both.)
+"""
 import os
 import sys
 
