@@ -210,8 +210,44 @@ else:
                     nan = int(torch.isnan(yw[i].float()).sum())
                     stats.append((ed, ew, md, mw, nan))
                 ed, ew, md, mw, nan = stats[0]
+                model_line = ""
+                if B <= 3:
+                    # the numpy model's arithmetic (V and U rounded to the 16-bit type, wide accumulation, one output rounding) in torch fp64 on
+                    # the device: the kernel's output must be within one 16-bit ulp of it and almost everywhere equal
+                    x64 = xs[0].double()
+                    ws32 = torch.from_numpy((w * scale[:, None, None, None]).astype(np.float32)).cuda()
+                    g0, g1, g2 = ws32[..., 0], ws32[..., 1], ws32[..., 2]
+                    U = [g0, 0.5 * ((g0 + g2) + g1), 0.5 * ((g0 + g2) - g1), -g2]
+                    U = [u.to(tdt).double() for u in U]
+                    P = (W + 1) // 2
+                    xp = torch.zeros(B, H + 2, 2 * P + 2, cin, device=dev, dtype=torch.float64)
+                    xp[:, 1:H + 1, 1:W + 1] = x64
+                    d = [xp[:, :, j:j + 2 * P:2] for j in range(4)]
+                    V = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[3] - d[1]]
+                    V = [v.float().to(tdt).double() for v in V]
+                    M = []
+                    for mi in range(4):
+                        acc = 0
+                        for dh in range(3):
+                            acc = acc + torch.einsum("bhpc,oc->bhpo", V[mi][:, dh:dh + H], U[mi][:, :, dh])
+                        M.append(acc)
+                    ym = torch.zeros(B, H, 2 * P, 128, device=dev, dtype=torch.float64)
+                    ym[:, :, 0::2] = M[0] + M[1] + M[2]
+                    ym[:, :, 1::2] = M[1] - M[2] - M[3]
+                    ym = ym[:, :, :W] + T.double()
+                    if flags & R.RD_ADD:
+                        ym = ym + rs[0].double()
+                    ym = ym.relu()
+                    ymr = ym.float().to(tdt).double()
+                    yk = yw[0].double()
+                    ulp = 2.0 ** (torch.floor(torch.log2(torch.clamp(ym.abs(), min=0.05))) - (7 if dt == R.RD_BF16 else 10))
+                    nbad = int(((yk - ymr).abs() > 1.001 * ulp).sum())
+                    neq = float((yk == ymr).double().mean())
+                    model_line = "   vs the fp64 model of the same arithmetic: %d beyond one ulp, %.4f equal" % (nbad, neq)
+                    assert nbad == 0 and neq > 0.97, model_line
                 line = "dt %d B %d H %d W %-5d cin %-3d flags %d: rel rms err vs fp32 conv: direct %.3e wino %.3e (x%.2f)  max/rms: %.3e / %.3e  nan %d" % (
                     dt, B, H, W, cin, flags, ed, ew, ew / ed, md, mw, nan)
+                line += model_line
                 if bench and B == 8:
                     res = {}
                     for name, fn in (("direct", direct), ("wino", wino), ("direct2", direct), ("wino2", wino)):
