@@ -68,6 +68,11 @@ extern "C" {
 #define RD_SCALE_FOLDED 8 /* 16-bit 3x3 family only: the packer folded the BatchNorm scale into the weights (fold_scale argument of
                            * the packers); `scale` must be NULL.  The shift then enters the accumulators through one extra MFMA
                            * per accumulator and the epilogue has no multiply-add (what the production lowering uses) */
+#define RD_MFMA16 16 /* rd_conv3x3_bn_act_ex (with RD_SCALE_FOLDED; stride 1, cout 128, cin a multiple of 32, no fused shortcut): w_packed is
+                      * the image of rd_pack_conv3x3_m16_host and the launch issues v_mfma_f32_16x16x32 instead of 32x32x16 -- the same
+                      * sums in the same per-channel order of the 32-channel chunks and taps; under the power cap of the part the
+                      * matrix cores sustain more of them.  Like RD_SCALE_FOLDED a property of the packed image
+                      * that the caller passes along: the library keeps no state per image */
 
 int rd_version(void);
 const char* rd_last_error_string(void);
@@ -127,6 +132,11 @@ int rd_conv2d_bn_act(const void* x, int x_cstride, int x_coff, const void* w_pac
 size_t rd_conv3x3_ex_packed_bytes(int cin, int cout, int stride_w, int x_cstride);
 int rd_pack_conv3x3_ex_host(const float* w_oihw_host, const float* fold_scale_host, int cout, int cin, int stride_w,
                             int x_cstride, int dtype, void* packed_host);
+/* weights of an RD_MFMA16 launch (same size as rd_conv3x3_ex_packed_bytes(cin, 128, 1, cin)); rd_conv3x3_mfma16_ok: 1 if the library has that
+ * launch form for a stride_w conv cin -> cout at width W (fused_output_conv: through rd_conv2d_bn_act_head_out) -- the caller asks before
+ * it packs; a launch with RD_MFMA16 where the answer is 0 fails with RD_ESHAPE */
+int rd_pack_conv3x3_m16_host(const float* w_oihw_host, const float* fold_scale_host, int cout, int cin, int dtype, void* packed_host);
+int rd_conv3x3_mfma16_ok(int cin, int cout, int stride_w, int W, int fused_output_conv);
 size_t rd_conv1x1_sc_packed_bytes(int cin, int cout);
 int rd_pack_conv1x1_sc_host(const float* w_oi_host, const float* fold_scale_host, int cout, int cin, int dtype,
                             void* packed_host);

@@ -136,6 +136,29 @@ inline void pack_taps_frag(int ntaps, int cin, int cout, void* out, F get, int d
           }
 }
 
+// M16 (round 6): the same weights for the v_mfma_f32_16x16x32 form of the kernel: [32-ch chunk][tap][Cout/16][64 lanes][8], lane (mm, q)
+// of fragment cb holds W[co = conv_row16(cb, mm)][ci = 32*chunk + 8*q + j][tap] -- one fragment is 16 output channels x all 32 input
+// channels of the chunk (the 32 x 32 x 16 form: 32 output channels x 16 input channels); same bytes, same slab size.
+// MFMA row mm = 4*qd + r lands in accumulator register r of the lanes of quad qd (D[m][n]: lane n + 16*(m/4), register m%4), and the
+// row -> channel map gives lane quad qd the 8 CONTIGUOUS channels 32*(cb/2) + 8*qd .. +7 from the fragment pair (cb even, cb odd): one
+// 16-byte slot of the output pixel per pair.
+__host__ __device__ inline int conv_row16(int cb, int mm) { return 32 * (cb >> 1) + 8 * (mm >> 2) + 4 * (cb & 1) + (mm & 3); }
+template <class F>
+inline void pack_taps_frag16(int ntaps, int cin, int cout, void* out, F get, int dt = RD_BF16) {
+  const int nchunk = (cin + 31) / 32, ncb = cout / 16;
+  bf16_t* o = (bf16_t*)out;
+  for (int c = 0; c < nchunk; ++c)
+    for (int t = 0; t < ntaps; ++t)
+      for (int cb = 0; cb < ncb; ++cb)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = conv_row16(cb, lane & 15);
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c * 32 + (lane >> 4) * 8 + j;
+            *o++ = h16_from_f32(dt, ci < cin ? get(co, ci, t) : 0.f);
+          }
+        }
+}
+
 // packed 1x1 output-conv weights of the HEAD variant: [hi | lo][ks 0..7][64 lanes][8 bf16]; lane (mm, hi) of k-step ks holds
 // w[mm][16*ks + 8*hi + j] (rows mm >= nout and channels >= cin are zero), hi = bf16(w), lo = bf16(w - hi).
 inline void pack_head_frag(const float* w, int nout, int cin, void* out, int dt = RD_BF16) {
@@ -218,6 +241,7 @@ constexpr int c3_younger(int R, int IPW, int s, int NS, int HP, int NHB = 2) {
 // BODY 1 (stride 2), per 128-byte line of the view pixel: [T6A odd chunk | T3 even | T3 even | T6A odd] -- the chunk whose lines
 //   are new to L2 is always fetched during a 6-step unit, the 3-step units fetch the second half of a line that is already there;
 // BODY 2: [T9, T9, P5] (64 + <= 16 channels: the level-0 tower convs on [agg3 | range image]);  BODY 3: [P5] (the first layer).
+constexpr int C3_BODY_M16 = 16;   // launch_conv3's `body` argument: not a tile body but the v_mfma_f32_16x16x32 form of the homogeneous one
 enum { UK_T9 = 0, UK_T6A = 1, UK_T6B = 2, UK_T6R = 3, UK_T3 = 4, UK_P5 = 5 };
 constexpr int uk_nsteps(int k) { return k == UK_T9 ? 9 : k == UK_T3 ? 3 : k == UK_P5 ? 5 : 6; }
 struct C3KStep { int dh, dw, slot; };   // tap row, column index into the per-lane column offsets, 16-channel slot of the chunk
@@ -308,9 +332,20 @@ inline int conv3_body_cat(int cin1, int cin2, bool folded) { return folded && co
 // GRP: two problems per launch (Conv3Args::ngrp): the tile list runs over 2B images, the group of an image selects the input,
 // weight image, shift, residual, output (and fused output conv) -- the launch then has twice the tiles per resident workgroup
 // slot (half the tail round) and one prologue / drain instead of two.  Only for the forms the lowering pairs: FOLD, no SC.
+// M16 (round 6): the MFMAs as v_mfma_f32_16x16x32 instead of 32x32x16.  Under the part's power cap the matrix cores sustain more of the
+// SAME arithmetic in that shape (tools/micro/mfma_power.hip, profiles/r06g_mfma_power.txt: operands from LDS at the same bytes per FLOP,
+// post-ReLU activations against N(0, 0.05) weights: 1 539 -> 1 698 TFLOP/s, shader clock 1 753 -> 2 015 MHz; a 16 x 16 tile moves half the
+// accumulator bits per FLOP).  Cout 128 on the 8 x 32 tiles only.  A step (one tap of one 32-channel chunk) is ONE k-step of 32 channels:
+// 4 pixel half-fragments (16 pixels x 32 channels: lane (n, q) reads slot q of pixel n -- the same LDS bytes as the two 16-channel
+// k-steps of a 32-pixel fragment) against the slab's 8 weight fragments (16 channels x 32: pack_taps_frag16) = 32 MFMAs on 32
+// accumulators of 4 registers.  Block 0 = weight fragments 0..3, block 1 = 4..7, pixel-major inside a block, so a pixel half-fragment's
+// register is free after its 4th MFMA of block 1 and is re-read for the next step right there (single buffered); the barrier, the counted
+// waits and the DMA schedule are those of the 32 x 32 form (12 fragment reads per step in both).
 template <int NCT, int DBG = 0, int TS = 0, bool HEAD = false, bool SC = false, bool FOLD = false, int FPW = 4, int FC = 2, int NHB = 2,
-          int DT = RD_BF16, bool WD = false, bool GRP = false, int BODY = 0>
+          int DT = RD_BF16, bool WD = false, bool GRP = false, int BODY = 0, bool M16 = false>
 __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel(Conv3Args a) {
+  static_assert(!M16 || (NCT == 4 && FPW == 2 && FC == 1 && WD && FOLD && !SC && !GRP && TS == 0 && BODY == 0 && DBG == 0),
+                "16 x 16 x 32 form: cout 128 on the 8 x 32 tiles, folded scales, all nine taps");
   static_assert(BODY == 0 || (WD && FOLD && !GRP && !HEAD && (TS == 0 || TS == 1)), "heterogeneous tile bodies: 8 x 32 tiles, folded scales");
   static_assert(!GRP || (FOLD && !SC && !(HEAD && FPW == 4)), "two problems per launch: folded scales, no shortcut, output-conv weights from L2");
   static_assert((NHB == 2 && !WD) || FOLD, "three halo buffers / wide tile: no room for the scale / shift array");
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       bzw[j] = hi ? 0u : ((unsigned)th | ((unsigned)tl << 16));
     }
   };
-  if constexpr (FOLD && !GRP) load_shift(a.shift);
+  if constexpr (FOLD && !GRP && !M16) load_shift(a.shift);
   // GRP: the fragment of BOTH problems, loaded once (4 more registers; a reload inside the tile loop would be a vector-memory
   // load whose wait drains the LDS-DMA queue -- measured +8 .. 12 us per launch); the tile's one is selected per tile
   unsigned bzw1[GRP ? NCT : 1];
@@ -364,6 +399,19 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 #pragma unroll
     for (int j = 0; j < NCT; ++j) bzw1[j] = bzw[j];
     load_shift(a.shift);
+  }
+  // M16: the shift of MFMA row lane & 15 of fragment cb as the dword {hi, lo}, held by lane quad cb & 3 in register cb >> 2: its two
+  // halves are k = 8*(cb & 3), +1 of the A operand, and the rank-1 MFMA of fragment cb takes ones in exactly those two k (2 registers
+  // instead of 8 across the MFMA phase)
+  unsigned bzw16[M16 ? 2 : 1];
+  if constexpr (M16) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float t = a.shift ? a.shift[conv_row16(4 * g + (lane >> 4), lane & 15)] : 0.f;
+      const bf16_t th = H16<DT>::from_f32(t);
+      const bf16_t tl = H16<DT>::from_f32(t - H16<DT>::to_f32(th));
+      bzw16[g] = (unsigned)th | ((unsigned)tl << 16);
+    }
   }
   int tpt = 0;
 #define C3_TRACE() { if (a.trace && tid == 0 && tpt < 7) a.trace[(size_t)blockIdx.x * 8 + tpt++] = wall_clock64(); }
@@ -539,6 +587,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   for (int d = 0; d < 3; ++d) {
     const int c = d + m;                                  // 1 + dw + m with dw = d - 1
     aoff[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * RW * C3_ROWB;
+    if constexpr (M16) {                                  // lane (n, q): slot q of pixel column d + n (+16 columns = +1024 B, same swizzle term)
+      const int c16 = d + (lane & 15);
+      aoff[d] = c16 * 64 + ((((lane >> 4) ^ (c16 >> 2)) & 3) << 4) + wave * RW * C3_ROWB;
+    }
   }
   const int boff = RING + lane * 16;
   // PH: the two column offsets of the tile's tap-set side; pq0 = column 0 of the NEXT list entry's side (the last step of a tile
@@ -553,8 +605,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   bool lastc = false;   // (PH) the unit being computed is the last chunk of its tile
 #define C3_AO(D) (PH ? pcol[(D)] : aoff[(D)])
 
-  f32x16 acc[FPW][NCT];
+  f32x16 acc[M16 ? 1 : FPW][M16 ? 1 : NCT];
+  f32x4 acc6[M16 ? 4 : 1][M16 ? 8 : 1];   // M16: [pixel half-fragment 2*row + half][16-channel fragment]
   s16x8 fa[2][FPW], fb[2][NCT];
+  s16x8 fa16[4];
 #define C3_FENCE() __builtin_amdgcn_sched_barrier(0)
   // fragment read k of a k-step, in the order the MFMA sequence needs them: fa[0], fb[0..NCT-1], fa[1..3]
 #define C3_RD(BUF, K, AADDR, BADDR, KS)                                                                   \
@@ -579,6 +633,15 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       acc[(N) / NCT][(N) % NCT] = H16<DT>::mfma(fb[BUF][(N) % NCT], fa[BUF][(N) / NCT], \
                                                                           f32x16{});             \
     C3_FENCE();                                                                                           \
+  }
+  // M16: weight fragment C of the slab half at BADDR; pixel half-fragment HX = 2*row + half of the tap at AADDR; MFMA N of block BK =
+  // pixel half-fragment N / 4 against weight fragment 4*BK + N % 4
+#define C3_RDW16(BUF, C, BADDR) { fb[BUF][C] = *(const s16x8*)(smem + (BADDR) + (C) * 1024); C3_FENCE(); }
+#define C3_RDP16(HX, AADDR) { fa16[HX] = *(const s16x8*)(smem + (AADDR) + ((HX) >> 1) * C3_ROWB + ((HX) & 1) * 1024); C3_FENCE(); }
+#define C3_MM16(BK, N)                                                                                                   \
+  {                                                                                                                      \
+    acc6[(N) >> 2][4 * (BK) + ((N) & 3)] = H16<DT>::mfma16(fb[BK][(N) & 3], fa16[(N) >> 2], acc6[(N) >> 2][4 * (BK) + ((N) & 3)]); \
+    C3_FENCE();                                                                                                          \
   }
   // workgroup barrier that retires the counted DMA and all LDS reads except the NR youngest (the fragments of the next
   // step just requested), nothing else (see k_conv.h for why this is not __syncthreads())
@@ -617,9 +680,16 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
   constexpr int K00DW = K00.dw, K00DH = K00.dh;
   int rslot = 0;        // ring slot of the slab being consumed
   int abuf = 0;         // halo buffer (byte offset) of the unit being consumed
+  if constexpr (M16) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C3_RDW16(0, k, boff + rslot * SLAB)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C3_RDP16(k, aoff[K00DW] + abuf + K00DH * C3_ROWB)
+  } else {
 #pragma unroll
   for (int k = 0; k < NR; ++k)   // fragments of (unit 0, first tap, ks 0)
     C3_RD(0, k, C3_AO(K00DW) + abuf + K00DH * C3_ROWB, boff + rslot * SLAB, 0)
+  }
 
   // One step = tap T of the current unit, software pipelined by hand (one wave per SIMD: nothing else hides latency).
   //   block 0: MFMAs of ks 0, with the reads of (this step, ks 1) interleaved 1:1 into its first half;
@@ -658,6 +728,45 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             C3_FENCE();                                                                                              \
           }                                                                                                          \
       }                                                                                                              \
+    }                                                                                                                \
+    slab_advance();                                                                                                  \
+    rslot = rnext_;                                                                                                  \
+  }
+
+  // M16 step (see the kernel's header): block 0 with the reads of the slab's second half, block 1 with the reads of the next step
+  // (weights first, a pixel half-fragment right after its last MFMA), the barrier after the first half of block 1 (6 reads of the next
+  // step outstanding), the DMA issue in its second half.
+#define C3_STEP16(S)                                                                                                 \
+  {                                                                                                                  \
+    constexpr int TN_ = c3_tap(TS, ((S) + 1) % NS), ndh_ = TN_ / 3, ndw_ = TN_ % 3;                                  \
+    constexpr int NH_ = c3_halo_pieces((S), NS, HPC), NP_ = IPW + NH_;                                               \
+    const int bcur_ = boff + rslot * SLAB;                                                                           \
+    const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                               \
+    const int anext_ = aoff[ndw_] + ((S) == NS - 1 ? hnext(abuf) : abuf) + ndh_ * C3_ROWB;                           \
+    const int bnext_ = boff + rnext_ * SLAB;                                                                         \
+    const int hbuf_ = hprev(abuf);                                                                                   \
+    C3_FENCE();                                                                                                      \
+    _Pragma("unroll") for (int n = 0; n < 16; ++n) {                                                                 \
+      C3_MM16(0, n)                                                                                                  \
+      if (n < 4) C3_RDW16(1, n, bcur_ + 4096)                                                                        \
+    }                                                                                                                \
+    _Pragma("unroll") for (int n = 0; n < 8; ++n) {                                                                  \
+      C3_MM16(1, n)                                                                                                  \
+      if (n < 4) C3_RDW16(0, n, bnext_)                                                                              \
+      if (n == 3) C3_RDP16(0, anext_)                                                                                \
+      if (n == 7) C3_RDP16(1, anext_)                                                                                \
+    }                                                                                                                \
+    C3_SYNC(c3_younger(R, IPW, (S), NS, HPC, NHB), 6)                                                                \
+    if ((S) == 0) halo_begin();                                                                                      \
+    _Pragma("unroll") for (int n = 8; n < 16; ++n) {                                                                 \
+      C3_MM16(1, n)                                                                                                  \
+      _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                                \
+        if (p * 8 / NP_ == n - 8) {                                                                                  \
+          if (p < IPW) slab_piece(p); else halo_piece(hbuf_, c3_halo_first((S), NS, HPC) + p - IPW);                 \
+          C3_FENCE();                                                                                                \
+        }                                                                                                            \
+      if (n == 11) C3_RDP16(2, anext_)                                                                               \
+      if (n == 15) C3_RDP16(3, anext_)                                                                               \
     }                                                                                                                \
     slab_advance();                                                                                                  \
     rslot = rnext_;                                                                                                  \
@@ -711,6 +820,35 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
 
   for (int k = 0; k < ntl; ++k) {
     if constexpr (PH) lastc = a.nchunk == 1;
+    if constexpr (M16) {
+      // every accumulator starts from its channel's shift: one rank-1 MFMA per 16-channel fragment (A = the shift as hi + lo in the two
+      // k of lane quad cb & 3, B = ones in the same two k), whose result is the same for every pixel -- the other three pixel
+      // half-fragments are register copies
+      unsigned z0 = 0u;
+      asm volatile("" : "+v"(z0));
+      int oq = lane >> 4;
+      asm volatile("" : "+v"(oq));
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        unsigned ob[4] = {oq == (cb & 3) ? H16<DT>::ONE * 0x10001u : z0, z0, z0, z0};
+        unsigned ab[4] = {bzw16[cb >> 2], z0, z0, z0};
+        s16x8 ones, bz;
+        memcpy(&ones, ob, 16);
+        memcpy(&bz, ab, 16);
+        acc6[0][cb] = H16<DT>::mfma16(bz, ones, f32x4{});
+        C3_FENCE();
+      }
+#pragma unroll
+      for (int h = 1; h < 4; ++h)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) acc6[h][cb] = acc6[0][cb];
+      C3_FENCE();
+#pragma unroll 1
+      for (int c = 0; c < a.nchunk; ++c) {
+        C3_STEP16(0) C3_STEP16(1) C3_STEP16(2) C3_STEP16(3) C3_STEP16(4) C3_STEP16(5) C3_STEP16(6) C3_STEP16(7) C3_STEP16(8)
+        abuf = hnext(abuf);
+      }
+    } else {
     {   // first chunk of the tile, peeled: its first k-step starts the accumulators from C = 0 (FOLD: from the shift)
       if constexpr (FOLD) {
         // (the zero words go through an opaque copy once per tile: as compile-time zeros the five operand tuples are loop
@@ -754,6 +892,7 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       abuf = hnext(abuf);
     }
     }
+    }   // !M16
     if (k == 0) C3_TRACE()
 
     // ---- epilogue of tile k: BN affine, ReLU / residual, then a transpose through LDS so that every global store
@@ -982,16 +1121,131 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
         }   // channel pass
       }
     };
+    // M16: lane (n, q) of accumulator (h = 2*row + half, cb) holds channels 32*(cb/2) + 8*q + 4*(cb & 1) + r (r = 0..3) of pixel
+    // 16*half + n of its row, i.e. per fragment pair the 8 contiguous channels of ONE 16-byte slot: convert, (add the residual slot,)
+    // clamp, write the slot into the same pixel-major scratch image, read it back and store as above.
+    auto epilogue16 = [&](auto FL) {
+      constexpr int F = decltype(FL)::value;
+      const bool relu_pre = F >= 0 ? (F & RD_RELU_PRE) != 0 : (a.flags & RD_RELU_PRE) != 0;
+      const bool do_add = F >= 0 ? (F & RD_ADD) != 0 : (a.flags & RD_ADD) != 0;
+      const bool relu_post = F >= 0 ? (F & RD_RELU_POST) != 0 : (a.flags & RD_RELU_POST) != 0;
+      const bool relu_f32 = relu_pre && do_add;
+      const bool relu_i16 = relu_post || (relu_pre && !do_add);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      const int en = el & 15, eq = el >> 4;
+      Slot16 rv[2][2][JW];                                   // [buffer][pixel half][fragment pair of the pass]: one pass (row i, 64 channels) ahead
+      auto res_load = [&](int t, Slot16 (&dst)[2][JW]) {      // pass t = NPASS * i + jp
+        const int i = t / NPASS, jp = t % NPASS;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int ow = ct * C3_TW + 16 * hf + en, oh = oh0 + i;
+          const bool live = ow < a.W && oh < a.H;
+          const bf16_t* rp = rimg0 + (live ? ((size_t)oh * a.Wo + (size_t)ow) * a.r_cs : 0) + 8 * eq + jp * CW;
+#pragma unroll
+          for (int pp = 0; pp < JW; ++pp) dst[hf][pp] = *(const Slot16*)(rp + 32 * pp);
+        }
+      };
+      if (do_add) res_load(0, rv[0]);
+#pragma unroll
+      for (int i = 0; i < FPW; ++i) {
+        f32x16 h0, h1;                       // HEAD: the output conv's accumulators (weights hi / lo), summed over the passes
+        if constexpr (HEAD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+        }
+#pragma unroll
+        for (int jp = 0; jp < NPASS; ++jp) {
+          const int t = NPASS * i + jp;
+          if (do_add && t + 1 < NPASS * FPW) res_load(t + 1, rv[(t + 1) & 1]);
+          // HEAD: this pass's weight fragments (hi and lo) from L2, requested before the conversion work (as in the 32 x 32 x 16 form:
+          // the output conv itself stays a 32 x 32 x 16 MFMA on the pixel-major scratch image, whatever shape produced it)
+          constexpr int KSP = 8 / NPASS;
+          s16x8 hwq[HEAD ? 2 : 1][HEAD ? KSP : 1];
+          if constexpr (HEAD) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+              for (int ks = 0; ks < KSP; ++ks)
+                hwq[part][ks] = *(const s16x8*)(e_hw + part * 8192 + (jp * KSP + ks) * 1024 + el * 16);
+          }
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int pp = 0; pp < JW; ++pp) {
+              C3_FENCE();   // one 16-byte slot at a time: keeps the register footprint of the epilogue small
+              const int p = jp * JW + pp, h = 2 * i + hf;
+              unsigned pk[4];
+#pragma unroll
+              for (int w2 = 0; w2 < 4; ++w2) {
+                const f32x4 av = acc6[h][2 * p + (w2 >> 1)];
+                f32x2 v = {av[2 * (w2 & 1)], av[2 * (w2 & 1) + 1]};
+                if (relu_f32) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+                if (do_add) v += H16<DT>::unpk(rv[t & 1][hf][pp][w2]);
+                unsigned p2 = H16<DT>::pk(v[0], v[1]);
+                if (relu_i16) p2 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
+                pk[w2] = p2;
+              }
+              const int px = 16 * hf + en;
+              *(Slot16*)(scr + px * ROWB + (((4 * pp + eq) ^ (px & (SPR - 1))) << 4)) = Slot16{pk[0], pk[1], pk[2], pk[3]};
+            }
+          C3_FENCE();
+          __builtin_amdgcn_wave_barrier();
+          if constexpr (HEAD) {
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks) {
+              const s16x8 bq = *(const s16x8*)(scr + em * ROWB + (((2 * ks + ehi) ^ (em & (SPR - 1))) << 4));
+              h0 = H16<DT>::mfma(hwq[1][ks], bq, h0);
+              h1 = H16<DT>::mfma(hwq[0][ks], bq, h1);
+            }
+            const int ows = ct * C3_TW + em, ohs = oh0 + i;
+            if (jp == NPASS - 1 && ows < a.W && ohs < a.H) {
+              float* o = e_ho + (size_t)b * e_ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * e_hn + 4 * ehi;
+              if (e_hn == 8 && !((size_t)o & 15)) {
+                const f32x4 bv = *(const f32x4*)(e_hb + 4 * ehi);
+                *(f32x4*)o = f32x4{(h0[0] + h1[0]) + bv[0], (h0[1] + h1[1]) + bv[1], (h0[2] + h1[2]) + bv[2], (h0[3] + h1[3]) + bv[3]};
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (4 * ehi + r < e_hn) o[r] = (h0[r] + h1[r]) + e_hb[4 * ehi + r];
+              }
+            }
+          } else {
+#pragma unroll
+          for (int it = 0; it < 32 / RPI; ++it) {
+            const int pr = it * RPI + el / SPR, sl = el % SPR;
+            const Slot16 v = *(const Slot16*)(scr + pr * ROWB + ((sl ^ (pr & (SPR - 1))) << 4));
+            const int ows = ct * C3_TW + pr;
+            if (ows < a.W && oh0 + i < a.H)
+              __builtin_nontemporal_store(v, (Slot16*)(yrow0 + (size_t)i * a.Wo * a.y_cs + (size_t)ows * a.y_cs + jp * CW + sl * 8));
+          }
+          }
+          __builtin_amdgcn_wave_barrier();
+          C3_FENCE();
+        }
+      }
+    };
+    if constexpr (M16) {
+      static_assert(!M16 || (NPASS == 2 && JW == 2 && CW == 64), "M16 epilogue: two passes of 64 channels");
+      if (a.flags == RD_RELU_POST) epilogue16(std::integral_constant<int, RD_RELU_POST>{});
+      else if (a.flags == (RD_ADD | RD_RELU_POST)) epilogue16(std::integral_constant<int, RD_ADD | RD_RELU_POST>{});
+      else epilogue16(std::integral_constant<int, -1>{});
+    } else {
     if (a.flags == RD_RELU_POST) epilogue(std::integral_constant<int, RD_RELU_POST>{});
     else if (a.flags == (RD_ADD | RD_RELU_POST)) epilogue(std::integral_constant<int, RD_ADD | RD_RELU_POST>{});
     else if (TS != 0 && a.flags == (RD_RELU_PRE | RD_ADD)) epilogue(std::integral_constant<int, RD_RELU_PRE | RD_ADD>{});   // skip + relu(BN(deconv))
     else epilogue(std::integral_constant<int, -1>{});
+    }
     if (k == 0) C3_TRACE()
   }
   // DMA still in flight (the dummy tail fetches) targets this workgroup's LDS: retire it before the LDS is released
   __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));
   C3_TRACE()
   if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - clk0;   // shader-clock ticks of the whole life
+#undef C3_STEP16
+#undef C3_MM16
+#undef C3_RDP16
+#undef C3_RDW16
 #undef C3_GBODY_FROM1
 #undef C3_RDX
 #undef C3_GSTEP
@@ -1022,9 +1276,9 @@ inline int conv_num_cus() {
 }
 
 // One launch of one instantiation; the first launch of each raises its dynamic-LDS limit (once per process and instantiation).
-template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false, int BODY = 0>
+template <int NCT, int TS, bool HEAD, bool SC, bool FOLD, int FPW, int FC, int NHB, int DT, bool WD = false, bool GRP = false, int BODY = 0, bool M16 = false>
 inline int c3_go(int grid, hipStream_t st, const Conv3Args& a) {
-  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP, BODY>;
+  auto k = conv3x3_stream_kernel<NCT, 0, TS, HEAD, SC, FOLD, FPW, FC, NHB, DT, WD, GRP, BODY, M16>;
   static std::atomic<unsigned long long> seen{0};
   once_per_device(seen, [&] { allow_big_lds(k); });
   constexpr size_t lds = C3Cfg<NCT, FPW, FC, NHB, WD>::LDS + (HEAD && FPW == 4 ? 16384 : 0);   // (8 x 62 tile: the output conv's weights in LDS)
@@ -1066,6 +1320,14 @@ inline bool conv3_phases_eligible(int cout, int flags) {
   const DevSwitches& sw_ = dev_switches();
   return (cout == 64 || cout == 128) && (flags & RD_SCALE_FOLDED) && sw_.conv_w30 && sw_.conv_wide && !sw_.conv_v1 &&
          ((cout == 64 && sw_.conv_th4 != 3) || (cout == 128 && sw_.conv_th4 && sw_.conv_w30 == 2));
+}
+// Does the launcher have the v_mfma_f32_16x16x32 form (RD_MFMA16) for this conv?  The packer side of the contract: an image made by
+// rd_pack_conv3x3_m16_host may only be launched where this says yes (the launch fails loudly otherwise).
+inline bool conv3_mfma16_ok(int cin, int cout, int stride_w, int W, bool headfuse) {
+  const DevSwitches& sw_ = dev_switches();
+  const bool head30_ok = sw_.conv_w30 == 2 && sw_.conv_head30 != 0;
+  return cout == 128 && stride_w == 1 && cin >= 32 && cin % 32 == 0 && !sw_.conv_v1 && sw_.conv_wide && sw_.conv_w30 == 2 && sw_.conv_th4 &&
+         (sw_.conv_th4 != 2 || W >= 600) && (!headfuse || head30_ok);
 }
 inline bool conv3_pair_eligible(int cout, int flags, int W, bool headfuse = false) {
   const DevSwitches& sw_ = dev_switches();
@@ -1125,7 +1387,9 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   //  fragment and pass; measured per layer: W = 1328 213 -> 205 us, W = 664 109 -> 107 us, W = 2656 398 -> 405 us, so the
   //  full-width level stays on the 8 x 62 tile.  RD_CONV_HEAD30=0 -> never, =2 -> always)
   // (a two-problem launch always takes the two-workgroup tile: its output-conv weights are per problem and come from L2)
-  const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && W <= 1400) || (g1 && head30));   // (only exists on the 8 x 30 tiles)
+  // (round 6: in the 16 x 16 x 32 form the two-workgroup tile wins at full width too -- W 2656: 352 -> 328 us, +0.5 % frames/s on one box,
+  //  profiles/EXPERIMENTS.md -- so an RD_MFMA16 image always takes it)
+  const bool head30_ok = w30_mode == 2 && (head30 == 2 || (head30 == 1 && (W <= 1400 || body == C3_BODY_M16)) || (g1 && head30));   // (only exists on the 8 x 30 tiles)
   const bool th4 = th4_mode && (cout == 128 || th4_mode == 3) && fold && (!headfuse || head30_ok) && (th4_mode != 2 || W >= 600);
   const bool w30_128 = w30_mode == 2 && th4 && cout == 128;
   const bool w30 = w30_mode && fold && ((!th4 && cout == 64 && !headfuse) || w30_128);
@@ -1184,6 +1448,11 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
   C3_DBG128(4) C3_DBG128(8) C3_DBG128(16) C3_DBG128(2) C3_DBG128(32) C3_DBG128(256) C3_DBG128(257)
 #undef C3_DBG128
 #endif
+#ifdef RD_CONV3_DEV_M16_ONLY   // tools/micro/conv16_dev.hip: only the plain cout-128 form on the 8 x 32 tiles, in its two MFMA shapes (a one-minute build)
+  RD_REQUIRE(wd && fold && !head && !g1 && !ph && !s2 && sw == 1 && ts == 0 && cout == 128 && DT == RD_BF16, RD_ESHAPE, "conv16_dev: plain bf16 cout-128 form only");
+  if (body == C3_BODY_M16) return c3_go<4, 0, false, false, true, 2, 1, 2, RD_BF16, true, false, 0, true>(grid, st, a);
+  return c3_go<4, 0, false, false, true, 2, 1, 2, RD_BF16, true>(grid, st, a);
+#else
   constexpr bool kAllForms = kF16AllForms || DT == RD_BF16;
   RD_REQUIRE(kAllForms || (fold && w30 && (cout == 128 || hb3 || sw_.conv_wide)) || (headfuse && fold), RD_ESHAPE,
              "conv3: this fp16 launch form is not instantiated in the emulator build (conv3_has_form)");
@@ -1202,6 +1471,13 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
                    : c3_go<N, 2, false, false, true, FPW_, FC_, NHB_, DT, WD_>(grid, st, a);              \
   }
   if constexpr (kAllForms) { if (th4 && !w30) { if (cout == 128) C3_BODY(4, 2, 2, 2) else C3_BODY(2, 2, 2, 2) } }
+  if (body == C3_BODY_M16) {   // v_mfma_f32_16x16x32 form (RD_MFMA16: rd_pack_conv3x3_m16_host made the matching weight image)
+    RD_REQUIRE(wd && fold && !sc && !g1 && !ph && !s2 && sw == 1 && ts == 0 && cout == 128 && cin % 32 == 0, RD_ESHAPE,
+               "conv3: the 16 x 16 x 32 form needs the 8 x 32 tile form: cout 128, folded scales, stride 1, cin a multiple of 32 (cin %d)%s", cin,
+               headfuse ? " (rd_conv3x3_mfma16_ok)" : "");
+    if (headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, DT, true, false, 0, true>(grid, st, a);
+    return c3_go<4, 0, false, false, true, 2, 1, 2, DT, true, false, 0, true>(grid, st, a);
+  }
   if (body) {   // heterogeneous tile body (c3_body): the packer made the matching weight image
     RD_REQUIRE(wd && fold && !headfuse && !g1 && !ph && sw == 1 && a.nchunk % c3_body(body).nu == 0, RD_ESHAPE,
                "conv3: tile body %d needs the 8 x 32 tile form with folded scales (%d chunks)", body, a.nchunk);
@@ -1250,6 +1526,7 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
 #undef C3_PLAIN
   }
   return rd::fail(RD_ESHAPE, "conv3: launch form not available");
+#endif
 }
 
 }  // namespace rd

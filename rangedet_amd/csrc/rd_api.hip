@@ -263,6 +263,20 @@ int rd_pack_conv3x3_ex_host(const float* w, const float* fold_scale, int cout, i
   }
   return RD_OK;
 }
+// the same conv for RD_MFMA16 launches (k_conv3.h M16: v_mfma_f32_16x16x32 fragments): stride 1, cout 128, cin a multiple of 32
+int rd_pack_conv3x3_m16_host(const float* w, const float* fold_scale, int cout, int cin, int dtype, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv3x3_m16: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_conv3x3_m16: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE(cout == 128 && cin >= 32 && cin % 32 == 0, RD_ESHAPE, "pack_conv3x3_m16: cout %d (128), cin %d (a multiple of 32)", cout, cin);
+  memset(out, 0, rd_conv3x3_ex_packed_bytes(cin, cout, 1, cin));
+  pack_taps_frag16(9, cin, cout, out, [&](int co, int ci, int t) {
+    return (fold_scale ? fold_scale[co] : 1.f) * w[(((size_t)co * cin + ci) * 3 + t / 3) * 3 + t % 3];
+  }, dtype);
+  return RD_OK;
+}
+int rd_conv3x3_mfma16_ok(int cin, int cout, int stride_w, int W, int fused_output_conv) {
+  return conv3_mfma16_ok(cin, cout, stride_w, W, fused_output_conv != 0) ? 1 : 0;
+}
 size_t rd_conv1x1_sc_packed_bytes(int cin, int cout) { return sc_frag_bytes(cin, cout); }
 int rd_pack_conv1x1_sc_host(const float* w, const float* fold_scale, int cout, int cin, int dtype, void* out) {
   RD_REQUIRE(w && out, RD_EINVAL, "pack_conv1x1_sc: null pointer");
@@ -300,8 +314,12 @@ int rd_conv3x3_bn_act_ex(const void* x, int x_cstride, int x_coff, const void* w
     fl |= RD_SCALE_FOLDED;                     // (both scales are in the two weight sets)
   }
   RD_REQUIRE(!(fl & RD_SCALE_FOLDED) || !scale, RD_EINVAL, "conv3x3_ex: folded weights take no scale array");
+  const bool m16 = (fl & RD_MFMA16) != 0;
+  fl &= ~RD_MFMA16;
   const bool folded = (fl & RD_SCALE_FOLDED) != 0;
-  const int body = stride_w == 2 ? conv3_body_s2(cin, x_cstride, folded) : (sc_x ? 0 : conv3_body_small(cin, folded));
+  RD_REQUIRE(!m16 || (folded && !sc_x && conv3_mfma16_ok(cin, cout, stride_w, Win, false)), RD_ESHAPE,
+             "conv3x3_ex: RD_MFMA16 takes folded weights of rd_pack_conv3x3_m16_host: stride 1, cout 128, cin a multiple of 32, no fused shortcut (rd_conv3x3_mfma16_ok)");
+  const int body = m16 ? C3_BODY_M16 : stride_w == 2 ? conv3_body_s2(cin, x_cstride, folded) : (sc_x ? 0 : conv3_body_small(cin, folded));
   RD_REQUIRE(!(stride_w == 1 && sc_x && conv3_body_small(cin, folded)), RD_ESHAPE, "conv3x3_ex: at most 16 input channels together with a fused shortcut is not a launch form");
   return launch_conv3(x, x_cstride * v, x_coff, w_packed, scale, shift, residual, r_cstride, r_coff, y, y_cstride, y_coff, B, H,
                       Wv, ex_view_cin(cin, x_cstride, stride_w), cout, fl, 1, (hipStream_t)stream, stride_w == 2 ? 1 : 0,
@@ -393,12 +411,15 @@ int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const vo
              "conv2d_head_out: x channel stride/offset");
   RD_REQUIRE(!dev_switches().conv_v1, RD_EINVAL, "conv2d_head_out: needs the persistent 3x3 kernel (RD_CONV_V1 is set)");
   RD_REQUIRE(!conv3_body_small(cin, (flags & RD_SCALE_FOLDED) != 0), RD_ESHAPE, "conv2d_head_out: cin %d (the packed image of a conv with <= 16 input channels is not this launch form's)", cin);
+  const bool m16 = (flags & RD_MFMA16) != 0;
+  RD_REQUIRE(!m16 || ((flags & RD_SCALE_FOLDED) && conv3_mfma16_ok(cin, 128, 1, W, true)), RD_ESHAPE,
+             "conv2d_head_out: RD_MFMA16 (weights of rd_pack_conv3x3_m16_host) is not a launch form for cin %d at width %d (rd_conv3x3_mfma16_ok)", cin, W);
   allow_conv_lds();
   Conv3Args h;
   memset(&h, 0, sizeof(h));
   h.hw = (const unsigned char*)head_w_packed; h.hb = head_bias; h.ho = out; h.ho_bs = out_batch_stride; h.ho_off = n_off; h.hn = nout;
-  return launch_conv3(x, x_cstride, x_coff, w_packed, scale, shift, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags, 1,
-                      (hipStream_t)stream, 0, &h, dtype);
+  return launch_conv3(x, x_cstride, x_coff, w_packed, scale, shift, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, flags & ~RD_MFMA16, 1,
+                      (hipStream_t)stream, 0, &h, dtype, nullptr, nullptr, nullptr, m16 ? C3_BODY_M16 : 0);
 }
 
 // ---- the cls and the reg tower conv of a head level as ONE launch (two problems of the same shape) -------------------------

@@ -230,6 +230,9 @@ template <> struct H16<RD_BF16> {
     return f32x2_t_{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
   }
   __device__ static __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  // 16 x 16 x 32: A[m][k] lane m + 16*(k/8) element k%8, B[k][n] lane n + 16*(k/8) element k%8, D[m][n] lane n + 16*(m/4) register m%4
+  // (tools/micro/mfma16_probe.hip checks the map on the GPU; k_conv3.h M16 says why this shape)
+  __device__ static __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct H16<RD_F16> {
   static constexpr unsigned short ONE = 0x3C00;
@@ -241,6 +244,9 @@ template <> struct H16<RD_F16> {
   }
   __device__ static __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   }
 };
 inline bool is_h16(int dt) { return dt == RD_BF16 || dt == RD_F16; }

@@ -13,7 +13,7 @@ import numpy as np
 RD_OK, RD_EINVAL, RD_ESHAPE, RD_EWORKSPACE, RD_EHIP = 0, -1, -2, -3, -4
 RD_F32, RD_BF16, RD_F16 = 0, 1, 2
 H16 = (RD_BF16, RD_F16)     # the two 16-bit element types (same layouts)
-RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED = 1, 2, 4, 8
+RD_RELU_PRE, RD_ADD, RD_RELU_POST, RD_SCALE_FOLDED, RD_MFMA16 = 1, 2, 4, 8, 16
 RD_WNMS_MAX_K = 65536
 # diagnostic bits of rd_wnms_4c's tie_order (include/rangedet_hip.h): per-call test aids, the result never depends on them
 RD_WNMS_DIAG_NO_SKIP = 0x100
@@ -51,6 +51,8 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_ex_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rd_pack_conv3x3_ex_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rd_pack_conv3x3_m16_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rd_conv3x3_mfma16_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "rd_conv1x1_sc_packed_bytes": (c_size_t, [c_int, c_int]),
     "rd_pack_conv1x1_sc_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv3x3_bn_act_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
@@ -194,6 +196,16 @@ class Lib:
         out = np.zeros(self.cdll.rd_conv3x3_ex_packed_bytes(cin, cout, stride_w, x_cstride), dtype=np.uint8)
         self.call("rd_pack_conv3x3_ex_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, stride_w,
                   x_cstride, dtype, out.ctypes.data)
+        return out
+
+    def pack_conv3x3_m16(self, w_oihw, fold_scale, dtype=RD_BF16):
+        """weights of an RD_MFMA16 launch of rd_conv3x3_bn_act_ex (stride 1, cout 128, cin a multiple of 32, folded scales)"""
+        w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+        cout, cin = w.shape[:2]
+        assert w.shape[2:] == (3, 3)
+        fs = np.ascontiguousarray(fold_scale, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_conv3x3_ex_packed_bytes(cin, cout, 1, cin), dtype=np.uint8)
+        self.call("rd_pack_conv3x3_m16_host", w.ctypes.data, fs.ctypes.data, cout, cin, dtype, out.ctypes.data)
         return out
 
     def pack_conv3x3_cat(self, w_oihw, cin1, cin2, fold_scale=None, dtype=RD_BF16):

@@ -102,8 +102,26 @@ class Lowering:
         self._fuse_head_out()
         self._fuse_blocks()
         self._pair_equal_convs()
+        self._mark_mfma16()
 
     # ---- fusion ------------------------------------------------------------------------------------------------
+    def _mark_mfma16(self):
+        """16-bit: the plain stride-1 3x3 convs with 128 output channels (tower conv_1 / conv_2 of every head level, conv_0 of the
+        levels whose input is 64 / 128 channels, the last tower convs with their fused output conv, the 128-channel BasicBlock convs of
+        the backbone -- head/builder.py:221-240,
+        dla_backbone.py:18-56) are launched in the v_mfma_f32_16x16x32 form of the persistent kernel (RD_MFMA16, k_conv3.h M16): the
+        same numbers bit for bit, 3 - 6 % less time from W = 664 up because the part sustains a higher clock on that instruction
+        (DESIGN.md 6.3, round 6).  Step key "m16": the executor packs with rd_pack_conv3x3_m16_host and passes the flag.
+        RD_NO_MFMA16=1 (development switch): off."""
+        if not self.h16 or devswitch.get("RD_NO_MFMA16"):
+            return
+        for st in self.plan.steps:
+            if st["kind"] == "conv" and tuple(st["k"]) == (3, 3) and st["cout"] == 128 and st["stride_w"] == 1 and st.get("ex") and \
+                    st.get("fold") and not st.get("sc") and st.get("x2") is None and not st.get("s2view"):
+                cin = len(st["cmap"]) if st.get("cmap") else st["cin"]
+                if cin % 32 == 0 and cin >= 32:
+                    st["m16"] = True      # (a request: the executor asks rd_conv3x3_mfma16_ok -- e.g. a full-width fused output conv stays as it was)
+
     def _pair_equal_convs(self):
         """16-bit: two 3x3 convs of the SAME shape whose inputs are both ready run as ONE launch (rd_conv3x3_bn_act_pair /
         rd_conv2d_bn_act_head_out_pair) -- in this graph the cls and the reg tower conv i of every head level

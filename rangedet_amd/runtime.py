@@ -215,6 +215,12 @@ class Executor:
                 b["w"] = A.upload(L.pack_conv3x3_cat(w, st["x"].C, st["x2"].cs, fold_scale=s, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload(t)
                 b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED
+            elif st.get("ex") and st.get("fold") and st.get("m16") and \
+                    L.raw("rd_conv3x3_mfma16_ok")(w.shape[1], st["cout"], 1, st["x"].W, 1 if st.get("head") else 0) == 1:
+                # the same in the 16 x 16 x 32 MFMA form (lower._mark_mfma16)
+                b["w"] = A.upload(L.pack_conv3x3_m16(w, s, dtype=dt))
+                b["scale"], b["shift"] = None, A.upload(t)
+                b["flags"] = st["flags"] | rdlib.RD_SCALE_FOLDED | rdlib.RD_MFMA16
             elif st.get("ex") and st.get("fold"):   # scale folded into the weights, the shift enters through the accumulators
                 b["w"] = A.upload(L.pack_conv3x3_ex(w, st["stride_w"], st["x"].cs, fold_scale=s, dtype=dt))
                 b["scale"], b["shift"] = None, A.upload(t)

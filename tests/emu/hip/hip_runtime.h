@@ -366,6 +366,43 @@ inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_h16x8 a, hipe
   for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
   return hipemu::mfma32<8>(fa, fb, c);
 }
+// 16 x 16 x 32 (gfx950): A[m][k] lane m + 16*(k/8) element k%8; B[k][n] lane n + 16*(k/8) element k%8; D[m][n] lane n + 16*(m/4) reg m%4
+// (the map tools/micro/mfma16_probe.hip confirms on the GPU)
+namespace hipemu {
+struct MfmaPkt16 { float a[8]; float b[8]; };
+inline hipemu_f32x4 mfma16(const float* a, const float* b, hipemu_f32x4 c) {
+  Wave& w = blk()->w[cur()->wave];
+  int lane = cur()->lane;
+  MfmaPkt16 pk;
+  for (int i = 0; i < 8; ++i) { pk.a[i] = a[i]; pk.b[i] = b[i]; }
+  memcpy(w.xchg[lane], &pk, sizeof(pk));
+  wave_barrier();
+  hipemu_f32x4 d;
+  int n = lane & 15, q = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int m = 4 * q + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      const MfmaPkt16* pa = (const MfmaPkt16*)w.xchg[m + 16 * (k / 8)];
+      const MfmaPkt16* pb = (const MfmaPkt16*)w.xchg[n + 16 * (k / 8)];
+      acc = fmaf(pa->a[k % 8], pb->b[k % 8], acc);
+    }
+    d[r] = acc;
+  }
+  wave_barrier();
+  return d;
+}
+}  // namespace hipemu
+inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_s16x8 a, hipemu_s16x8 b, hipemu_f32x4 c, int, int, int) {
+  float fa[8], fb[8];
+  for (int i = 0; i < 8; ++i) { fa[i] = hipemu::bf16_bits_to_f32((unsigned short)a[i]); fb[i] = hipemu::bf16_bits_to_f32((unsigned short)b[i]); }
+  return hipemu::mfma16(fa, fb, c);
+}
+inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_h16x8 a, hipemu_h16x8 b, hipemu_f32x4 c, int, int, int) {
+  float fa[8], fb[8];
+  for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+  return hipemu::mfma16(fa, fb, c);
+}
 inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
   return hipemu::mfma32<1>(&a, &b, c);
 }

@@ -150,7 +150,21 @@ def test_conv_fused_with_head_out(be, case):
     c = be.down(o3, np.float32, (B, N, nout))
     assert np.abs(c[:, off:off + H * W] - want).max() < 3 * _ulp(BF16) * max(1.0, np.abs(want).max())
     assert (c[:, :off] == 0).all() and (c[:, off + H * W:] == 0).all()
+    if cin % 32 == 0:
+        # ... and its 16 x 16 x 32 MFMA form (RD_MFMA16): every product is exact in fp32 and each accumulator adds the same 32-channel
+        # groups in the same order, so the tower activations -- and with them the outputs -- are the SAME numbers
+        assert L.raw("rd_conv3x3_mfma16_ok")(cin, 128, 1, W, 1) == 1 and L.raw("rd_conv3x3_mfma16_ok")(72, 128, 1, W, 1) == 0
+        o4 = be.empty(B * N * nout * 4)
+        wp16 = be.up(L.pack_conv3x3_m16(w, sc, dtype=BF16))
+        L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wp16), None, be.ptr(dsh), B, H, W, cin,
+               R.RD_RELU_POST | R.RD_SCALE_FOLDED | R.RD_MFMA16, be.ptr(dhp), be.ptr(dhb), be.ptr(o4), N * nout, off, nout, BF16, be.stream)
+        d = be.down(o4, np.float32, (B, N, nout))
+        assert np.abs(d[:, off:off + H * W] - want).max() < 3 * _ulp(BF16) * max(1.0, np.abs(want).max())
+        assert np.abs(d - c).max() <= 1e-6 * max(1.0, np.abs(c).max()), np.abs(d - c).max()
+        assert (d[:, :off] == 0).all() and (d[:, off + H * W:] == 0).all()
     buf = be.ptr(be.empty(1 << 16))
+    # RD_MFMA16 where the library has no such form (72 input channels): refused, not mis-launched
+    assert L.raw("rd_conv2d_bn_act_head_out")(buf, 80, 0, buf, None, buf, 1, 4, 8, 72, 4 | 8 | 16, buf, buf, buf, 100, 0, 8, BF16, be.stream) == R.RD_ESHAPE
     assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 9, BF16, be.stream) == R.RD_ESHAPE
     assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 6, buf, buf, buf, 100, 0, 8, BF16, be.stream) == R.RD_EINVAL
     assert L.raw("rd_conv2d_bn_act_head_out")(buf, 128, 0, buf, buf, buf, 1, 4, 8, 128, 4, buf, buf, buf, 100, 0, 8, F32, be.stream) == R.RD_EINVAL
@@ -570,7 +584,7 @@ def test_wnms_two_rounds_vs_oracle(be, is3d):
     assert keep2.tolist() == rk and np.array_equal(rows2.view(np.uint32), rows.view(np.uint32))
 
 
-def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0, fold=False, dt=R.RD_BF16):
+def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_cs=None, seed=0, fold=False, dt=R.RD_BF16, m16=False):
     """rd_conv3x3_bn_act_ex (bf16) vs torch fp32: conv2 of a BasicBlock with stride (1,stride), optional residual, optional fused
     1x1 projection shortcut of a second input (scales folded into both weight sets by the packers)."""
     if dt == R.RD_F16 and be.name == "emu" and not sc_cin and not fold:
@@ -603,10 +617,12 @@ def run_conv_ex(be, B, H, W, cin, cout, stride, sc_cin=None, residual=False, sc_
         flags |= R.RD_ADD
     else:
         ref = ref * sc2[None, :, None, None] + sh2[None, :, None, None]
-        wp = be.up(L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2 if fold else None, dtype=dt))
+        wp = be.up(L.pack_conv3x3_m16(w, sc2, dtype=dt) if m16 else L.pack_conv3x3_ex(w, stride, cs, fold_scale=sc2 if fold else None, dtype=dt))
         scale_ptr, shift_ptr = (None if fold else be.ptr(be.up(sc2))), be.ptr(be.up(sh2))
         if fold:
             flags |= R.RD_SCALE_FOLDED
+        if m16:
+            flags |= R.RD_MFMA16
         if residual:
             r = h16_round(rng.standard_normal((B, cout, H, Wo)).astype(np.float32), dt)
             ref = ref + r
@@ -657,6 +673,21 @@ def test_conv3x3_ex_fp16(be, case):
 @pytest.mark.parametrize("case", CONV_FOLD_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_conv3x3_ex_folded_scale(be, case):
     run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True)
+
+
+CONV_M16_CASES = [   # RD_MFMA16 (v_mfma_f32_16x16x32 form): cout 128, stride 1; plain / residual, ragged H / W, 1 / 2 / 4 chunks, XCD order
+    (2, 9, 130, 128, 128, 1, None, True), (1, 5, 70, 64, 128, 1, None, False), (1, 11, 33, 32, 128, 1, None, True),
+    (8, 9, 100, 128, 128, 1, None, False),
+]
+
+
+@pytest.mark.parametrize("be", WITH_LATE_DMA, indirect=True)
+@pytest.mark.parametrize("dt", [R.RD_BF16, F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", CONV_M16_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv3x3_ex_mfma16(be, case, dt):
+    """The 16 x 16 x 32 MFMA form of the persistent conv (RD_MFMA16 + rd_pack_conv3x3_m16_host) against torch fp32, same tolerance as the
+    32 x 32 x 16 form."""
+    run_conv_ex(be, *case, seed=sum(v or 0 for v in case[:6]), fold=True, dt=dt, m16=True)
 
 
 @pytest.mark.parametrize("be", BOTH, indirect=True)

@@ -11,7 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from rangedet_amd import lib as R  # noqa: E402
+from power_sample import PowerSampler  # noqa: E402
 
 L = R.get_lib()
 trace = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")       # the caller owns the trace buffer (the library never allocates)
@@ -38,11 +40,14 @@ for name, gen in (("random", lambda n: torch.randn(n, device="cuda")), ("post-Re
         run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
+    with PowerSampler() as ps:
+        for _ in range(200):                                      # ~60 ms under the sampler first: the power management settles in ms
+            run()
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
     buf = np.zeros(nwg * 8, dtype=np.uint64)
     assert fn(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(nwg, 8).astype(np.int64)
@@ -51,4 +56,4 @@ for name, gen in (("random", lambda n: torch.randn(n, device="cuda")), ("post-Re
     npt = int((t[0] > 0).sum())
     life = (t[:, npt - 1] - t[:, 0]) / 100.0                      # us
     print("%d->%d W%d B%d  %-18s %7.1f us/launch   shader clock %4.0f MHz (median over %d workgroups)" %
-          (cin, cout, W, B, name, e0.elapsed_time(e1) * 1e3 / 20, np.median(clk / life), nwg), flush=True)
+          (cin, cout, W, B, name, e0.elapsed_time(e1) * 1e3 / 20, np.median(clk / life), nwg), ps.summary(), flush=True)
