@@ -169,6 +169,11 @@ int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const v
  * summation order. */
 size_t rd_head_packed_bytes(void);
 int rd_pack_head_weight_host(const float* w, int nout, int cin, int dtype, void* out_host);
+/* ... of an RD_MFMA16 launch of rd_conv2d_bn_act_head_out (flags carry RD_MFMA16, w_packed from rd_pack_conv3x3_m16_host): head_w_packed must be
+ * THIS image (rd_head_m16_packed_bytes() = 8 KB: 16-row fragments in the order the conv's epilogue holds the channels) -- the output conv
+ * then reads the rounded tower activations straight from the registers */
+size_t rd_head_m16_packed_bytes(void);
+int rd_pack_head_weight_m16_host(const float* w, int nout, int cin, int dtype, void* out_host);
 int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
                               const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
                               const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, int dtype,

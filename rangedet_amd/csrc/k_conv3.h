@@ -174,6 +174,22 @@ inline void pack_head_frag(const float* w, int nout, int cin, void* out, int dt 
         }
 }
 
+// ... for the M16 form of the kernel (16 x 16 x 32 MFMAs, 16 output rows: nout <= 8 needs no more): [hi | lo][pair p 0..3][64 lanes][8],
+// lane (mm, q) of fragment p holds w[mm][32*p + 8*q + j] -- the 8 channels lane quad q of the conv's epilogue holds for fragment pair p of
+// its pixel, in order, so the rounded accumulators ARE the B operand (no trip through LDS): 2 x 4 KB
+inline void pack_head_frag16(const float* w, int nout, int cin, void* out, int dt = RD_BF16) {
+  bf16_t* o = (bf16_t*)out;
+  for (int part = 0; part < 2; ++part)
+    for (int p = 0; p < 4; ++p)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int mm = lane & 15, c = 32 * p + 8 * (lane >> 4) + j;
+          const float v = (mm < nout && c < cin) ? w[(size_t)mm * cin + c] : 0.f;
+          const bf16_t h = h16_from_f32(dt, v);
+          *o++ = part == 0 ? h : h16_from_f32(dt, v - h16_to_f32(dt, h));
+        }
+}
+
 // packed 1x1 projection-shortcut weights of the SC variant: [ks][Cout/32][64 lanes][8 bf16], lane (mm, hi) of fragment
 // (ks, cb) holds scale[co] * w[co = 32*cb + conv_row_perm(mm)][ci = 16*ks + 8*hi + j]  (w: (cout, cin) row-major).
 inline size_t sc_frag_bytes(int cin, int cout) { return (size_t)((cin + 15) / 16) * (cout / 32) * 1024; }
@@ -828,10 +844,14 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       asm volatile("" : "+v"(z0));
       int oq = lane >> 4;
       asm volatile("" : "+v"(oq));
+      // (the two shift words through opaque copies as well: as loop invariants hipcc keeps an operand TUPLE across the MFMA phase, spills it
+      //  and reloads it here -- a vector-memory load whose wait drains the DMA queue at every tile start; seen in the HEAD form)
+      unsigned bq2[2] = {bzw16[0], bzw16[1]};
+      asm volatile("" : "+v"(bq2[0]), "+v"(bq2[1]));
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb) {
         unsigned ob[4] = {oq == (cb & 3) ? H16<DT>::ONE * 0x10001u : z0, z0, z0, z0};
-        unsigned ab[4] = {bzw16[cb >> 2], z0, z0, z0};
+        unsigned ab[4] = {bq2[cb >> 2], z0, z0, z0};
         s16x8 ones, bz;
         memcpy(&ones, ob, 16);
         memcpy(&bz, ab, 16);
@@ -917,6 +937,10 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
     // opaque copies of the lane coordinates: without them every per-lane epilogue address is hoisted out of the tile loop
     // and kept (spilled) across the whole MFMA phase
     int em = m, ehi = hi, el = lane;
+    if constexpr (M16) {   // (m and hi are not otherwise live in this form: derive them from the lane id instead of carrying two registers)
+      asm volatile("" : "+v"(el));
+      em = el & 31; ehi = el >> 5;
+    } else
     asm volatile("" : "+v"(em), "+v"(ehi), "+v"(el));
     // The transpose scratch of a wave is a quarter of the free halo buffer: 10 KB (FPW 4) or 6 KB (FPW 2).  A fragment's 32
     // pixels x CW channels x 2 B must fit: all COUT channels in one pass, or (cout 128 on the 4-row tile) two passes of 64.
@@ -1149,25 +1173,28 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
       if (do_add) res_load(0, rv[0]);
 #pragma unroll
       for (int i = 0; i < FPW; ++i) {
-        f32x16 h0, h1;                       // HEAD: the output conv's accumulators (weights hi / lo), summed over the passes
+        // HEAD: the 1x1 output conv as 16 x 16 x 32 MFMAs (nout <= 8 rows of 16) whose B operand is the slot this lane has just rounded --
+        // lane (n, q) holds the 8 channels 32*p + 8*q .. of pixel 16*half + n, which is lane (n, q)'s share of the k-step of pair p
+        // (pack_head_frag16) -- so the 128-channel result goes neither to HBM nor through LDS.  Accumulators [pixel half][weights lo / hi].
+        f32x4 hh[HEAD ? 2 : 1][HEAD ? 2 : 1];
         if constexpr (HEAD) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) hh[hf][part] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int jp = 0; jp < NPASS; ++jp) {
           const int t = NPASS * i + jp;
           if (do_add && t + 1 < NPASS * FPW) res_load(t + 1, rv[(t + 1) & 1]);
-          // HEAD: this pass's weight fragments (hi and lo) from L2, requested before the conversion work (as in the 32 x 32 x 16 form:
-          // the output conv itself stays a 32 x 32 x 16 MFMA on the pixel-major scratch image, whatever shape produced it)
-          constexpr int KSP = 8 / NPASS;
-          s16x8 hwq[HEAD ? 2 : 1][HEAD ? KSP : 1];
+          // HEAD: this pass's weight fragments (hi and lo of pairs 2*jp, 2*jp + 1: L2 resident), requested before the conversion work
+          s16x8 hwq[HEAD ? 2 : 1][HEAD ? JW : 1];
           if constexpr (HEAD) {
 #pragma unroll
             for (int part = 0; part < 2; ++part)
 #pragma unroll
-              for (int ks = 0; ks < KSP; ++ks)
-                hwq[part][ks] = *(const s16x8*)(e_hw + part * 8192 + (jp * KSP + ks) * 1024 + el * 16);
+              for (int pp = 0; pp < JW; ++pp)
+                hwq[part][pp] = *(const s16x8*)(e_hw + part * 4096 + (jp * JW + pp) * 1024 + el * 16);
           }
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
@@ -1186,31 +1213,21 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
                 if (relu_i16) p2 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
                 pk[w2] = p2;
               }
-              const int px = 16 * hf + en;
-              *(Slot16*)(scr + px * ROWB + (((4 * pp + eq) ^ (px & (SPR - 1))) << 4)) = Slot16{pk[0], pk[1], pk[2], pk[3]};
-            }
-          C3_FENCE();
-          __builtin_amdgcn_wave_barrier();
-          if constexpr (HEAD) {
-#pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) {
-              const s16x8 bq = *(const s16x8*)(scr + em * ROWB + (((2 * ks + ehi) ^ (em & (SPR - 1))) << 4));
-              h0 = H16<DT>::mfma(hwq[1][ks], bq, h0);
-              h1 = H16<DT>::mfma(hwq[0][ks], bq, h1);
-            }
-            const int ows = ct * C3_TW + em, ohs = oh0 + i;
-            if (jp == NPASS - 1 && ows < a.W && ohs < a.H) {
-              float* o = e_ho + (size_t)b * e_ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * e_hn + 4 * ehi;
-              if (e_hn == 8 && !((size_t)o & 15)) {
-                const f32x4 bv = *(const f32x4*)(e_hb + 4 * ehi);
-                *(f32x4*)o = f32x4{(h0[0] + h1[0]) + bv[0], (h0[1] + h1[1]) + bv[1], (h0[2] + h1[2]) + bv[2], (h0[3] + h1[3]) + bv[3]};
+              if constexpr (HEAD) {
+                s16x8 bq;
+                memcpy(&bq, pk, 16);
+                hh[hf][0] = H16<DT>::mfma16(hwq[1][pp], bq, hh[hf][0]);
+                hh[hf][1] = H16<DT>::mfma16(hwq[0][pp], bq, hh[hf][1]);
               } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  if (4 * ehi + r < e_hn) o[r] = (h0[r] + h1[r]) + e_hb[4 * ehi + r];
+                // (the lane's 16-byte slot straight to global memory instead -- 64-byte runs per pixel, no LDS round trip -- measured slower:
+                //  W 2656 312 -> 331 us, profiles/r06l_conv16_direct_store_ab.txt)
+                const int px = 16 * hf + en;
+                *(Slot16*)(scr + px * ROWB + (((4 * pp + eq) ^ (px & (SPR - 1))) << 4)) = Slot16{pk[0], pk[1], pk[2], pk[3]};
               }
             }
-          } else {
+          C3_FENCE();
+          if constexpr (!HEAD) {
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int it = 0; it < 32 / RPI; ++it) {
             const int pr = it * RPI + el / SPR, sl = el % SPR;
@@ -1219,8 +1236,27 @@ __global__ __launch_bounds__(256, (FPW == 2 ? 2 : 1)) void conv3x3_stream_kernel
             if (ows < a.W && oh0 + i < a.H)
               __builtin_nontemporal_store(v, (Slot16*)(yrow0 + (size_t)i * a.Wo * a.y_cs + (size_t)ows * a.y_cs + jp * CW + sl * 8));
           }
-          }
           __builtin_amdgcn_wave_barrier();
+          C3_FENCE();
+          }
+        }
+        if constexpr (HEAD) {   // out[o][px]: lane (n, q) holds outputs 4*q .. 4*q + 3 (q < 2: nout <= 8) of pixel 16*half + n
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int ows = ct * C3_TW + 16 * hf + en, ohs = oh0 + i;
+            if (eq < 2 && ows < a.W && ohs < a.H) {
+              float* o = e_ho + (size_t)b * e_ho_bs + (a.ho_off + (size_t)ohs * a.W + ows) * e_hn + 4 * eq;
+              if (e_hn == 8 && !((size_t)o & 15)) {   // (the box regression head: one 16-byte store per lane)
+                const f32x4 bv = *(const f32x4*)(e_hb + 4 * eq);
+                *(f32x4*)o = f32x4{(hh[hf][0][0] + hh[hf][1][0]) + bv[0], (hh[hf][0][1] + hh[hf][1][1]) + bv[1],
+                                   (hh[hf][0][2] + hh[hf][1][2]) + bv[2], (hh[hf][0][3] + hh[hf][1][3]) + bv[3]};
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (4 * eq + r < e_hn) o[r] = (hh[hf][0][r] + hh[hf][1][r]) + e_hb[4 * eq + r];
+              }
+            }
+          }
           C3_FENCE();
         }
       }
@@ -1449,7 +1485,8 @@ inline int launch_conv3_dt(const void* x, int x_cs, int x_co, const void* w, con
 #undef C3_DBG128
 #endif
 #ifdef RD_CONV3_DEV_M16_ONLY   // tools/micro/conv16_dev.hip: only the plain cout-128 form on the 8 x 32 tiles, in its two MFMA shapes (a one-minute build)
-  RD_REQUIRE(wd && fold && !head && !g1 && !ph && !s2 && sw == 1 && ts == 0 && cout == 128 && DT == RD_BF16, RD_ESHAPE, "conv16_dev: plain bf16 cout-128 form only");
+  RD_REQUIRE(wd && fold && !sc && !g1 && !ph && !s2 && sw == 1 && ts == 0 && cout == 128 && DT == RD_BF16 && (!headfuse || body == C3_BODY_M16), RD_ESHAPE, "conv16_dev: plain bf16 cout-128 form only");
+  if (body == C3_BODY_M16 && headfuse) return c3_go<4, 0, true, false, true, 2, 1, 2, RD_BF16, true, false, 0, true>(grid, st, a);
   if (body == C3_BODY_M16) return c3_go<4, 0, false, false, true, 2, 1, 2, RD_BF16, true, false, 0, true>(grid, st, a);
   return c3_go<4, 0, false, false, true, 2, 1, 2, RD_BF16, true>(grid, st, a);
 #else

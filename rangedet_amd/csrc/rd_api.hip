@@ -399,6 +399,15 @@ int rd_pack_head_weight_host(const float* w, int nout, int cin, int dtype, void*
   pack_head_frag(w, nout, cin, out_host, dtype);
   return RD_OK;
 }
+// ... for RD_MFMA16 launches (k_conv3.h pack_head_frag16): 8 KB
+size_t rd_head_m16_packed_bytes(void) { return 8192; }
+int rd_pack_head_weight_m16_host(const float* w, int nout, int cin, int dtype, void* out_host) {
+  RD_REQUIRE(w && out_host, RD_EINVAL, "pack_head_weight_m16: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_head_weight_m16: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE(nout >= 1 && nout <= 8 && cin >= 1 && cin <= 128, RD_ESHAPE, "pack_head_weight_m16: nout %d (1..8), cin %d (1..128)", nout, cin);
+  pack_head_frag16(w, nout, cin, out_host, dtype);
+  return RD_OK;
+}
 int rd_conv2d_bn_act_head_out(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* scale,
                               const float* shift, int B, int H, int W, int cin, int flags, const void* head_w_packed,
                               const float* head_bias, float* out, long out_batch_stride, long n_off, int nout, int dtype,

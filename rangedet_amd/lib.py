@@ -79,7 +79,9 @@ SIGNATURES = {
     "rd_block64_bn_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
+    "rd_head_m16_packed_bytes": (c_size_t, []),
     "rd_pack_head_weight_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rd_pack_head_weight_m16_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "rd_conv2d_bn_act_head_out": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p]),
     "rd_conv3x3_bn_act_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] * 2 +
@@ -257,10 +259,11 @@ class Lib:
         self.call("rd_pack_deconv_phase_pair_host", a.ctypes.data, b.ctypes.data, cin, dtype, out.ctypes.data)
         return out
 
-    def pack_head_weight(self, w, dtype=RD_BF16):
+    def pack_head_weight(self, w, dtype=RD_BF16, m16=False):
+        """m16: the image an RD_MFMA16 launch of rd_conv2d_bn_act_head_out reads"""
         w = np.ascontiguousarray(w, dtype=np.float32)
-        out = np.zeros(self.cdll.rd_head_packed_bytes(), dtype=np.uint8)
-        self.call("rd_pack_head_weight_host", w.ctypes.data, w.shape[0], w.shape[1], dtype, out.ctypes.data)
+        out = np.zeros(self.cdll.rd_head_m16_packed_bytes() if m16 else self.cdll.rd_head_packed_bytes(), dtype=np.uint8)
+        self.call("rd_pack_head_weight_m16_host" if m16 else "rd_pack_head_weight_host", w.ctypes.data, w.shape[0], w.shape[1], dtype, out.ctypes.data)
         return out
 
     def pack_meta(self, w0, b0, w1, b1, s1, t1, agg, s2, t2, dtype):

@@ -268,7 +268,7 @@ class Executor:
             h = st["head"]
             r0, r1 = h["rows"]
             hw = np.asarray(P[h["name"] + "_weight"], np.float32).reshape(-1, st["cout"])[r0:r1]
-            b["head_w"] = A.upload(L.pack_head_weight(hw, dtype=dt))
+            b["head_w"] = A.upload(L.pack_head_weight(hw, dtype=dt, m16=bool(b.get("flags", 0) & rdlib.RD_MFMA16)))
             b["head_bias"] = A.upload(np.asarray(P[h["name"] + "_bias"], np.float32)[r0:r1])
         elif k == "head_out":
             r0, r1 = st["rows"]

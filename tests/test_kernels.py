@@ -152,15 +152,16 @@ def test_conv_fused_with_head_out(be, case):
     assert (c[:, :off] == 0).all() and (c[:, off + H * W:] == 0).all()
     if cin % 32 == 0:
         # ... and its 16 x 16 x 32 MFMA form (RD_MFMA16): every product is exact in fp32 and each accumulator adds the same 32-channel
-        # groups in the same order, so the tower activations -- and with them the outputs -- are the SAME numbers
+        # groups in the same order, so the tower activations are the SAME numbers; the output conv sums them in another order
         assert L.raw("rd_conv3x3_mfma16_ok")(cin, 128, 1, W, 1) == 1 and L.raw("rd_conv3x3_mfma16_ok")(72, 128, 1, W, 1) == 0
         o4 = be.empty(B * N * nout * 4)
         wp16 = be.up(L.pack_conv3x3_m16(w, sc, dtype=BF16))
+        dhp16 = be.up(L.pack_head_weight(hw, dtype=BF16, m16=True))      # (its own head-weight image: 16-row fragments, pack_head_frag16)
         L.call("rd_conv2d_bn_act_head_out", be.ptr(xin), cs, 0, be.ptr(wp16), None, be.ptr(dsh), B, H, W, cin,
-               R.RD_RELU_POST | R.RD_SCALE_FOLDED | R.RD_MFMA16, be.ptr(dhp), be.ptr(dhb), be.ptr(o4), N * nout, off, nout, BF16, be.stream)
+               R.RD_RELU_POST | R.RD_SCALE_FOLDED | R.RD_MFMA16, be.ptr(dhp16), be.ptr(dhb), be.ptr(o4), N * nout, off, nout, BF16, be.stream)
         d = be.down(o4, np.float32, (B, N, nout))
         assert np.abs(d[:, off:off + H * W] - want).max() < 3 * _ulp(BF16) * max(1.0, np.abs(want).max())
-        assert np.abs(d - c).max() <= 1e-6 * max(1.0, np.abs(c).max()), np.abs(d - c).max()
+        assert np.abs(d - c).max() <= 2e-5 * max(1.0, np.abs(c).max()), np.abs(d - c).max()
         assert (d[:, :off] == 0).all() and (d[:, off + H * W:] == 0).all()
     buf = be.ptr(be.empty(1 << 16))
     # RD_MFMA16 where the library has no such form (72 input channels): refused, not mis-launched

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-L = ctypes.CDLL(os.path.join(HERE, "libconv16_dev.so"))
+L = ctypes.CDLL(os.path.join(HERE, os.environ.get("CONV16_LIB", "libconv16_dev.so")))   # (CONV16_LIB: another build of the harness, for A/B runs)
 L.rdm_conv3_packed_bytes.restype = ctypes.c_size_t
 L.rdm_last_error.restype = ctypes.c_char_p
 vp, ci = ctypes.c_void_p, ctypes.c_int
@@ -70,3 +70,48 @@ for W, cin, add in ((2656, 128, 0), (2656, 128, 1), (1328, 128, 0), (1328, 64, 0
     fl = 2.0 * B * H * W * cin * cout * 9
     print("W %4d cin %3d %s  32x32x16 %s us (%.0f TFLOP/s)   16x16x32 %s us (%.0f TFLOP/s)   %s" % (
         W, cin, "+res" if add else "    ", "/".join("%.1f" % v for v in t[0]), fl / min(t[0]) / 1e6, "/".join("%.1f" % v for v in t[1]), fl / min(t[1]) / 1e6, msg), flush=True)
+
+# ---- the M16 form with the fused 1x1 output conv (16-row MFMAs on the registers the epilogue has just rounded) ------------------------------
+L.rdm_pack_head16.argtypes = [vp, ci, ci, ci, vp]
+L.rdm_conv3_head.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+for W, nout in ((2656, 8), (2656, 1), (1328, 8), (664, 8)):
+    cin = 128
+    g = torch.Generator(device="cuda").manual_seed(W + nout)
+    x = torch.relu(torch.randn(B, H, W, cin, device="cuda", generator=g)).to(torch.bfloat16)
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    fs = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+    hw = (rng.standard_normal((nout, 128)) / np.sqrt(128)).astype(np.float32)
+    hb = torch.from_numpy(rng.standard_normal(8).astype(np.float32)).cuda()
+    hp = np.zeros(8192, np.uint8)
+    assert L.rdm_pack_head16(hw.ctypes.data, nout, 128, 1, hp.ctypes.data) == 0
+    hp = torch.from_numpy(hp).cuda()
+    wp16 = pack(w, fs, 1)
+    out = torch.zeros(B, H * W, nout, device="cuda")
+    y16 = torch.empty(B, H, W, cout, device="cuda", dtype=torch.bfloat16)
+
+    def run_h():
+        rc = L.rdm_conv3_head(x.data_ptr(), cin, wp16.data_ptr(), sh.data_ptr(), hp.data_ptr(), hb.data_ptr(), out.data_ptr(), nout, B, H, W, cin, 1, st)
+        assert rc == 0, L.rdm_last_error()
+
+    def run_p():
+        assert L.rdm_conv3(x.data_ptr(), cin, wp16.data_ptr(), sh.data_ptr(), None, y16.data_ptr(), B, H, W, cin, cout, RELU, 1, 1, st) == 0
+    run_h(), run_p()
+    torch.cuda.synchronize()
+    want = y16[:1].float().reshape(1, H * W, cout) @ torch.from_numpy(hw).cuda().T + hb[:nout]
+    err = (out[:1] - want).abs().max().item()
+    t = [[], []]
+    for rep in range(3):
+        for m, fn in enumerate((run_p, run_h)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t[m].append(e0.elapsed_time(e1) * 1e3 / reps)
+    print("W %4d nout %d: plain 16x16x32 conv %s us   + fused output conv %s us   max |out - head(conv)| %.2e (spread %.2f)" % (
+        W, nout, "/".join("%.1f" % v for v in t[0]), "/".join("%.1f" % v for v in t[1]), err, want.std().item()), flush=True)

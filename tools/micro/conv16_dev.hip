@@ -17,5 +17,15 @@ int rdm_conv3(const void* x, int x_cs, const void* w, const float* shift, const 
   return rd::launch_conv3(x, x_cs, 0, w, nullptr, shift, res, cout, 0, y, cout, 0, B, H, W, cin, cout, flags | RD_SCALE_FOLDED, 1, (hipStream_t)stream, 0,
                           nullptr, dtype, nullptr, nullptr, nullptr, m16 ? rd::C3_BODY_M16 : 0);
 }
+// the M16 form with the fused 1x1 output conv (head weights: pack_head_frag16)
+int rdm_pack_head16(const float* w, int nout, int cin, int dtype, void* out) { rd::pack_head_frag16(w, nout, cin, out, dtype); return 0; }
+int rdm_conv3_head(const void* x, int x_cs, const void* w, const float* shift, const void* hw, const float* hb, float* out, int nout, int B, int H,
+                   int W, int cin, int dtype, void* stream) {
+  rd::Conv3Args h;
+  memset(&h, 0, sizeof(h));
+  h.hw = (const unsigned char*)hw; h.hb = hb; h.ho = out; h.ho_bs = (long)H * W * nout; h.ho_off = 0; h.hn = nout;
+  return rd::launch_conv3(x, x_cs, 0, w, nullptr, shift, nullptr, 0, 0, nullptr, 128, 0, B, H, W, cin, 128, RD_RELU_POST | RD_SCALE_FOLDED, 1,
+                          (hipStream_t)stream, 0, &h, dtype, nullptr, nullptr, nullptr, rd::C3_BODY_M16);
+}
 const char* rdm_last_error(void) { return rd::err_buf(); }
 }

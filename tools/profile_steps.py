@@ -68,9 +68,12 @@ for i, st in enumerate(pipe.plan.steps):
         desc = "meta unit"
     else:
         desc = st.get("name", "")
+    if st.get("m16"):
+        desc += " [16x16x32]"
     rows.append((us, k, desc, fl))
     # tiles per resident workgroup slot of the persistent 3x3 kernel (the rule of launch_conv3, k_conv3.h, restated for this
-    # report: 8 x 32 tiles (RD_CONV_WIDE=0: 8 x 30) with two workgroups per CU, except a fused output conv wider than 1400 columns: 8 x 62, one per CU;
+    # report: 8 x 32 tiles (RD_CONV_WIDE=0: 8 x 30) with two workgroups per CU, except a fused output conv wider than 1400 columns that is not
+    # in the 16 x 16 x 32 form (step key "m16"; round 6): 8 x 62, one per CU;
     # a stride-2 conv runs on the pixel-pair view = its output grid, a transposed conv phase on its input grid)
     tps = ""
     if dt in rdlib.H16 and k == "block":
@@ -84,7 +87,7 @@ for i, st in enumerate(pipe.plan.steps):
     elif dt in rdlib.H16 and k in ("conv", "deconv") and st["k"][0] == 3:
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         Wt = st["x"].W if k == "deconv" else st["out"].W
-        wide_head = bool(st.get("head")) and Wt > 1400
+        wide_head = bool(st.get("head")) and Wt > 1400 and not st.get("m16")
         tw, slots = (62, cus) if wide_head else (32 if os.environ.get("RD_CONV_WIDE", "1") != "0" else 30, 2 * cus)
         ntiles = -(-Wt // tw) * -(-st["out"].H // 8) * B
         tps = "  %5d tiles / %d slots = %5.2f" % (ntiles, slots, ntiles / slots) + (" per phase" if k == "deconv" else "")
