@@ -160,6 +160,14 @@ int rd_pack_block64_host(const float* w1_oihw_host, const float* fold_scale1_hos
                          const float* fold_scale2_host, int cin, int dtype, void* packed_host);
 int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const void* w_packed, const float* shift1, const float* shift2,
                       const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream);
+/* The same block (64 input channels) issuing v_mfma_f32_16x16x32 instead of 32x32x16 (round 6; see RD_MFMA16): w_packed from
+ * rd_pack_block64_m16_host (rd_block64_packed_bytes(64) bytes), sc_w_packed (projection shortcut 64 -> 64, or NULL) from
+ * rd_pack_conv1x1_sc_m16_host (rd_conv1x1_sc_packed_bytes(64, 64) bytes); results identical to rd_block64_bn_act */
+int rd_pack_block64_m16_host(const float* w1_oihw_host, const float* fold_scale1_host, const float* w2_oihw_host,
+                             const float* fold_scale2_host, int dtype, void* packed_host);
+int rd_pack_conv1x1_sc_m16_host(const float* w_oi_host, const float* fold_scale_host, int dtype, void* packed_host);
+int rd_block64_m16_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* shift1, const float* shift2,
+                          const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream);
 
 /* Last conv of a head tower (3x3, cout 128, BN + ReLU, RD_BF16 or RD_F16) FUSED with the tower's 1x1 output conv (head/builder.py:221-261:
  * rpn_{cls,reg}_conv_3 + BN + ReLU, then rpn_cls_logit / rpn_reg_delta with bias): the 128-channel result is consumed in

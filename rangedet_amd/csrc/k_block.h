@@ -71,9 +71,15 @@ constexpr int bk_younger(bool first, int g) {
   return (bk_fetches(first, g) && bk_ord(first, g) == 7 && n > cap) ? cap : n;
 }
 
-template <int DT, bool SC, bool FIRST = false>
+// M16 (round 6): the MFMAs as v_mfma_f32_16x16x32 (k_conv3.h M16 says why: the part sustains more of them under its power cap; this kernel
+// runs at the cap too, tools/clock_probe.py).  A step is ONE 32-channel k-step: conv1's three flat 32-pixel fragments are 6 half-fragments
+// (16 flat positions x 32 channels: lane (n, q) reads slot q), conv2's two rows 4; the 4-KB slab is 4 weight fragments of 16 channels x 32
+// (pack_taps_frag16): block 0 = fragments 0, 1, block 1 = 2, 3, pixel-major, half-fragments single-buffered (re-read for the next step right
+// after their last MFMA).  Same sums in the same order per accumulator: results bit-identical to the 32 x 32 x 16 form and to the two launches.
+template <int DT, bool SC, bool FIRST = false, bool M16 = false>
 __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   static_assert(!FIRST || SC, "the first block changes the channel count: projection shortcut");
+  static_assert(!(FIRST && M16), "the first block (five two-tap steps on one 16-channel slot) stays in the 32 x 32 x 16 form");
   HIP_DYNAMIC_SHARED(unsigned char, smem);
   constexpr int R = BK_R, SLAB = BK_SLAB, RING = 2 * BK_BUF, NCT = 2;
   constexpr int ROWB2 = BK_TP * 64;        // bytes of one row of the intermediate image
@@ -89,6 +95,16 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     const bf16_t l1 = H16<DT>::from_f32(t1 - H16<DT>::to_f32(h1)), l2 = H16<DT>::from_f32(t2 - H16<DT>::to_f32(h2));
     bz1[j] = hi ? 0u : ((unsigned)h1 | ((unsigned)l1 << 16));
     bz2[j] = hi ? 0u : ((unsigned)h2 | ((unsigned)l2 << 16));
+  }
+
+  // M16: the shift of MFMA row lane & 15 of 16-channel fragment cb = lane quad (4 fragments: one register per conv)
+  unsigned bz1m = 0u, bz2m = 0u;
+  if constexpr (M16) {
+    const float t1 = a.shift1[conv_row16(lane >> 4, lane & 15)], t2 = a.shift2[conv_row16(lane >> 4, lane & 15)];
+    const bf16_t h1 = H16<DT>::from_f32(t1), h2 = H16<DT>::from_f32(t2);
+    const bf16_t l1 = H16<DT>::from_f32(t1 - H16<DT>::to_f32(h1)), l2 = H16<DT>::from_f32(t2 - H16<DT>::to_f32(h2));
+    bz1m = (unsigned)h1 | ((unsigned)l1 << 16);
+    bz2m = (unsigned)h2 | ((unsigned)l2 << 16);
   }
 
   const int G = gridDim.x, wg = blockIdx.x;
@@ -191,10 +207,27 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
     const int c = d + m;
     a2[d] = c * 64 + (((hi ^ (c >> 2)) & 3) << 4) + wave * 2 * ROWB2;
   }
+  if constexpr (M16) {   // lane (n, q): slot q (all 32 channels of the chunk in one k-step) of flat position / pixel n; +16 positions = +1024 B
+    const int n16 = lane & 15, q16 = lane >> 4;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int P = 96 * wave + n16 + BK_XP * dh + dw;
+        a1[dh][dw] = P * 64 + (((q16 ^ (P >> 2)) & 3) << 4);
+      }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int c = d + n16;
+      a2[d] = c * 64 + (((q16 ^ (c >> 2)) & 3) << 4) + wave * 2 * ROWB2;
+    }
+  }
   const int boff = RING + lane * 16;
 
-  f32x16 acc[3][NCT];
+  f32x16 acc[M16 ? 1 : 3][M16 ? 1 : NCT];
+  f32x4 acc6[M16 ? 6 : 1][M16 ? 4 : 1];      // M16: [pixel half-fragment][16-channel fragment]
   s16x8 fa[2][3], fb[2][NCT];
+  s16x8 fa16[6];
 #define BK_FENCE() __builtin_amdgcn_sched_barrier(0)
   // fragment read k of a k-step with F pixel fragments: fa[0], fb[0], fb[1], fa[1], (fa[2]); FS = byte stride between pixel fragments
 #define BK_RD(F, FS, BUF, K, AADDR, BADDR, KS)                                                              \
@@ -274,6 +307,61 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
           (a2[(S_) % 3] + ((S_) / 3) * ROWB2 + (C_) * BK_BUF) ^ 32,                                                \
           ((S_) == 8 ? ((C_) == 1 ? a1[0][0] : a2[0] + BK_BUF) : a2[((S_) + 1) % 3] + ((((S_) + 1) % 9) / 3) * ROWB2 + (C_) * BK_BUF))
 
+  // ---- M16 forms of the above ---------------------------------------------------------------------------------------------------------
+  // half-fragment HX of the step at AADDR: 32-pixel fragment HX >> 1 (stride FS), half HX & 1; weight fragment C of the slab half at BADDR;
+  // MFMA N of block BK: half-fragment N >> 1 against weight fragment 2 * BK + (N & 1)
+#define BK_RDW16(BUF, C, BADDR) { fb[BUF][C] = *(const s16x8*)(smem + (BADDR) + (C) * 1024); BK_FENCE(); }
+#define BK_RDP16(HX, AADDR, FS) { fa16[HX] = *(const s16x8*)(smem + (AADDR) + ((HX) >> 1) * (FS) + ((HX) & 1) * 1024); BK_FENCE(); }
+#define BK_MM16(BK, N)                                                                                             \
+  {                                                                                                                \
+    acc6[(N) >> 1][2 * (BK) + ((N) & 1)] = H16<DT>::mfma16(fb[BK][(N) & 1], fa16[(N) >> 1], acc6[(N) >> 1][2 * (BK) + ((N) & 1)]); \
+    BK_FENCE();                                                                                                    \
+  }
+  // One step with F half-fragments (6: conv1, 4: conv2); the next step has NF_ (0: the pipeline is cut) at fragment stride NFS_ from ANEXT_.
+  // Half-fragment hx is re-read right after MFMA 2 hx + 1 of block 1, its last use; half-fragments the next step has more (conv2 -> the next
+  // tile's conv1) go into registers this step does not use.  LG_ = the next step's reads issued before the barrier.
+#define BK_STEP16(F, G_, HB_, NF_, NFS_, ANEXT_)                                                                   \
+  {                                                                                                                \
+    constexpr int NM_ = 2 * (F);                                                                                   \
+    constexpr int NX_ = (NF_) > (F) ? (NF_) - (F) : 0;                                                             \
+    constexpr int LG_ = (NF_) ? 2 + NX_ + ((NF_) < (F) / 2 ? (NF_) : (F) / 2) : 0;                                 \
+    constexpr int NH_ = bk_pieces(FIRST, G_), NP_ = 1 + NH_, HF_ = bk_first_u(bk_ord(FIRST, G_)), YG_ = bk_younger(FIRST, G_); \
+    const int bcur_ = boff + rslot * SLAB;                                                                         \
+    const int rnext_ = rslot + 1 == R ? 0 : rslot + 1;                                                             \
+    const int anext_ = (ANEXT_);                                                                                   \
+    const int bnext_ = boff + rnext_ * SLAB;                                                                       \
+    BK_FENCE();                                                                                                    \
+    _Pragma("unroll") for (int n = 0; n < NM_; ++n) {                                                              \
+      BK_MM16(0, n)                                                                                                \
+      if (n < 2) BK_RDW16(1, n, bcur_ + 2048)                                                                      \
+    }                                                                                                              \
+    _Pragma("unroll") for (int n = 0; n < NM_ / 2; ++n) {                                                          \
+      BK_MM16(1, n)                                                                                                \
+      if ((NF_) && n < 2) BK_RDW16(0, n, bnext_)                                                                   \
+      if (n < NX_) BK_RDP16((F) + n, anext_, NFS_)                                                                 \
+      if ((n & 1) && (n >> 1) < (NF_)) BK_RDP16(n >> 1, anext_, NFS_)                                              \
+    }                                                                                                              \
+    BK_SYNC(YG_, LG_)                                                                                              \
+    if (NH_ > 0 && bk_ord(FIRST, G_) == 0) halo_begin();                                                           \
+    _Pragma("unroll") for (int n = NM_ / 2; n < NM_; ++n) {                                                        \
+      BK_MM16(1, n)                                                                                                \
+      _Pragma("unroll") for (int p = 0; p < NP_; ++p)                                                              \
+        if (p * (NM_ / 2) / NP_ == n - NM_ / 2) {                                                                  \
+          if (p == 0) slab_piece(); else halo_piece(HB_, HF_ + p - 1);                                             \
+          BK_FENCE();                                                                                              \
+        }                                                                                                          \
+      if ((n & 1) && (n >> 1) < (NF_) && (n >> 1) < (F)) BK_RDP16(n >> 1, anext_, NFS_)                            \
+    }                                                                                                              \
+    slab_advance();                                                                                                \
+    rslot = rnext_;                                                                                                \
+  }
+#define BK_C1M(U_, S_)                                                                                             \
+  BK_STEP16(6, 9 * (U_) + (S_), BK_BUF, (((U_) == 1 && (S_) == 8) ? 0 : 6), 2048,                                  \
+            ((S_) == 8 ? a1[0][0] + BK_BUF : a1[(((S_) + 1) % 9) / 3][((S_) + 1) % 3] + (U_) * BK_BUF))
+#define BK_C2M(C_, S_)                                                                                             \
+  BK_STEP16(4, 18 + 9 * (C_) + (S_), 0, (((C_) == 1 && (S_) == 8) ? 6 : 4), (((C_) == 1 && (S_) == 8) ? 2048 : ROWB2), \
+            ((S_) == 8 ? ((C_) == 1 ? a1[0][0] : a2[0] + BK_BUF) : a2[((S_) + 1) % 3] + ((((S_) + 1) % 9) / 3) * ROWB2 + (C_) * BK_BUF))
+
   // ---- prologue: x chunk 0 of the first tile, a full ring ----------------------------------------------------------------------------
   halo_begin();
 #pragma unroll
@@ -282,10 +370,167 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
   for (int s0 = 0; s0 < R; ++s0) { slab_piece(); slab_advance(); }
   BK_SYNC(0, 0)
   int rslot = 0;
+  if constexpr (M16) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) BK_RDW16(0, kk, boff + rslot * SLAB)
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) BK_RDP16(kk, a1[0][0], 2048)
+  } else {
 #pragma unroll
   for (int kk = 0; kk < 3 + NCT; ++kk) BK_RD(3, 2048, 0, kk, a1[0][0], boff + rslot * SLAB, 0)      // first fragments of the first tile
+  }
 
   for (int k = 0; k < ntl; ++k) {
+    if constexpr (M16) {
+      // ================= the tile in the 16 x 16 x 32 form =========================================================================
+      unsigned z0 = 0u, b1 = bz1m, b2 = bz2m;
+      int oq = lane >> 4;
+      asm volatile("" : "+v"(z0), "+v"(b1), "+v"(b2), "+v"(oq));      // (opaque: no operand tuple may be loop invariant, k_conv3.h)
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      // accumulators of NH half-fragments from the shift: one rank-1 MFMA per 16-channel fragment (A = {hi, lo} in the two k of lane quad cb,
+      // B = ones there), the same for every pixel -> register copies for the other half-fragments
+      auto init_acc = [&](unsigned bz, int NH) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          unsigned ob[4] = {oq == cb ? H16<DT>::ONE * 0x10001u : z0, z0, z0, z0};
+          unsigned ab[4] = {bz, z0, z0, z0};
+          s16x8 ones, bzv;
+          memcpy(&ones, ob, 16);
+          memcpy(&bzv, ab, 16);
+          acc6[0][cb] = H16<DT>::mfma16(bzv, ones, f32x4{});
+          BK_FENCE();
+        }
+#pragma unroll
+        for (int h = 1; h < 6; ++h)
+          if (h < NH) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc6[h][cb] = acc6[0][cb];
+          }
+        BK_FENCE();
+      };
+      // ---- conv1 on the wave's six flat half-fragments ----------------------------------------------------------------------------------
+      init_acc(b1, 6);
+      BK_C1M(0, 0) BK_C1M(0, 1) BK_C1M(0, 2) BK_C1M(0, 3) BK_C1M(0, 4) BK_C1M(0, 5) BK_C1M(0, 6) BK_C1M(0, 7) BK_C1M(0, 8)
+      BK_C1M(1, 0) BK_C1M(1, 1) BK_C1M(1, 2) BK_C1M(1, 3) BK_C1M(1, 4) BK_C1M(1, 5) BK_C1M(1, 6) BK_C1M(1, 7) BK_C1M(1, 8)
+      // ---- t = relu(conv1 + shift1), rounded, into buf0 / buf1 in conv2's halo layout: lane (n, q) of accumulators (h, 2 j), (h, 2 j + 1)
+      // holds channels 32 j + 8 q .. + 7 of flat position J = 96 w + 16 h + n -- one 16-byte slot (slot q of chunk j)
+      const int ct = c_ct, rb = c_rb, b = c_b;
+      tile_advance(c_ct, c_rb, c_b);
+      {
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int en = el & 15, eq = el >> 4;
+#pragma unroll
+        for (int h = 0; h < 6; ++h) {
+          const int J = 96 * wave + 16 * h + en, rr = (J * 1821) >> 16, cc = J - BK_XP * rr;
+          const bool keep = cc < BK_TP && rr < 10;
+          const bool inside = (unsigned)(rb * 8 - 1 + rr) < (unsigned)a.H && (unsigned)(ct * 32 - 1 + cc) < (unsigned)a.W;
+          const int doff = (rr * BK_TP + cc) * 64 + (((eq ^ (cc >> 2)) & 3) << 4);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            BK_FENCE();
+            unsigned pk[4];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+              const f32x4 av = acc6[h][2 * j + (w2 >> 1)];
+              unsigned p2 = H16<DT>::pk(av[2 * (w2 & 1)], av[2 * (w2 & 1) + 1]);
+              p2 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p2), (s16x2){0, 0}));
+              pk[w2] = inside ? p2 : 0u;
+            }
+            if (keep) *(Slot16*)(smem + j * BK_BUF + doff) = Slot16{pk[0], pk[1], pk[2], pk[3]};
+          }
+        }
+      }
+      // ---- conv2 on the wave's two rows (four half-fragments) ---------------------------------------------------------------------------
+      init_acc(b2, 4);
+      BK_SYNC(63, 0)       // every wave's part of t is in LDS
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) BK_RDW16(0, kk, boff + rslot * SLAB)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) BK_RDP16(kk, a2[0], ROWB2)
+      BK_C2M(0, 0) BK_C2M(0, 1) BK_C2M(0, 2) BK_C2M(0, 3) BK_C2M(0, 4) BK_C2M(0, 5) BK_C2M(0, 6) BK_C2M(0, 7) BK_C2M(0, 8)
+      BK_C2M(1, 0) BK_C2M(1, 1) BK_C2M(1, 2) BK_C2M(1, 3) BK_C2M(1, 4) BK_C2M(1, 5) BK_C2M(1, 6) BK_C2M(1, 7) BK_C2M(1, 8)
+      // ---- epilogue: (+ projection shortcut on the accumulators |) + x, round, ReLU, transpose through this wave's quarter of buf1 ---------
+      {
+        const int oh0 = rb * 8 + 2 * wave;
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int en = el & 15, eq = el >> 4;
+        unsigned char* scr = smem + BK_BUF + wave * (BK_BUF / 4);
+        bf16_t* __restrict__ yrow0 = a.y + (size_t)b * a.y_bs + (size_t)oh0 * a.W * a.y_cs + a.y_co;
+        const bf16_t* __restrict__ rimg0 = a.x + (size_t)b * a.x_bs + a.x_co;
+        if constexpr (SC) {
+          // acc[px][co] += sum_ci scw[co][ci] * x[px][ci]: B = this wave's output pixels of x from global memory (lane (n, q): channels
+          // 32 ks + 8 q .. of pixel 16 half + n), A = the packed 1x1 weights (pack_sc_frag16), two 32-channel k-steps
+          const unsigned char* __restrict__ wq = a.scw + el * 16;
+          s16x8 sxq[4][2];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int ow = ct * 32 + 16 * (h & 1) + en, oh = oh0 + (h >> 1);
+            const bool live = ow < a.W && oh < a.H;
+            const bf16_t* sp = rimg0 + (live ? ((size_t)oh * a.W + ow) * a.x_cs : 0) + 8 * eq;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) sxq[h][ks] = *(const s16x8*)(sp + 32 * ks);
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const s16x8 wf = *(const s16x8*)(wq + (size_t)(ks * 4 + cb) * 1024);
+#pragma unroll
+              for (int h = 0; h < 4; ++h) acc6[h][cb] = H16<DT>::mfma16(wf, sxq[h][ks], acc6[h][cb]);
+            }
+          BK_FENCE();
+        }
+        Slot16 rv[2][2][2];                                  // [buffer][pixel half][fragment pair]
+        auto res_load = [&](int i, Slot16 (&dst)[2][2]) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int ow = ct * 32 + 16 * hf + en, oh = oh0 + i;
+            const bool live = ow < a.W && oh < a.H;
+            const bf16_t* rp = rimg0 + (live ? ((size_t)oh * a.W + (size_t)ow) * a.x_cs : 0) + 8 * eq;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) dst[hf][p2] = *(const Slot16*)(rp + 32 * p2);
+          }
+        };
+        if constexpr (!SC) res_load(0, rv[0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (!SC) { if (i + 1 < 2) res_load(i + 1, rv[(i + 1) & 1]); }
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+              BK_FENCE();
+              unsigned pk[4];
+#pragma unroll
+              for (int w2 = 0; w2 < 4; ++w2) {
+                const f32x4 av = acc6[2 * i + hf][2 * p2 + (w2 >> 1)];
+                f32x2 v = {av[2 * (w2 & 1)], av[2 * (w2 & 1) + 1]};
+                if constexpr (!SC) v += H16<DT>::unpk(rv[i & 1][hf][p2][w2]);
+                const unsigned q2 = H16<DT>::pk(v[0], v[1]);
+                pk[w2] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, q2), (s16x2){0, 0}));
+              }
+              const int px = 16 * hf + en;
+              *(Slot16*)(scr + px * 128 + (((4 * p2 + eq) ^ (px & 7)) << 4)) = Slot16{pk[0], pk[1], pk[2], pk[3]};
+            }
+          BK_FENCE();
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int pr = it * 8 + el / 8, sl = el % 8;
+            const Slot16 v = *(const Slot16*)(scr + pr * 128 + ((sl ^ (pr & 7)) << 4));
+            const int ows = ct * 32 + pr;
+            if (ows < a.W && oh0 + i < a.H)
+              __builtin_nontemporal_store(v, (Slot16*)(yrow0 + (size_t)i * a.W * a.y_cs + (size_t)ows * a.y_cs + sl * 8));
+          }
+          __builtin_amdgcn_wave_barrier();
+          BK_FENCE();
+        }
+      }
+    } else {
+    // ================= the tile in the 32 x 32 x 16 form ===============================================================================
     unsigned z0 = 0u;
     asm volatile("" : "+v"(z0));      // (opaque zero: k_conv3.h explains why the operand tuples must not be loop invariant)
     const unsigned one2 = hi ? z0 : H16<DT>::ONE * 0x10001u;
@@ -440,8 +685,15 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
         BK_FENCE();
       }
     }
+    }   // !M16
   }
   __builtin_amdgcn_s_waitcnt(RD_VMCNT_IMM(0));      // the dummy tail fetches target this workgroup's LDS: retire them before it is released
+#undef BK_C2M
+#undef BK_C1M
+#undef BK_STEP16
+#undef BK_MM16
+#undef BK_RDP16
+#undef BK_RDW16
 #undef BK_C2
 #undef BK_P1
 #undef BK_C1
@@ -458,6 +710,26 @@ __global__ __launch_bounds__(256, 2) void block64_stream_kernel(BlockArgs a) {
 inline bool block64_first(int cin) { return cin <= 16; }
 inline size_t block64_body_bytes(int cin) { return (size_t)bk_nsteps(block64_first(cin)) * BK_SLAB; }
 inline size_t block64_packed_bytes(int cin) { return block64_body_bytes(cin) + RD_CONV_TAIL; }
+// ... for the M16 form (cin = 64 only): both convs as pack_taps_frag16
+inline void pack_block64_m16(const float* w1, const float* s1, const float* w2, const float* s2, int dt, void* out) {
+  memset(out, 0, block64_packed_bytes(64));
+  pack_taps_frag16(9, 64, 64, out, [&](int co, int ci, int t) { return (s1 ? s1[co] : 1.f) * w1[((size_t)co * 64 + ci) * 9 + t]; }, dt);
+  pack_taps_frag16(9, 64, 64, (unsigned char*)out + 18 * BK_SLAB, [&](int co, int ci, int t) { return (s2 ? s2[co] : 1.f) * w2[((size_t)co * 64 + ci) * 9 + t]; }, dt);
+}
+// the 1x1 projection shortcut 64 -> 64 of the M16 form: [32-channel k-step (2)][16-channel fragment (4)][64 lanes][8], lane (mm, q) holds
+// scale[co] * w[co = conv_row16(cb, mm)][ci = 32 ks + 8 q + j]   (8 KB, like pack_sc_frag)
+inline void pack_sc_frag16(const float* w, const float* scale, void* out, int dt = RD_BF16) {
+  bf16_t* o = (bf16_t*)out;
+  for (int ks = 0; ks < 2; ++ks)
+    for (int cb = 0; cb < 4; ++cb)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = conv_row16(cb, lane & 15);
+        for (int j = 0; j < 8; ++j) {
+          const int ci = 32 * ks + 8 * (lane >> 4) + j;
+          *o++ = h16_from_f32(dt, (scale ? scale[co] : 1.f) * w[(size_t)co * 64 + ci]);
+        }
+      }
+}
 inline void pack_block64(const float* w1, const float* s1, const float* w2, const float* s2, int cin, int dt, void* out) {
   memset(out, 0, block64_packed_bytes(cin));
   if (block64_first(cin))
@@ -469,9 +741,10 @@ inline void pack_block64(const float* w1, const float* s1, const float* w2, cons
 }
 
 inline int launch_block64(const void* x, int x_cs, int x_co, int cin, const void* w, const float* shift1, const float* shift2, const void* sc_w,
-                          void* y, int y_cs, int y_co, int B, int H, int W, int dt, hipStream_t st) {
+                          void* y, int y_cs, int y_co, int B, int H, int W, int dt, hipStream_t st, bool m16 = false) {
   RD_REQUIRE(is_h16(dt), RD_EINVAL, "block64: dtype %d (RD_BF16 or RD_F16)", dt);
   const bool first = block64_first(cin);
+  RD_REQUIRE(!m16 || !first, RD_ESHAPE, "block64: the 16 x 16 x 32 form takes 64 input channels");
   RD_REQUIRE(cin == 64 || (first && cin >= 1), RD_ESHAPE, "block64: %d input channels (64, or at most 16 for the network's first block)", cin);
   RD_REQUIRE(!first || sc_w, RD_EINVAL, "block64: a block that changes the channel count needs its projection shortcut");
   BlockArgs a;
@@ -491,10 +764,14 @@ inline int launch_block64(const void* x, int x_cs, int x_co, int cin, const void
     allow_big_lds(block64_stream_kernel<RD_F16, false>); allow_big_lds(block64_stream_kernel<RD_BF16, false>);
     allow_big_lds(block64_stream_kernel<RD_F16, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true>);
     allow_big_lds(block64_stream_kernel<RD_F16, true, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true, true>);
+    allow_big_lds(block64_stream_kernel<RD_F16, false, false, true>); allow_big_lds(block64_stream_kernel<RD_BF16, false, false, true>);
+    allow_big_lds(block64_stream_kernel<RD_F16, true, false, true>); allow_big_lds(block64_stream_kernel<RD_BF16, true, false, true>);
   });
 #define BK_GO(DT_)                                                                                                         \
   {                                                                                                                        \
-    if (first) hipLaunchKernelGGL((block64_stream_kernel<DT_, true, true>), dim3(grid), dim3(256), BK_LDS, st, a);         \
+    if (m16 && sc_w) hipLaunchKernelGGL((block64_stream_kernel<DT_, true, false, true>), dim3(grid), dim3(256), BK_LDS, st, a);  \
+    else if (m16) hipLaunchKernelGGL((block64_stream_kernel<DT_, false, false, true>), dim3(grid), dim3(256), BK_LDS, st, a);    \
+    else if (first) hipLaunchKernelGGL((block64_stream_kernel<DT_, true, true>), dim3(grid), dim3(256), BK_LDS, st, a);    \
     else if (sc_w) hipLaunchKernelGGL((block64_stream_kernel<DT_, true>), dim3(grid), dim3(256), BK_LDS, st, a);           \
     else hipLaunchKernelGGL((block64_stream_kernel<DT_, false>), dim3(grid), dim3(256), BK_LDS, st, a);                    \
   }

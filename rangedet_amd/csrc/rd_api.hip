@@ -350,6 +350,30 @@ int rd_block64_bn_act(const void* x, int x_cstride, int x_coff, int cin, const v
   return launch_block64(x, x_cstride, x_coff, cin, w_packed, shift1, shift2, sc_w_packed, y, y_cstride, y_coff, B, H, W, dtype, (hipStream_t)stream);
 }
 
+// ... in the 16 x 16 x 32 MFMA form (k_block.h M16; 64 input channels): its own weight images, the same results
+int rd_pack_block64_m16_host(const float* w1, const float* fold_scale1, const float* w2, const float* fold_scale2, int dtype, void* out) {
+  RD_REQUIRE(w1 && w2 && out, RD_EINVAL, "pack_block64_m16: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_block64_m16: dtype %d (RD_BF16 or RD_F16)", dtype);
+  pack_block64_m16(w1, fold_scale1, w2, fold_scale2, dtype, out);
+  return RD_OK;
+}
+int rd_pack_conv1x1_sc_m16_host(const float* w, const float* fold_scale, int dtype, void* out) {
+  RD_REQUIRE(w && out, RD_EINVAL, "pack_conv1x1_sc_m16: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "pack_conv1x1_sc_m16: dtype %d (RD_BF16 or RD_F16)", dtype);
+  pack_sc_frag16(w, fold_scale, out, dtype);
+  return RD_OK;
+}
+int rd_block64_m16_bn_act(const void* x, int x_cstride, int x_coff, const void* w_packed, const float* shift1, const float* shift2,
+                          const void* sc_w_packed, void* y, int y_cstride, int y_coff, int B, int H, int W, int dtype, void* stream) {
+  RD_REQUIRE(x && w_packed && shift1 && shift2 && y, RD_EINVAL, "block64_m16: null pointer");
+  RD_REQUIRE(is_h16(dtype), RD_EINVAL, "block64_m16: dtype %d (RD_BF16 or RD_F16)", dtype);
+  RD_REQUIRE(B > 0 && H > 0 && W > 0, RD_ESHAPE, "block64_m16: shape");
+  RD_REQUIRE(x_cstride % 8 == 0 && x_coff % 8 == 0 && x_coff >= 0 && x_coff + 64 <= x_cstride, RD_ESHAPE, "block64_m16: x channel stride / offset");
+  RD_REQUIRE(y_cstride % 8 == 0 && y_coff % 8 == 0 && y_coff >= 0 && y_coff + 64 <= y_cstride, RD_ESHAPE, "block64_m16: y channel stride / offset");
+  RD_REQUIRE(x != y, RD_EINVAL, "block64_m16: in-place (a tile's halo is another tile's output)");
+  return launch_block64(x, x_cstride, x_coff, 64, w_packed, shift1, shift2, sc_w_packed, y, y_cstride, y_coff, B, H, W, dtype, (hipStream_t)stream, true);
+}
+
 // ---- 3x3 conv over the channel concatenation [x1 | x2] of two tensors that is never materialised (16-bit, folded scales) -----------
 // dla_backbone.py:153-154 (concat of the range image with the agg3 feature map) feeding head/builder.py:221-240: w_packed is
 // rd_pack_conv3x3_cat_host of the weight whose input channels are laid out [cin1 channels of x1 | cin2 channels of x2].

@@ -76,6 +76,10 @@ SIGNATURES = {
                                          c_int, c_void_p]),
     "rd_block64_packed_bytes": (c_size_t, [c_int]),
     "rd_pack_block64_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rd_pack_block64_m16_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rd_pack_conv1x1_sc_m16_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "rd_block64_m16_bn_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
     "rd_block64_bn_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "rd_head_packed_bytes": (c_size_t, []),
@@ -228,15 +232,27 @@ class Lib:
         self.call("rd_pack_conv1x1_sc_host", w.ctypes.data, None if fs is None else fs.ctypes.data, cout, cin, dtype, out.ctypes.data)
         return out
 
-    def pack_block64(self, w1_oihw, scale1, w2_oihw, scale2, dtype=RD_BF16):
+    def pack_block64(self, w1_oihw, scale1, w2_oihw, scale2, dtype=RD_BF16, m16=False):
         """weights of rd_block64_bn_act: the two 3x3 convs of a BasicBlock, (64, cin, 3, 3) with cin = 64 or <= 16 and (64, 64, 3, 3), with
-        their BatchNorm scales folded in"""
+        their BatchNorm scales folded in.  m16: the image of rd_block64_m16_bn_act (cin = 64)"""
         w1, w2 = (np.ascontiguousarray(w, dtype=np.float32) for w in (w1_oihw, w2_oihw))
         s1, s2 = (np.ascontiguousarray(v, dtype=np.float32) for v in (scale1, scale2))
         cin = w1.shape[1]
         assert w1.shape == (64, cin, 3, 3) and w2.shape == (64, 64, 3, 3) and s1.shape == (64,) and s2.shape == (64,)
         out = np.zeros(self.cdll.rd_block64_packed_bytes(cin), dtype=np.uint8)
-        self.call("rd_pack_block64_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, cin, dtype, out.ctypes.data)
+        if m16:
+            assert cin == 64
+            self.call("rd_pack_block64_m16_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, dtype, out.ctypes.data)
+        else:
+            self.call("rd_pack_block64_host", w1.ctypes.data, s1.ctypes.data, w2.ctypes.data, s2.ctypes.data, cin, dtype, out.ctypes.data)
+        return out
+
+    def pack_conv1x1_sc_m16(self, w_oi, fold_scale, dtype=RD_BF16):
+        """projection shortcut 64 -> 64 of rd_block64_m16_bn_act"""
+        w = np.ascontiguousarray(w_oi, dtype=np.float32).reshape(64, 64)
+        fs = np.ascontiguousarray(fold_scale, dtype=np.float32)
+        out = np.zeros(self.cdll.rd_conv1x1_sc_packed_bytes(64, 64), dtype=np.uint8)
+        self.call("rd_pack_conv1x1_sc_m16_host", w.ctypes.data, fs.ctypes.data, dtype, out.ctypes.data)
         return out
 
     def pack_deconv_weight(self, w_iohw, stride_w, pad_w, phase, dtype, fold_scale=None):

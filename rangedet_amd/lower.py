@@ -111,11 +111,14 @@ class Lowering:
         the backbone -- head/builder.py:221-240,
         dla_backbone.py:18-56) are launched in the v_mfma_f32_16x16x32 form of the persistent kernel (RD_MFMA16, k_conv3.h M16): the
         same numbers bit for bit, 3 - 6 % less time from W = 664 up because the part sustains a higher clock on that instruction
-        (DESIGN.md 6.3, round 6).  Step key "m16": the executor packs with rd_pack_conv3x3_m16_host and passes the flag.
-        RD_NO_MFMA16=1 (development switch): off."""
+        (DESIGN.md 6.3, round 6); likewise the fused 64-channel BasicBlocks with 64 input channels (rd_block64_m16_bn_act).  Step key
+        "m16": the executor packs with rd_pack_conv3x3_m16_host / rd_pack_block64_m16_host and passes the flag / calls that entry.
+        RD_NO_MFMA16=1 (development switch): off; RD_NO_MFMA16_BLOCK=1: only the blocks off."""
         if not self.h16 or devswitch.get("RD_NO_MFMA16"):
             return
         for st in self.plan.steps:
+            if st["kind"] == "block" and st["a"]["cin"] == 64 and not devswitch.get("RD_NO_MFMA16_BLOCK"):
+                st["m16"] = True          # the fused 64-channel BasicBlocks too (rd_block64_m16_bn_act; not the network's first block)
             if st["kind"] == "conv" and tuple(st["k"]) == (3, 3) and st["cout"] == 128 and st["stride_w"] == 1 and st.get("ex") and \
                     st.get("fold") and not st.get("sc") and st.get("x2") is None and not st.get("s2view"):
                 cin = len(st["cmap"]) if st.get("cmap") else st["cin"]

@@ -170,7 +170,9 @@ class Executor:
                         wp[:, pc] = w1[:, lc]
                 w1 = wp
             (s1, t1), (s2, t2) = bn_affine(P, ca["bn"], ca["eps"]), bn_affine(P, cb["bn"], cb["eps"])
-            b["w"] = A.upload(L.pack_block64(w1, s1, w2, s2, dtype=dt))
+            m16 = bool(st.get("m16")) and w1.shape[1] == 64      # the 16 x 16 x 32 MFMA form (lower._mark_mfma16): its own weight images
+            b["m16"] = m16
+            b["w"] = A.upload(L.pack_block64(w1, s1, w2, s2, dtype=dt, m16=m16))
             b["shift1"] = A.upload(t1)
             b["sc_w"] = None
             if cb.get("sc"):
@@ -183,7 +185,7 @@ class Executor:
                             wq[:, pc] = wsc[:, lc]
                     wsc = wq
                 ss, ts = bn_affine(P, sc["bn"], sc["eps"])
-                b["sc_w"] = A.upload(L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
+                b["sc_w"] = A.upload(L.pack_conv1x1_sc_m16(wsc, ss, dtype=dt) if m16 else L.pack_conv1x1_sc(wsc, fold_scale=ss, dtype=dt))
                 t2 = (t2.astype(np.float64) + ts).astype(np.float32)
             b["shift2"] = A.upload(t2)
             b["cin"] = w1.shape[1]
@@ -309,8 +311,12 @@ class Executor:
                 L.call("rd_nchw_to_nhwc", A.ptr(src), self.p(o), B, o.C, o.H, o.W, o.cs, o.co, b["zero_pad"], dt, st_)
             elif k == "block":
                 x, o = b["x"], b["out"]
-                L.call("rd_block64_bn_act", self.p(x), x.cs, x.co, b["cin"], A.ptr(b["w"]), A.ptr(b["shift1"]), A.ptr(b["shift2"]),
-                       A.ptr(b["sc_w"]) if b["sc_w"] is not None else None, self.p(o), o.cs, o.co, B, x.H, x.W, dt, st_)
+                if b.get("m16"):
+                    L.call("rd_block64_m16_bn_act", self.p(x), x.cs, x.co, A.ptr(b["w"]), A.ptr(b["shift1"]), A.ptr(b["shift2"]),
+                           A.ptr(b["sc_w"]) if b["sc_w"] is not None else None, self.p(o), o.cs, o.co, B, x.H, x.W, dt, st_)
+                else:
+                    L.call("rd_block64_bn_act", self.p(x), x.cs, x.co, b["cin"], A.ptr(b["w"]), A.ptr(b["shift1"]), A.ptr(b["shift2"]),
+                           A.ptr(b["sc_w"]) if b["sc_w"] is not None else None, self.p(o), o.cs, o.co, B, x.H, x.W, dt, st_)
             elif k == "conv_pair":
                 # two convs of one shape in ONE launch (lower._pair_equal_convs: the cls and reg tower conv of a head level)
                 p, q = b["a"], b["b"]

@@ -779,6 +779,15 @@ def test_block64_equals_the_two_launches(be, case):
     L.call("rd_block64_bn_act", be.ptr(dx), xcs, 0, cin, be.ptr(pk), be.ptr(d1), be.ptr(d2), be.ptr(psc) if proj else None, be.ptr(y), 64, 0, B, H, W, dt, be.stream)
     got, two = be.down(y, np.uint16, (B, H, W, 64)), be.down(yr, np.uint16, (B, H, W, 64))
     assert np.array_equal(got, two), int((got != two).sum())
+    if cin == 64:
+        # ... and its 16 x 16 x 32 MFMA form (rd_block64_m16_bn_act, round 6): the same bits once more
+        y16 = be.empty(B * H * W * 64 * 2)
+        pk16 = be.up(L.pack_block64(w1, s1, w2, s2, dtype=dt, m16=True))
+        psc16 = be.up(L.pack_conv1x1_sc_m16(wsc, ss, dtype=dt)) if proj else None
+        L.call("rd_block64_m16_bn_act", be.ptr(dx), xcs, 0, be.ptr(pk16), be.ptr(d1), be.ptr(d2), be.ptr(psc16) if proj else None, be.ptr(y16), 64, 0,
+               B, H, W, dt, be.stream)
+        got16 = be.down(y16, np.uint16, (B, H, W, 64))
+        assert np.array_equal(got16, two), int((got16 != two).sum())
     # ... and the pair itself against torch, conv by conv on the device's own intermediate (one output rounding each)
     tq = from_nhwc(be.down(t, np.uint16, (B, H, W, 64)), dt, 64)
     w1q, w2q = h16_round(w1 * s1[:, None, None, None], dt), h16_round(w2 * s2[:, None, None, None], dt)
