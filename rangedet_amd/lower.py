@@ -106,13 +106,14 @@ class Lowering:
 
     # ---- fusion ------------------------------------------------------------------------------------------------
     def _mark_mfma16(self):
-        """16-bit: the plain stride-1 3x3 convs with 128 output channels (tower conv_1 / conv_2 of every head level, conv_0 of the
-        levels whose input is 64 / 128 channels, the last tower convs with their fused output conv, the 128-channel BasicBlock convs of
-        the backbone -- head/builder.py:221-240,
-        dla_backbone.py:18-56) are launched in the v_mfma_f32_16x16x32 form of the persistent kernel (RD_MFMA16, k_conv3.h M16): the
-        same numbers bit for bit, 3 - 6 % less time from W = 664 up because the part sustains a higher clock on that instruction
-        (DESIGN.md 6.3, round 6); likewise the fused 64-channel BasicBlocks with 64 input channels (rd_block64_m16_bn_act).  Step key
-        "m16": the executor packs with rd_pack_conv3x3_m16_host / rd_pack_block64_m16_host and passes the flag / calls that entry.
+        """16-bit: the stride-1 3x3 convs with 128 output channels and no fused shortcut (tower conv_1 / conv_2 of every head level, conv_0
+        of the levels whose input is 64 / 128 channels, the last tower convs with their fused output conv, the 128-channel BasicBlock
+        convs of the backbone -- head/builder.py:221-240, dla_backbone.py:18-56) are launched in the v_mfma_f32_16x16x32 form of the
+        persistent kernel (RD_MFMA16, k_conv3.h M16): the conv's numbers bit for bit (a fused output conv sums in another order: fp32
+        rounding level), 3 - 6 % less time from W = 664 up because the part sustains a higher clock on that instruction under its power
+        cap; likewise the fused 64-channel BasicBlocks with 64 input channels (rd_block64_m16_bn_act,
+        bit-identical).  Step key "m16" is a request: the executor asks rd_conv3x3_mfma16_ok, packs with rd_pack_conv3x3_m16_host /
+        rd_pack_head_weight_m16_host / rd_pack_block64_m16_host and passes the flag / calls that entry.
         RD_NO_MFMA16=1 (development switch): off; RD_NO_MFMA16_BLOCK=1: only the blocks off."""
         if not self.h16 or devswitch.get("RD_NO_MFMA16"):
             return
@@ -123,7 +124,7 @@ class Lowering:
                     st.get("fold") and not st.get("sc") and st.get("x2") is None and not st.get("s2view"):
                 cin = len(st["cmap"]) if st.get("cmap") else st["cin"]
                 if cin % 32 == 0 and cin >= 32:
-                    st["m16"] = True      # (a request: the executor asks rd_conv3x3_mfma16_ok -- e.g. a full-width fused output conv stays as it was)
+                    st["m16"] = True
 
     def _pair_equal_convs(self):
         """16-bit: two 3x3 convs of the SAME shape whose inputs are both ready run as ONE launch (rd_conv3x3_bn_act_pair /
