@@ -65,3 +65,17 @@ for W in (2656, 1328):
     loop("conv 64->64 W%d" % W,
          lambda: L.call("rd_conv3x3_bn_act_ex", x6.data_ptr(), 64, 0, wc.data_ptr(), None, sh64.data_ptr(), None, 0, 0, None, 0, 0, 0, None,
                         y6.data_ptr(), 64, 0, B, H, W, 64, 64, 1, R.RD_RELU_POST | R.RD_SCALE_FOLDED, dt, st), 2.0 * B * H * W * 64 * 64 * 9)
+
+# the fused Meta-Kernel unit at the production shape
+from rangedet_amd import synth  # noqa: E402
+from rangedet_amd.runtime import TorchAllocator, bn_affine  # noqa: E402
+A = TorchAllocator()
+P = synth.make_weights(seed=18)
+name, pre = 'res1_unit2', 'res1_unit2_%d' % 2656
+s1, t1 = bn_affine(P, name + "point_wise_mlp_bn1", 1e-5 + 1e-10)
+s2, t2 = bn_affine(P, name + "aggregation_bn1", 1e-5 + 1e-10)
+pk = A.upload(L.pack_meta(P[pre + "_mlp0_weight"].reshape(32, 3), P[pre + "_mlp0_bias"], P[pre + "_mlp1_weight"].reshape(64, 32),
+                          P[pre + "_mlp1_bias"], s1, t1, P[name + "aggregation_conv1_weight"].reshape(64, 576), s2, t2, dt))
+xm, cm = act(64, 2656), torch.randn(B, 3, H, 2656, device="cuda")
+ym = torch.empty(B, H, 2656, 64, device="cuda", dtype=torch.bfloat16)
+loop("meta unit W2656", lambda: L.call("rd_meta_kernel_fwd", xm.data_ptr(), 64, 0, cm.data_ptr(), A.ptr(pk), ym.data_ptr(), 64, 0, B, H, 2656, dt, A.stream), B * 19.29e9)
