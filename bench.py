@@ -268,6 +268,9 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (BASELINE config 4: 64 frames over 8 GPUs = 8 per GPU)")
     ap.add_argument("--tie-order", default="reference", choices=["reference", "stable"],
                     help="processing order of equal scores in the weighted NMS: the reference's std::sort order (default) or index order")
+    ap.add_argument("--h2d", action="store_true",
+                    help="PCIe-inclusive diagnostic (never the headline): every step first uploads its batch's input tensors from pinned host "
+                         "memory on the batch's launch stream, instead of reading inputs resident in HBM (DESIGN.md section 6)")
     ap.add_argument("--graph", action="store_true",
                     help="hipGraph replay: every pipeline captures its ~80 launches per batch once per input set and replays them with one call "
                          "(pipeline.RangeDetPipeline(graph=True)); same results (config.results_sha256_all_steps), ~1 ms less host work per step")
@@ -354,6 +357,15 @@ def main(argv=None):
         frames = [synth.make_batch(shard.frames_of_step(i, Bf), lib=pipe.lib, alloc=pipe.alloc) for i in range(args.frames)]
     L = pipe.lib
     A = pipe.alloc
+    h2d_mb = None
+    if args.h2d:
+        # PCIe-inclusive diagnostic: pinned host copies of every batch, one device input set per pipeline (a pipeline's previous batch
+        # has been harvested before its inputs are overwritten), uploaded on the batch's launch stream in front of its forward
+        if args.graph:
+            raise SystemExit("bench.py: --h2d replays no graph (the upload is an eager copy in front of the forward)")
+        host_in = [{k: v.cpu().pin_memory() for k, v in f.items()} for f in frames]
+        dev_in = [{k: torch.empty_like(v) for k, v in frames[0].items()} for _ in multi.pipes]
+        h2d_mb = sum(v.numel() * v.element_size() for v in frames[0].values()) / 1e6
     # one gather per pipeline and class (the two-class KITTI variant has two post-processors per pipeline)
     gathers = [[rdist.DetectionGather(p.bposts[c], shard, A, L) for c in p.class_names] for p in multi.pipes] if gather else None
     comm_streams = [torch.cuda.Stream(device=dev) for _ in multi.pipes] if gather else None   # one communication stream per pipeline
@@ -400,7 +412,13 @@ def main(argv=None):
         # (two batches in flight: the other batch's launches fill the tails / launch gaps of this one)
         j = i % len(multi.pipes)
         harvest(j)                                         # the batch that last used this pipeline (two steps ago)
-        j2, _ = multi.enqueue(frames[i % len(frames)])
+        if args.h2d:
+            with multi.stream_context(j):
+                for k, v in host_in[i % len(frames)].items():
+                    dev_in[j][k].copy_(v, non_blocking=True)
+            j2, _ = multi.enqueue(dev_in[j])
+        else:
+            j2, _ = multi.enqueue(frames[i % len(frames)])
         assert j2 == j
         pj, h = multi.pipes[j], host[j]
         with torch.cuda.stream(pj._post_stream):
@@ -638,6 +656,8 @@ def main(argv=None):
                                      for c, r in res.get("per_class", {}).items()} or None,
                        "hip_graph": {"replays": int(sum(p_.graph_replays for p_ in multi.pipes)), "graphs": int(sum(len(p_._graphs) for p_ in multi.pipes))} if args.graph else None,
                        "wnms_cap": int(pipe.bpost.cap), "wnms_tie_order": args.tie_order, "max_candidates_seen": int(max_cand[0]),
+                       "inputs": ("uploaded every step from pinned host memory on the batch's launch stream: %.1f MB per step (PCIe-inclusive diagnostic)" % h2d_mb
+                                  if args.h2d else "resident in HBM before the timed region"),
                        "results_to_host": "every step: (B,200,8) boxes + counts, async D2H on the post-processing stream into pinned memory, K <= cap checked",
                        "gathered_frames_last_step": gathered_frames, "gather_matches_local": gather_matches_local,
                        "results_sha256_last_step": results_sha256, "results_sha256_all_steps": all_steps_sha.hexdigest()[:16],
