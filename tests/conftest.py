@@ -10,9 +10,33 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _auto_parallel(config):
+    """The CPU tier (`-m "not gpu"`: the unmodified HIP sources under the CPU emulator) takes 22 min in one process and 6.5 min in four.
+    When exactly that tier is asked for without any distribution option and pytest-xdist is importable, run it on four workers -- the same
+    as `-n 4` on the command line (RD_PYTEST_SERIAL=1 keeps one process).  The GPU tier is never touched: one process, one GPU, and the
+    library the tests load is mapped into THAT process."""
+    opt = config.option
+    if os.environ.get("RD_PYTEST_SERIAL") or hasattr(config, "workerinput") or not config.pluginmanager.hasplugin("xdist"):
+        return
+    if getattr(opt, "numprocesses", None) is not None or getattr(opt, "dist", "no") != "no" or getattr(opt, "tx", None):
+        return
+    if (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return
+    n = min(4, os.cpu_count() or 1)
+    if n < 2:
+        return
+    try:                                    # build the emulator library ONCE, here, before the workers start
+        from emu_util import emu_lib
+        emu_lib()
+    except Exception:                       # (a broken build fails in the tests that need it, with their own message)
+        pass
+    opt.numprocesses, opt.dist, opt.tx = n, "load", ["popen"] * n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: full-size case")
+    _auto_parallel(config)
 
 
 class Backend:

@@ -19,7 +19,11 @@ def emu_lib():
         srcs.append(os.path.join(_HERE, "emu", "hip", "hip_runtime.h"))
         newest = max(os.path.getmtime(s) for s in srcs)
         if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < newest:
-            subprocess.check_call([os.path.join(_HERE, "emu", "build_emu.sh")])
+            import fcntl
+            with open(EMU_SO + ".lock", "w") as lk:           # pytest-xdist workers: one of them builds, the others wait and re-check
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < newest:
+                    subprocess.check_call([os.path.join(_HERE, "emu", "build_emu.sh")])
         _EMU = rdlib.Lib(EMU_SO)
     return _EMU
 
