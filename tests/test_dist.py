@@ -336,6 +336,13 @@ def test_bench_results_independent_of_block_fusion():
         hg = g["config"]["hip_graph"]
         assert hg["graphs"] >= 2 and hg["replays"] >= 100, hg
         assert g["config"]["results_sha256_all_steps"] == a["config"]["results_sha256_all_steps"]
+    # ... and of the same steps with every batch's inputs uploaded from pinned host memory in front of its forward (--h2d, the PCIe-inclusive
+    # diagnostic: one device input set per pipeline, overwritten only after that pipeline's previous batch has been harvested)
+    r = subprocess.run(cmd + ["--h2d"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    u = _json_line(r.stdout)
+    assert u["config"]["inputs"].startswith("uploaded every step") and a["config"]["inputs"].startswith("resident")
+    assert u["config"]["results_sha256_all_steps"] == a["config"]["results_sha256_all_steps"]
     assert a["config"]["wnms_kept"] == b["config"]["wnms_kept"] > 0 and a["meta_dla_forward"] is None
 
 
