@@ -366,6 +366,12 @@ def main(argv=None):
         host_in = [{k: v.cpu().pin_memory() for k, v in f.items()} for f in frames]
         dev_in = [{k: torch.empty_like(v) for k, v in frames[0].items()} for _ in multi.pipes]
         h2d_mb = sum(v.numel() * v.element_size() for v in frames[0].values()) / 1e6
+    gmode = os.environ.get("RD_BENCH_GATHER_MODE", "") if gather else ""
+    if gmode in ("pack", "copy", "packonly"):
+        # experiment (tools/exp/r6o_gather_cost.sh): what of the collective path costs frames/s on ONE GPU?  "pack": the pack copies, the
+        # event and the communication stream's wait, but no collective; "copy": the collective replaced by a device copy on that stream
+        _real_ag = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = (lambda dst, src, **kw: None) if gmode in ("pack", "packonly") else (lambda dst, src, **kw: dst[:src.numel()].copy_(src))
     # one gather per pipeline and class (the two-class KITTI variant has two post-processors per pipeline)
     gathers = [[rdist.DetectionGather(p.bposts[c], shard, A, L) for c in p.class_names] for p in multi.pipes] if gather else None
     comm_streams = [torch.cuda.Stream(device=dev) for _ in multi.pipes] if gather else None   # one communication stream per pipeline
@@ -436,7 +442,20 @@ def main(argv=None):
                 # launch stream with two or more batches in flight), but ENQUEUED ON THE PIPELINE'S COMMUNICATION STREAM behind the pack's
                 # event -- no launch stream carries a collective, so a late rank delays only this batch's harvest, not the kernels behind it
                 for g_ in gathers[j]:
-                    done_on = g_.enqueue(pj._post_stream, comm_streams[j])
+                    if gmode == "packonly":                 # experiment: the pack copies alone, everything on the launch stream
+                        done_on = g_.enqueue(pj._post_stream, None)
+                    elif gmode == "evonly":                 # experiment: event + communication-stream wait alone
+                        A.wait_event(A.record_event(pj._post_stream), comm_streams[j])
+                        done_on = comm_streams[j]
+                    elif gmode == "evwait":                 # experiment: the communication stream waits, but the batch's done event stays on the launch stream
+                        A.wait_event(A.record_event(pj._post_stream), comm_streams[j])
+                    elif gmode == "evlate":                 # experiment: the wait of the PREVIOUS batch of this pipeline, enqueued now that its event has fired
+                        if h.get("e1") is not None:
+                            A.wait_event(h["e1"], comm_streams[j])
+                            torch.cuda.Event().record(comm_streams[j])
+                        h["e1"] = A.record_event(pj._post_stream)
+                    elif gmode != "init":                   # ("init": communicator up, no per-step collective -- experiment)
+                        done_on = g_.enqueue(pj._post_stream, comm_streams[j])
             h["done"] = torch.cuda.Event(enable_timing=True)
             h["done"].record(done_on)
             h["step"] = i
