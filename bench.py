@@ -366,12 +366,11 @@ def main(argv=None):
         host_in = [{k: v.cpu().pin_memory() for k, v in f.items()} for f in frames]
         dev_in = [{k: torch.empty_like(v) for k, v in frames[0].items()} for _ in multi.pipes]
         h2d_mb = sum(v.numel() * v.element_size() for v in frames[0].values()) / 1e6
-    gmode = os.environ.get("RD_BENCH_GATHER_MODE", "") if gather else ""
-    if gmode in ("pack", "copy", "packonly"):
-        # experiment (tools/exp/r6o_gather_cost.sh): what of the collective path costs frames/s on ONE GPU?  "pack": the pack copies, the
-        # event and the communication stream's wait, but no collective; "copy": the collective replaced by a device copy on that stream
-        _real_ag = dist.all_gather_into_tensor
-        dist.all_gather_into_tensor = (lambda dst, src, **kw: None) if gmode in ("pack", "packonly") else (lambda dst, src, **kw: dst[:src.numel()].copy_(src))
+    # RD_BENCH_GATHER_MODE=eager (A/B only): the collective enqueued WITH the batch, its communication stream waiting for the pack's event from
+    # then on (DetectionGather.enqueue) -- the form of the first session of round 6, 7 % slower (profiles/r06o_gather_path_cost_bisect.txt)
+    gather_eager = gather and os.environ.get("RD_BENCH_GATHER_MODE", "") == "eager"
+    from collections import deque
+    gather_pending = deque()        # (step, pipeline) of the batches whose pack is enqueued and whose collective is not: strictly in step order
     # one gather per pipeline and class (the two-class KITTI variant has two post-processors per pipeline)
     gathers = [[rdist.DetectionGather(p.bposts[c], shard, A, L) for c in p.class_names] for p in multi.pipes] if gather else None
     comm_streams = [torch.cuda.Stream(device=dev) for _ in multi.pipes] if gather else None   # one communication stream per pipeline
@@ -391,6 +390,22 @@ def main(argv=None):
     all_steps_sha = hashlib.sha256()      # every harvested step's host results (boxes of the kept detections, keep counts), in step order
     step_digests = []
 
+    def issue_gathers(upto=None):
+        """Enqueue the collectives of the batches whose done event has fired, oldest first and never out of step order (every rank issues the
+        same sequence); upto = a step whose collective must be out when this returns (its event is waited for)."""
+        while gather_pending:
+            st_, j_ = gather_pending[0]
+            ev_ = host[j_]["done_ev"]
+            if upto is not None and st_ <= upto:
+                ev_.synchronize()
+            elif not ev_.query():
+                break
+            gather_pending.popleft()
+            for g_ in gathers[j_]:
+                g_.gather(comm_streams[j_])
+            host[j_]["gdone"] = torch.cuda.Event()
+            host[j_]["gdone"].record(comm_streams[j_])
+
     def harvest(j):
         """Host side of a finished batch: wait for its copies, check the WNMS capacity (K <= cap is what makes the
         device result the complete one), keep the largest candidate count for the report."""
@@ -398,6 +413,8 @@ def main(argv=None):
         if h["done"] is None:
             return None
         h["done"].synchronize()
+        if gather and not gather_eager:
+            issue_gathers(upto=h["step"])
         for c in classes:
             kmax = int(h[c]["count"].max())
             if kmax > multi.pipes[j].bposts[c].cap:
@@ -438,30 +455,33 @@ def main(argv=None):
                 hc["count"].copy_(A.view_i32(bp.count, (Bf,)), non_blocking=True)
             done_on = pj._post_stream
             if gather:
-                # the ONE collective of the path: packed behind this batch's post-processing on its post-processing stream (the batch's own
-                # launch stream with two or more batches in flight), but ENQUEUED ON THE PIPELINE'S COMMUNICATION STREAM behind the pack's
-                # event -- no launch stream carries a collective, so a late rank delays only this batch's harvest, not the kernels behind it
+                # the ONE collective of the path.  Its PACK (two strided copies) goes behind this batch's post-processing on its
+                # post-processing stream (the batch's own launch stream with two or more batches in flight) -- after the previous gather of
+                # this pipeline, which read the same record buffer (an event that fired n steps ago unless a peer rank is that late).  The
+                # COLLECTIVE runs on the pipeline's communication stream -- no launch stream carries a collective -- and is issued by the
+                # host once this batch's done event has fired (issue_gathers below), in step order on every rank: a communication stream
+                # that waits for the pack from now on parks a barrier packet in a hardware queue for the whole forward, and that alone costs
+                # 7 % of the throughput (RD_BENCH_GATHER_MODE=eager, profiles/r06o_gather_path_cost_bisect.txt)
+                if h.get("gdone") is not None and not gather_eager:
+                    pj._post_stream.wait_event(h["gdone"])
                 for g_ in gathers[j]:
-                    if gmode == "packonly":                 # experiment: the pack copies alone, everything on the launch stream
-                        done_on = g_.enqueue(pj._post_stream, None)
-                    elif gmode == "evonly":                 # experiment: event + communication-stream wait alone
-                        A.wait_event(A.record_event(pj._post_stream), comm_streams[j])
-                        done_on = comm_streams[j]
-                    elif gmode == "evwait":                 # experiment: the communication stream waits, but the batch's done event stays on the launch stream
-                        A.wait_event(A.record_event(pj._post_stream), comm_streams[j])
-                    elif gmode == "evlate":                 # experiment: the wait of the PREVIOUS batch of this pipeline, enqueued now that its event has fired
-                        if h.get("e1") is not None:
-                            A.wait_event(h["e1"], comm_streams[j])
-                            torch.cuda.Event().record(comm_streams[j])
-                        h["e1"] = A.record_event(pj._post_stream)
-                    elif gmode != "init":                   # ("init": communicator up, no per-step collective -- experiment)
+                    if gather_eager:
                         done_on = g_.enqueue(pj._post_stream, comm_streams[j])
+                    else:
+                        g_.pack(pj._post_stream)
+                if not gather_eager:
+                    gather_pending.append((i, j))
             h["done"] = torch.cuda.Event(enable_timing=True)
             h["done"].record(done_on)
+            h["done_ev"] = h["done"]           # (harvest() clears "done"; the pending collective of this batch keeps the event)
             h["step"] = i
             done_events.append(h["done"])      # (completion time of every step: the per-step percentiles of the report)
+        if gather and not gather_eager:
+            issue_gathers()                    # whatever has finished in the meantime (usually the batch before last)
 
     def barrier():
+        if gather and not gather_eager:
+            issue_gathers(upto=1 << 60)        # the collective of every enqueued batch is out (and, below, complete) inside the timed region
         torch.cuda.synchronize(dev)
         if gather:
             dist.barrier()

@@ -2,13 +2,16 @@
 collective -- the reference's eval driver does the same with one DetModule per GPU fed from a shared queue
 (tools/test.py:117-161).  The only exchange is the gather of the final detections, one `all_gather` of a fixed-size padded
 record per step (RCCL over xGMI on the GPUs: latency-only, 77 KB per rank for 8 frames).  The pack (two strided device copies) runs
-behind the batch's NMS on its post-processing stream; the COLLECTIVE runs on a communication stream of its own that waits for the
-pack's event (round 6): no launch stream ever carries a collective, so a rank that arrives late stalls only the peers' communication
-streams (and, through the completion event, the host's harvest of THAT batch), never the kernels of the batches behind it.
+behind the batch's NMS on its post-processing stream; the COLLECTIVE runs on a communication stream of its own (round 6): no launch
+stream ever carries a collective, so a rank that arrives late stalls only the peers' communication streams, never the kernels of the
+batches behind it.  The host issues the collective once the pack's event has FIRED (`gather()`), in step order on every rank, instead of
+parking a cross-stream wait on that stream when the batch is enqueued: a barrier packet that sits in a hardware queue for the 8 - 24 ms
+of a forward costs 7 % of the GPU's throughput by itself (third session of round 6, profiles/r06o_gather_path_cost_bisect.txt).
 
     shard    = FrameSharding(rank, world)             which frames are mine / where a gathered record belongs
     gatherer = DetectionGather(post, shard, alloc)    pack (rd_copy_rows) + all_gather of a BatchPostProcessor's results
-    gatherer.enqueue(stream, comm_stream)   ...   frames = gatherer.unpack()     # {global frame index: (rows (M,12), M)} on every rank
+    gatherer.pack(stream) ... (the pack's event has fired) ... gatherer.gather(comm_stream)   |   gatherer.enqueue(stream, comm_stream)
+    frames = gatherer.unpack()     # {global frame index: (rows (M,12), M)} on every rank
 
 The backend is whatever process group is initialised ("nccl" == RCCL on the GPUs; "gloo" in the CPU test tier, where the
 buffers are host memory and the same code runs).
@@ -176,30 +179,49 @@ class DetectionGather:
             return torch.from_numpy(buf[: int(np.prod(shape)) * 4].view(np.float32).reshape(shape))
         return self.A.view_f32(buf, shape)
 
-    def enqueue(self, stream=None, comm_stream=None):
-        """pack on `stream` (the batch's post-processing stream; None = current), then the collective on `comm_stream` behind the pack's
-        event (None: on `stream` itself -- host buffers / gloo, or a caller with a single stream).  Returns the stream whose completion
-        covers the gathered buffer (record the batch's done event THERE)."""
-        import torch.distributed as dist
+    def pack(self, stream=None):
+        """The two strided copies into the contiguous record buffer, on `stream` (the batch's post-processing stream, behind its NMS)."""
         A, L, p = self.A, self.L, self.post
         st = A.stream_ptr(stream) if hasattr(A, "stream_ptr") else A.stream
         L.call("rd_copy_rows", A.ptr(p.out), p.cap * 48, A.ptr(self.src), self.rec * 4, 0, self.nrow * 48, self.B, st)
         L.call("rd_copy_rows", A.ptr(p.nkeep), 4, A.ptr(self.src), self.rec * 4, self.max_det * 48, 4, self.B, st)
+
+    def gather(self, comm_stream=None):
+        """The ONE collective, enqueued on `comm_stream` (None: the current stream) WITHOUT any stream dependency: call it once the pack is
+        known to be complete -- the host has waited for (or polled) an event recorded behind `pack()`.  This is the form the timed pipeline
+        uses (bench.py): a communication stream that WAITS for the pack's event from the moment the batch is enqueued parks a barrier
+        packet in a hardware queue for the whole forward (8 - 24 ms), and that costs 7 % of the GPU's throughput whatever the collective
+        is (profiles/r06o_gather_path_cost_bisect.txt); issued after the fact the wait does not exist.  Every rank must issue its gathers in
+        the same (step, class) order.  Returns the stream whose completion covers the gathered buffer."""
+        import torch.distributed as dist
+        A = self.A
         src = self._as_torch(self.src, (self.B * self.rec,))
         dst = self._as_torch(self.dst, (self.shard.world * self.B * self.rec,))
-        if comm_stream is not None and hasattr(A, "torch"):
-            A.wait_event(A.record_event(stream), comm_stream)
+        if not hasattr(A, "torch"):
+            # host buffers (gloo): returns at once, unpack() waits for THIS gather only
+            self._work = dist.all_gather_into_tensor(dst, src, async_op=True)
+            return comm_stream
+        if comm_stream is not None:
             with A.torch.cuda.stream(comm_stream):
                 dist.all_gather_into_tensor(dst, src)
-            return comm_stream
-        if stream is not None and hasattr(A, "torch"):
-            with A.torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(dst, src)
-        elif hasattr(A, "torch"):
-            dist.all_gather_into_tensor(dst, src)
         else:
-            # host buffers (gloo): the same contract as on the GPU -- enqueue returns at once, unpack() waits for THIS gather only
-            self._work = dist.all_gather_into_tensor(dst, src, async_op=True)
+            dist.all_gather_into_tensor(dst, src)
+        return comm_stream
+
+    def enqueue(self, stream=None, comm_stream=None):
+        """pack on `stream` (the batch's post-processing stream; None = current), then the collective on `comm_stream` behind the pack's
+        event (None: on `stream` itself -- host buffers / gloo, or a caller with a single stream) -- everything enqueued at once, for a
+        caller that cannot come back later.  Returns the stream whose completion covers the gathered buffer (record the batch's done
+        event THERE).  On the GPU prefer pack() now and gather() once the pack's event has fired: see gather()."""
+        A = self.A
+        self.pack(stream)
+        if comm_stream is not None and hasattr(A, "torch"):
+            A.wait_event(A.record_event(stream), comm_stream)
+            return self.gather(comm_stream)
+        if stream is not None and hasattr(A, "torch"):
+            self.gather(stream)
+            return stream
+        self.gather(None)
         return stream
 
     def unpack(self, step=0, sync=True):

@@ -132,7 +132,8 @@ def _late_worker(rank, world, port, out):
     t0 = time.perf_counter()
     g0.enqueue()                 # rank 0: its peer has not arrived -- the enqueue must return, ...
     t_enq0 = time.perf_counter() - t0
-    g1.enqueue()                 # ... and so must the NEXT batch's (nothing queues up behind the first collective)
+    g1.pack()                    # ... and so must the NEXT batch's (nothing queues up behind the first collective) -- in the two-call form
+    g1.gather()                  #     the timed pipeline uses: pack behind the NMS, the collective once the pack's event has fired
     t_enq1 = time.perf_counter() - t0
     got0 = g0.unpack(0)          # only the harvest of batch 0 waits for the late rank
     t_done0 = time.perf_counter() - t0
