@@ -197,7 +197,12 @@ class RangeDetPipeline:
         self.max_graphs = 8
         self.graph_replays = 0
         self._post_stream = None
-        self.post_on_launch_stream = False       # one pipeline alone: score filter + NMS on a side stream (overlaps the next batch's forward)
+        # score filter + NMS on the stream the forward was launched on.  Rounds 1 - 4 used a side stream per pipeline (the NMS of batch i
+        # beside the forward of batch i + 1); with two or more batches in flight the other pipelines give that overlap anyway (round 5),
+        # and for ONE pipeline alone the side stream loses too (round 6: 846.5 vs 838.6 frames/s, profiles/r06o_single_pipeline_post_stream_ab.txt):
+        # its wait for the forward's event sits in a hardware queue for the whole forward, and a parked barrier packet slows every
+        # dispatch on the other queues.  RD_POST_SIDE_STREAM=1 (development switch) brings the side stream back.
+        self.post_on_launch_stream = not devswitch.get("RD_POST_SIDE_STREAM")
         self._filter_done = None
         self._post_done = None
         assert self.wnms or len(self.class_names) == 1, "the NMS3D branch is single-class (tools/test.py:182)"
@@ -341,16 +346,17 @@ class RangeDetPipeline:
 
 
 class InterleavedPipelines:
-    """`n` pipelines, each with its own launch stream (and its own post-processing side stream): successive batches
-    alternate between them, so two batches are in flight.  The persistent conv kernels give every CU a fixed list of
+    """`n` pipelines, each with its own launch stream (forward AND post-processing of a batch on it): successive batches
+    alternate between them, so n batches are in flight.  The persistent conv kernels give every CU a fixed list of
     tiles; when the tile count is not a multiple of the CU count (W = 1328 and W <= 332 levels) the tail of a launch leaves
-    CUs idle -- the other batch's launches fill those tails and the ~120 launch gaps per batch (measured +8 %, n = 2;
-    n = 3 is slower again).  The caller keeps a batch's input tensors alive until its results are collected."""
+    CUs idle -- the other batches' launches fill those tails and the ~80 launch gaps per batch (n = 2: +8 % in round 2; n = 3: another
+    +2 % since round 5; n = 4 gives nothing more, and needs GPU_MAX_HW_QUEUES > 4 not to lose: profiles/EXPERIMENTS.md, round 6).
+    The caller keeps a batch's input tensors alive until its results are collected."""
 
     def __init__(self, params, n=2, **kw):
         self.pipes = [RangeDetPipeline(params, **kw) for _ in range(n)]
         for p in self.pipes:      # (RD_POST_SIDE_STREAM=1: a side stream per pipeline as in rounds 1 - 4, for A/B runs)
-            p.post_on_launch_stream = n >= 2 and not devswitch.get("RD_POST_SIDE_STREAM")
+            p.post_on_launch_stream = not devswitch.get("RD_POST_SIDE_STREAM")
         A = self.pipes[0].alloc
         self.streams = [A.new_stream(priority=_stream_prio("RD_LAUNCH_STREAM_PRIO")) for _ in range(n)] if hasattr(A, "new_stream") else [None] * n
         self._i = 0
