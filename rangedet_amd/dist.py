@@ -66,6 +66,14 @@ def init_process_group(backend=None, device=None):
         if backend is None:
             backend = "nccl" if device is not None else "gloo"
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        if backend == "nccl":
+            # the collective's kernel runs on the process group's own stream: make that a HIGH-priority queue.  The persistent conv
+            # workgroups of the batches in flight fill every CU's LDS, so an RCCL kernel gets on the GPU only when one of them exits --
+            # a high-priority queue is served first at that moment instead of competing with three launch streams' next kernels
+            try:
+                kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:      # noqa: BLE001  (an older torch: the default stream priority)
+                pass
         dist.init_process_group(backend, **kw)
     return dist.get_rank(), dist.get_world_size()
 
