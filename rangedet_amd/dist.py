@@ -122,7 +122,13 @@ def device_identity(device):
     import hashlib
     import torch
     p = torch.cuda.get_device_properties(device)
-    ident = str(getattr(p, "uuid", "")) or str(getattr(p, "pci_bus_id", "")) or "%s/%d" % (p.name, device.index or 0)
+    # the PCI address (domain : bus : device) is unique per GPU of a node; the UUID too where its str() is the UUID itself (some torch
+    # builds print the wrapper object with its ADDRESS instead, which would make any two processes look distinct: left out then)
+    uu = str(getattr(p, "uuid", ""))
+    pci = [getattr(p, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    ident = "|".join([uu if " object at " not in uu else ""] + ["" if v is None else str(v) for v in pci])
+    if not ident.strip("|"):
+        ident = "%s/%d" % (p.name, device.index or 0)
     return hashlib.sha256((ident + "@" + os.uname().nodename).encode()).digest()[:16]
 
 
